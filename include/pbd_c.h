@@ -1,0 +1,211 @@
+/*
+ * pbd_c.h — C ABI of libpbd_hip.so: the MI355X (gfx950) inference path behind
+ * PartsBasedDetector<float>::detect().
+ *
+ * Every entry point below names the reference interface it replaces
+ * (file:line under wg-perception/PartsBasedDetector).  The ABI is plain C:
+ * opaque handle, POD structs, raw pointers + sizes, int status codes; no C++
+ * exception ever crosses it.  INTEGRATION.md shows the reference-side
+ * adaptors (IFeatures / IConvolutionEngine / DynamicProgram / detect()) that
+ * bind it.
+ *
+ * Conventions
+ *   - all matrices are dense row-major, "H x W" = rows x cols;
+ *   - feature maps are cell-major with `flen` floats contiguous per cell
+ *     (the reference's H x (W*flen) cv::Mat, src/HOGFeatures.cpp:178);
+ *   - filters are kh x (kw*flen) floats, same interleave
+ *     (src/MatlabIOModel.cpp:106-125);
+ *   - a handle owns one GPU + one stream; calls on one handle must be
+ *     serialised by the caller (the reference detector is not re-entrant
+ *     either: src/HOGFeatures.cpp:99,106-107).
+ */
+#ifndef PBD_C_H_
+#define PBD_C_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (reference: assert / CV_Error / bool) */
+enum {
+  PBD_OK = 0,
+  PBD_ERR_ARG = 1,         /* bad pointer / size / index                       */
+  PBD_ERR_UNSUPPORTED = 2, /* CV_StsUnsupportedFormat, src/HOGFeatures.cpp:141 */
+  PBD_ERR_CAPACITY = 3,    /* output array too small; *count = needed          */
+  PBD_ERR_HIP = 4,         /* HIP runtime failure (see pbd_last_error)         */
+  PBD_ERR_STATE = 5        /* stage called before its producer stage           */
+};
+
+/* ---- model: POD mirror of include/Model.hpp:49-122 ------------------------
+ * Parts of all components are stored back to back ("flat part" index fp);
+ * mixtures of all parts are stored back to back ("flat mixture" index fm).
+ *   component c owns flat parts  part_offset[c] .. part_offset[c+1]-1
+ *   flat part fp owns mixtures   mix_offset[fp] .. mix_offset[fp+1]-1
+ * filterid/defid/biasid are 0-based like the C++ Model after zeroIndex
+ * (src/MatlabIOModel.cpp:155-166).  For a child part with K mixtures whose
+ * parent has L mixtures, bias(mm)[m] = biasw[biasid[fm0+mm] + m]
+ * (include/Parts.hpp:172-175), deformation defw[defid[fm0+mm]][0..3] and
+ * anchor anchors[defid[fm0+mm]] (include/Parts.hpp:179-183).
+ */
+typedef struct pbd_model_desc {
+  int32_t nfilters;      /* Model::filters().size()                            */
+  int32_t kh, kw;        /* filter rows / cols (uniform over the bank)         */
+  int32_t flen;          /* Model::flen()  (32)                                */
+  int32_t norient;       /* Model::norient() (18)                              */
+  int32_t sbin;          /* Model::binsize()                                   */
+  int32_t interval;      /* Model::nscales() (levels per octave)               */
+  float thresh;          /* Model::thresh()                                    */
+  const float* filters;  /* [nfilters][kh][kw*flen]                            */
+  int32_t ndefs;
+  const float* defw;     /* [ndefs][4]  = {wxx, wx, wyy, wy}                   */
+  const int32_t* anchors;/* [ndefs][2]  = {x, y}, 0-based                      */
+  int32_t nbias;
+  const float* biasw;    /* [nbias]                                            */
+  int32_t ncomponents;
+  const int32_t* part_offset; /* [ncomponents+1]                               */
+  const int32_t* parentid;    /* [nparts_total], index local to the component  */
+  const int32_t* mix_offset;  /* [nparts_total+1]                              */
+  const int32_t* filterid;    /* [nmix_total]                                  */
+  const int32_t* defid;       /* [nmix_total] (root: ignored)                  */
+  const int32_t* biasid;      /* [nmix_total]                                  */
+} pbd_model_desc;
+
+/* ---- options -------------------------------------------------------------- */
+enum {
+  PBD_CONV_AUTO = 0,  /* MFMA filter bank when nfilters*flen is a real GEMM     */
+  PBD_CONV_EXACT = 1, /* VALU direct correlation, reference summation order:
+                         bit-identical to src/filter.cpp:3899-3922 + pdf+=pdfc */
+  PBD_CONV_MFMA = 2   /* fp32 MFMA implicit GEMM (k-ordered fma chain)          */
+};
+typedef struct pbd_options {
+  int32_t device;        /* HIP device ordinal                                 */
+  int32_t conv_mode;     /* PBD_CONV_*                                         */
+  int32_t max_candidates;/* device-side candidate capacity per frame           */
+  int32_t dt_correct_ptr;/* 0 = reference pointer composition
+                            (include/DistanceTransform.hpp:233-244), 1 = true
+                            arg-max composition                                */
+  int32_t level_begin;   /* process pyramid levels [level_begin, level_end)    */
+  int32_t level_end;     /* <=0: all levels (multi-GPU level sharding)         */
+  int32_t reserved[2];
+} pbd_options;
+
+/* ---- output record: include/Candidate.hpp:56-111 --------------------------
+ * One candidate = head + max_parts boxes (x, y, width, height as cv::Rect)
+ * + max_parts part locations (x, y, mixture) in cells of its pyramid level.
+ * max_parts = pbd_max_parts(handle).  Part confidences are the reference's:
+ * root = rootv, every other part 0.0 (src/DynamicProgram.cpp:241-244).
+ */
+typedef struct pbd_candidate_head {
+  float score;        /* Candidate::score()                                    */
+  int32_t component;  /* Candidate::component()                                */
+  int32_t level;      /* pyramid level the root was found at                   */
+  int32_t nparts;     /* parts of that component                               */
+} pbd_candidate_head;
+
+typedef struct pbd_handle pbd_handle;
+
+/* PartsBasedDetector<T>::distributeModel (src/PartsBasedDetector.cpp:102-127)
+ * incl. SpatialConvolutionEngine::setFilters (src/SpatialConvolutionEngine.cpp:133-159)
+ * and Parts construction (include/Parts.hpp:229-235).                        */
+int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle** out);
+int pbd_destroy(pbd_handle* h);
+const char* pbd_last_error(const pbd_handle* h);
+int pbd_max_parts(const pbd_handle* h);
+/* set the stream all work of this handle is enqueued on (hipStream_t as void*) */
+int pbd_set_stream(pbd_handle* h, void* hip_stream);
+
+/* PartsBasedDetector<T>::detect(im, candidates) (src/PartsBasedDetector.cpp:69-95).
+ * `im` is a host pointer to an 8-bit image, cn = 1 or 3 (BGR interleaved),
+ * stride in bytes.  Candidates are written in the order of a single-threaded
+ * reference run (level, component, row-major root location); at most
+ * `capacity`; *count = number found (PBD_ERR_CAPACITY if > capacity).
+ * heads[capacity], boxes[capacity][max_parts][4], locs[capacity][max_parts][3]
+ * (boxes / locs may be NULL).                                                 */
+int pbd_detect_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride,
+                  pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
+                  int capacity, int* count);
+/* same, image already resident in device memory (tightly packed or strided)  */
+int pbd_detect_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, int cn, int stride,
+                      pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
+                      int capacity, int* count);
+/* asynchronous halves of pbd_detect_dev_u8: enqueue all kernels + the D2H of
+ * the candidate buffer on the handle's stream; collect after the stream (or
+ * the caller's event) has completed.  Lets a caller overlap frames.          */
+int pbd_detect_enqueue_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, int cn, int stride);
+int pbd_detect_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
+                       int capacity, int* count);
+
+/* ---- stage entry points (parity testing; same kernels as detect) ----------
+ * IFeatures::nscales/scales (include/IFeatures.hpp:54-63) + pyramid geometry
+ * of HOGFeatures<T>::pyramid (src/HOGFeatures.cpp:98-127).  Arrays sized
+ * >= *nlevels (call with NULL arrays to query).  img_* = level image size,
+ * cell_* = feature map size, scales = IFeatures::scales().                   */
+int pbd_pyramid_geometry(const pbd_handle* h, int w, int hgt, int* nlevels,
+                         int32_t* img_w, int32_t* img_h, int32_t* cell_w, int32_t* cell_h,
+                         float* scales);
+/* HOGFeatures<T>::pyramid (src/HOGFeatures.cpp:95-151): image pyramid + HOG  */
+int pbd_pyramid_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride);
+int pbd_get_level_image(pbd_handle* h, int level, uint8_t* out /* img_h*img_w*cn */);
+int pbd_get_level_features(pbd_handle* h, int level, float* out /* cell_h*cell_w*flen */);
+int pbd_set_level_features(pbd_handle* h, int level, const float* in);
+/* declare a frame geometry without running the pyramid (inject features)     */
+int pbd_begin_frame(pbd_handle* h, int w, int hgt, int cn);
+/* SpatialConvolutionEngine::pdf (src/SpatialConvolutionEngine.cpp:106-124)   */
+int pbd_pdf(pbd_handle* h);
+int pbd_get_level_response(pbd_handle* h, int level, int filter, float* out /* cell_h*cell_w */);
+int pbd_set_level_response(pbd_handle* h, int level, int filter, const float* in);
+/* DynamicProgram<T>::min (src/DynamicProgram.cpp:66-173)                      */
+int pbd_dp_min(pbd_handle* h);
+/* Ix/Iy/Ik[level][component][part][parent mixture] as int32 cell_h*cell_w     */
+int pbd_get_dp_pointers(pbd_handle* h, int level, int component, int part, int parent_mix,
+                        int32_t* ix, int32_t* iy, int32_t* ik);
+int pbd_get_root(pbd_handle* h, int level, int component, float* rootv, int32_t* rooti);
+/* DynamicProgram<T>::argmin (src/DynamicProgram.cpp:189-255)                  */
+int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
+                  int capacity, int* count);
+
+/* ---- stand-alone primitives ------------------------------------------------
+ * DistanceTransform<T>::compute (include/DistanceTransform.hpp:202-245) with
+ * Quadratic(ax,bx), Quadratic(ay,by) and anchor (osx, osy); host arrays.      */
+int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols,
+             double ax, double bx, double ay, double by, int osx, int osy,
+             float* out, int32_t* ix, int32_t* iy);
+/* HOGFeatures<T>::features<uint8_t> (src/HOGFeatures.cpp:168-341), one image */
+int pbd_hog_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride,
+               float* out, int* cell_w, int* cell_h);
+/* cv::resize(INTER_LINEAR) / cv::pyrDown on 8-bit images as used at
+ * src/HOGFeatures.cpp:116,122 (this library's definition)     */
+int pbd_resize_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride,
+                  uint8_t* out, int ow, int oh);
+int pbd_pyrdown_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride,
+                   uint8_t* out);
+/* Neubeck-Van Gool block NMS on a score map (src/nms.cpp:84-129)             */
+int pbd_nms_map(pbd_handle* h, const float* src, int rows, int cols, int sz, uint8_t* dst);
+
+/* ---- host-side post-processing (include/Candidate.hpp:91-99, 277-304) ------
+ * operate in place on the arrays returned by detect; pure host code.         */
+int pbd_candidates_sort(pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
+                        int count, int max_parts);
+int pbd_candidates_nms(pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
+                       int count, int max_parts, int im_w, int im_h, float overlap, int* kept);
+
+/* ---- instrumentation --------------------------------------------------------
+ * GPU time (ms, hipEvent) of the stages of the last synchronous detect:
+ * [0] image pyramid [1] HOG [2] pdf [3] dp min [4] argmin [5] total            */
+int pbd_get_stage_ms(const pbd_handle* h, float ms[6]);
+/* enable per-stage events (adds host syncs between stages; off by default)   */
+int pbd_set_profiling(pbd_handle* h, int on);
+/* algorithmic bytes / flops of the last frame geometry (SURVEY §8d formulas):
+ * [0] B_hog [1] B_pdf [2] F_pdf [3] B_dp [4] cells [5] dt_elements            */
+int pbd_get_work(const pbd_handle* h, double work[6]);
+/* average GPU ms of the DP-min kernels alone over frames since the last reset
+ * (HIP events on the handle's stream around the DP stage)                    */
+int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBD_C_H_ */

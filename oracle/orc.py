@@ -1,0 +1,228 @@
+"""ctypes binding of oracle/liborc.so (pbd_oracle.c).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Never by partsbaseddetector_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liborc.so")
+HEAD_DTYPE = np.dtype([("score", np.float32), ("component", np.int32), ("level", np.int32), ("nparts", np.int32)])
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        for n in ("orc_frame_image", "orc_frame_feat", "orc_frame_resp", "orc_frame_ix", "orc_frame_iy",
+                  "orc_frame_ik", "orc_frame_rootv", "orc_frame_rooti"):
+            getattr(L, n).restype = C.c_void_p
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int]
+        L.orc_frame_free.argtypes = [C.c_void_p]
+        L.orc_frame_nlevels.argtypes = [C.c_void_p]
+        L.orc_frame_dims.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def geometry(w, h, sbin, interval):
+    n = C.c_int(0)
+    a = [np.zeros(128, np.int32) for _ in range(4)]
+    sc = np.zeros(128, np.float32)
+    rc = lib().orc_pyramid_geometry(w, h, sbin, interval, C.byref(n), *[_p(x) for x in a], _p(sc))
+    if rc:
+        raise ValueError("image too small for the pyramid")
+    k = n.value
+    return dict(nlevels=k, img_w=a[0][:k], img_h=a[1][:k], cell_w=a[2][:k], cell_h=a[3][:k], scales=sc[:k])
+
+
+def _cn(im):
+    return 1 if im.ndim == 2 else im.shape[2]
+
+
+def resize(im, ow, oh):
+    im = np.ascontiguousarray(im, np.uint8)
+    h, w = im.shape[:2]
+    cn = _cn(im)
+    out = np.zeros((oh, ow) + ((cn,) if cn > 1 else ()), np.uint8)
+    lib().orc_resize_linear_8u(_p(im), w, h, cn, w * cn, _p(out), ow, oh)
+    return out
+
+
+def pyrdown(im):
+    im = np.ascontiguousarray(im, np.uint8)
+    h, w = im.shape[:2]
+    cn = _cn(im)
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2) + ((cn,) if cn > 1 else ()), np.uint8)
+    lib().orc_pyrdown_8u(_p(im), w, h, cn, w * cn, _p(out))
+    return out
+
+
+def hog(im, sbin):
+    im = np.ascontiguousarray(im, np.uint8)
+    h, w = im.shape[:2]
+    cn = _cn(im)
+    cw, ch = C.c_int(0), C.c_int(0)
+    lib().orc_cells_of(w, h, sbin, C.byref(cw), C.byref(ch))
+    out = np.zeros((ch.value, cw.value, 32), np.float32)
+    rc = lib().orc_hog_u8(_p(im), w, h, cn, w * cn, sbin, _p(out))
+    assert rc == 0
+    return out
+
+
+def pdf_level(feat, filters):
+    """feat [H, W, 32]; filters list of kh x (kw*32) -> [nf, H, W]."""
+    feat = np.ascontiguousarray(feat, np.float32)
+    H, W, flen = feat.shape
+    filt = np.ascontiguousarray(np.stack(filters).astype(np.float32))
+    nf, kh = filt.shape[0], filt.shape[1]
+    kw = filt.shape[2] // flen
+    out = np.zeros((nf, H, W), np.float32)
+    lib().orc_pdf_level(_p(feat), H, W, flen, _p(filt), nf, kh, kw, _p(out))
+    return out
+
+
+def dt1d(src, a, b, os_):
+    src = np.ascontiguousarray(src, np.float32)
+    dst = np.zeros_like(src)
+    ptr = np.zeros(src.shape, np.int32)
+    lib().orc_dt1d(_p(src), _p(dst), _p(ptr), src.shape[0], C.c_double(a), C.c_double(b), os_)
+    return dst, ptr
+
+
+def dt2d(a, ax, bx, ay, by, osx, osy, correct_ptr=0):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.zeros_like(a)
+    ix, iy = np.zeros(a.shape, np.int32), np.zeros(a.shape, np.int32)
+    lib().orc_dt2d(_p(a), a.shape[0], a.shape[1], C.c_double(ax), C.c_double(bx), C.c_double(ay), C.c_double(by),
+                   osx, osy, _p(out), _p(ix), _p(iy), correct_ptr)
+    return out, ix, iy
+
+
+def ptr_planes(desc, comp):
+    return lib().orc_ptr_planes(C.byref(desc), comp)
+
+
+def dp_min_level(desc, comp, resp, correct_ptr=0):
+    """resp [nf, H, W] -> Ix, Iy, Ik [planes, H, W], rootv, rooti [H, W]."""
+    resp = np.ascontiguousarray(resp, np.float32)
+    _, H, W = resp.shape
+    npl = ptr_planes(desc, comp)
+    Ix, Iy, Ik = (np.zeros((npl, H, W), np.int32) for _ in range(3))
+    rv, ri = np.zeros((H, W), np.float32), np.zeros((H, W), np.int32)
+    lib().orc_dp_min_level(C.byref(desc), comp, _p(resp), H, W, _p(Ix), _p(Iy), _p(Ik), _p(rv), _p(ri), correct_ptr)
+    return Ix, Iy, Ik, rv, ri
+
+
+class Frame:
+    """Intermediates of one orc_detect_u8 run."""
+
+    def __init__(self, ptr, model):
+        self.ptr, self.model = ptr, model
+        self.nlevels = lib().orc_frame_nlevels(ptr)
+        self.dims = []
+        for l in range(self.nlevels):
+            v = [C.c_int(0) for _ in range(4)]
+            s = C.c_float(0)
+            lib().orc_frame_dims(ptr, l, *[C.addressof(x) for x in v], C.addressof(s))
+            self.dims.append(tuple(x.value for x in v) + (s.value,))
+
+    def _arr(self, fn, l, shape, dtype):
+        p = getattr(lib(), fn)(self.ptr, l)
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.zeros(shape, dtype)
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape).copy()
+
+    def image(self, l, cn):
+        iw, ih = self.dims[l][0], self.dims[l][1]
+        return self._arr("orc_frame_image", l, (ih, iw) + ((cn,) if cn > 1 else ()), np.uint8)
+
+    def feat(self, l):
+        return self._arr("orc_frame_feat", l, (self.dims[l][3], self.dims[l][2], 32), np.float32)
+
+    def resp(self, l):
+        return self._arr("orc_frame_resp", l, (len(self.model.filtersw), self.dims[l][3], self.dims[l][2]), np.float32)
+
+    def pointers(self, l, total_planes):
+        sh = (total_planes, self.dims[l][3], self.dims[l][2])
+        return tuple(self._arr(f, l, sh, np.int32) for f in ("orc_frame_ix", "orc_frame_iy", "orc_frame_ik"))
+
+    def root(self, l):
+        sh = (self.model.ncomponents, self.dims[l][3], self.dims[l][2])
+        return self._arr("orc_frame_rootv", l, sh, np.float32), self._arr("orc_frame_rooti", l, sh, np.int32)
+
+    def free(self):
+        if self.ptr:
+            lib().orc_frame_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
+
+
+def detect(model, im, capacity=8192, keep=False, correct_ptr=0, desc=None):
+    """orc_detect_u8 -> (heads, boxes, locs, stage_ms[, Frame])."""
+    im = np.ascontiguousarray(im, np.uint8)
+    h, w = im.shape[:2]
+    cn = _cn(im)
+    desc = desc or model.to_desc()
+    mp = lib().orc_max_parts(C.byref(desc))
+    heads = np.zeros(capacity, HEAD_DTYPE)
+    boxes = np.zeros((capacity, mp, 4), np.int32)
+    locs = np.zeros((capacity, mp, 3), np.int32)
+    cnt = C.c_int(0)
+    ms = (C.c_double * 5)()
+    fp = C.c_void_p()
+    rc = lib().orc_detect_u8(C.byref(desc), _p(im), w, h, cn, w * cn, _p(heads), _p(boxes), _p(locs), capacity,
+                             C.byref(cnt), ms, C.byref(fp) if keep else None, correct_ptr)
+    if rc:
+        raise ValueError("orc_detect_u8 failed (image too small?)")
+    n = min(cnt.value, capacity)
+    res = (heads[:n].copy(), boxes[:n].copy(), locs[:n].copy(), list(ms))
+    if keep:
+        return res + (Frame(fp, model),)
+    return res
+
+
+def candidates_sort(heads, boxes, locs):
+    heads, boxes, locs = heads.copy(), boxes.copy(), locs.copy()
+    lib().orc_candidates_sort(_p(heads), _p(boxes), _p(locs), len(heads), boxes.shape[1])
+    return heads, boxes, locs
+
+
+def candidates_nms(heads, boxes, locs, im_w, im_h, overlap):
+    heads, boxes, locs = heads.copy(), boxes.copy(), locs.copy()
+    kept = C.c_int(0)
+    lib().orc_candidates_nms(_p(heads), _p(boxes), _p(locs), len(heads), boxes.shape[1], im_w, im_h,
+                             C.c_float(overlap), C.byref(kept))
+    return heads[:kept.value], boxes[:kept.value], locs[:kept.value]
+
+
+def nms_map(src, sz):
+    src = np.ascontiguousarray(src, np.float32)
+    out = np.zeros(src.shape, np.uint8)
+    lib().orc_nms_map(_p(src), src.shape[0], src.shape[1], sz, _p(out))
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()

@@ -1,0 +1,312 @@
+"""ctypes binding of libpbd_hip.so (include/pbd_c.h).
+
+The library is the product; this module only marshals numpy arrays / device
+pointers into it.  There is NO CPU fallback: if the shared object is missing
+the import of `lib()` raises, and `pbd_create` fails on a box without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .model import pbd_model_desc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpbd_hip.so")
+
+PBD_OK, PBD_ERR_ARG, PBD_ERR_UNSUPPORTED, PBD_ERR_CAPACITY, PBD_ERR_HIP, PBD_ERR_STATE = range(6)
+PBD_CONV_AUTO, PBD_CONV_EXACT, PBD_CONV_MFMA = 0, 1, 2
+
+EXPORTS = [
+    "pbd_create", "pbd_destroy", "pbd_last_error", "pbd_max_parts", "pbd_set_stream",
+    "pbd_detect_u8", "pbd_detect_dev_u8", "pbd_detect_enqueue_dev_u8", "pbd_detect_collect",
+    "pbd_pyramid_geometry", "pbd_pyramid_u8", "pbd_get_level_image", "pbd_get_level_features",
+    "pbd_set_level_features", "pbd_begin_frame", "pbd_pdf", "pbd_get_level_response",
+    "pbd_set_level_response", "pbd_dp_min", "pbd_get_dp_pointers", "pbd_get_root", "pbd_dp_argmin",
+    "pbd_dt2d", "pbd_hog_u8", "pbd_resize_u8", "pbd_pyrdown_u8", "pbd_nms_map",
+    "pbd_candidates_sort", "pbd_candidates_nms", "pbd_get_stage_ms", "pbd_set_profiling",
+    "pbd_get_work", "pbd_dp_timer",
+]
+
+
+class pbd_options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("conv_mode", C.c_int32), ("max_candidates", C.c_int32),
+                ("dt_correct_ptr", C.c_int32), ("level_begin", C.c_int32), ("level_end", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+
+class pbd_candidate_head(C.Structure):
+    _fields_ = [("score", C.c_float), ("component", C.c_int32), ("level", C.c_int32), ("nparts", C.c_int32)]
+
+
+HEAD_DTYPE = np.dtype([("score", np.float32), ("component", np.int32), ("level", np.int32), ("nparts", np.int32)])
+
+_lib = None
+
+
+class PbdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pbd error {code}: {msg}")
+        self.code = code
+
+
+def lib() -> C.CDLL:
+    """Load libpbd_hip.so; fail loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.pbd_last_error.restype = C.c_char_p
+        L.pbd_last_error.argtypes = [C.c_void_p]
+        for name in EXPORTS:
+            getattr(L, name)  # every declared symbol must be exported
+        _lib = L
+    return _lib
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+class Handle:
+    """Owns one pbd_handle (one GPU, one stream)."""
+
+    def __init__(self, model, device=0, conv_mode=PBD_CONV_AUTO, max_candidates=4096, dt_correct_ptr=0,
+                 level_begin=0, level_end=0):
+        self.L = lib()
+        self.model = model
+        self.desc = model.to_desc()
+        opt = pbd_options(device, conv_mode, max_candidates, dt_correct_ptr, level_begin, level_end)
+        self.h = C.c_void_p()
+        rc = self.L.pbd_create(C.byref(self.desc), C.byref(opt), C.byref(self.h))
+        if rc != PBD_OK:
+            msg = self.L.pbd_last_error(self.h).decode() if self.h else "allocation failed"
+            if self.h:
+                self.L.pbd_destroy(self.h)
+            self.h = None
+            raise PbdError(rc, msg)
+        self.max_parts = self.L.pbd_max_parts(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pbd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != PBD_OK:
+            raise PbdError(rc, self.L.pbd_last_error(self.h).decode())
+
+    # ---- detect ----------------------------------------------------------------
+    def _bufs(self, capacity):
+        heads = np.zeros(capacity, HEAD_DTYPE)
+        boxes = np.zeros((capacity, self.max_parts, 4), np.int32)
+        locs = np.zeros((capacity, self.max_parts, 3), np.int32)
+        return heads, boxes, locs
+
+    def _out(self, heads, boxes, locs, n):
+        return heads[:n].copy(), boxes[:n].copy(), locs[:n].copy()
+
+    def detect(self, im: np.ndarray, capacity=4096):
+        im = np.ascontiguousarray(im, np.uint8)
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        heads, boxes, locs = self._bufs(capacity)
+        cnt = C.c_int(0)
+        self._chk(self.L.pbd_detect_u8(self.h, _p(im, C.c_uint8), w, hgt, cn, w * cn,
+                                       heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32), _p(locs, C.c_int32),
+                                       capacity, C.byref(cnt)))
+        return self._out(heads, boxes, locs, cnt.value)
+
+    def detect_dev(self, dptr: int, w, hgt, cn, stride=None, capacity=4096):
+        heads, boxes, locs = self._bufs(capacity)
+        cnt = C.c_int(0)
+        self._chk(self.L.pbd_detect_dev_u8(self.h, C.c_void_p(dptr), w, hgt, cn, stride or w * cn,
+                                           heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32),
+                                           _p(locs, C.c_int32), capacity, C.byref(cnt)))
+        return self._out(heads, boxes, locs, cnt.value)
+
+    def enqueue_dev(self, dptr: int, w, hgt, cn, stride=None):
+        self._chk(self.L.pbd_detect_enqueue_dev_u8(self.h, C.c_void_p(dptr), w, hgt, cn, stride or w * cn))
+
+    def collect(self, capacity=4096):
+        heads, boxes, locs = self._bufs(capacity)
+        cnt = C.c_int(0)
+        self._chk(self.L.pbd_detect_collect(self.h, heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32),
+                                            _p(locs, C.c_int32), capacity, C.byref(cnt)))
+        return self._out(heads, boxes, locs, cnt.value)
+
+    def set_stream(self, stream_ptr: int):
+        self._chk(self.L.pbd_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ---- stages ------------------------------------------------------------------
+    def geometry(self, w, hgt):
+        n = C.c_int(0)
+        self._chk(self.L.pbd_pyramid_geometry(self.h, w, hgt, C.byref(n), None, None, None, None, None))
+        a = [np.zeros(n.value, np.int32) for _ in range(4)]
+        sc = np.zeros(n.value, np.float32)
+        self._chk(self.L.pbd_pyramid_geometry(self.h, w, hgt, C.byref(n), *[_p(x, C.c_int32) for x in a],
+                                              _p(sc, C.c_float)))
+        return dict(nlevels=n.value, img_w=a[0], img_h=a[1], cell_w=a[2], cell_h=a[3], scales=sc)
+
+    def begin_frame(self, w, hgt, cn):
+        self._chk(self.L.pbd_begin_frame(self.h, w, hgt, cn))
+        self._geo = self.geometry(w, hgt)
+        self._cn = cn
+
+    def pyramid(self, im: np.ndarray):
+        im = np.ascontiguousarray(im, np.uint8)
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        self._chk(self.L.pbd_pyramid_u8(self.h, _p(im, C.c_uint8), w, hgt, cn, w * cn))
+        self._geo = self.geometry(w, hgt)
+        self._cn = cn
+
+    def level_image(self, l):
+        g = self._geo
+        shape = (g["img_h"][l], g["img_w"][l]) + ((self._cn,) if self._cn > 1 else ())
+        out = np.zeros(shape, np.uint8)
+        self._chk(self.L.pbd_get_level_image(self.h, l, _p(out, C.c_uint8)))
+        return out
+
+    def level_features(self, l):
+        g = self._geo
+        out = np.zeros((g["cell_h"][l], g["cell_w"][l], 32), np.float32)
+        self._chk(self.L.pbd_get_level_features(self.h, l, _p(out, C.c_float)))
+        return out
+
+    def set_level_features(self, l, f):
+        f = np.ascontiguousarray(f, np.float32)
+        self._chk(self.L.pbd_set_level_features(self.h, l, _p(f, C.c_float)))
+
+    def pdf(self):
+        self._chk(self.L.pbd_pdf(self.h))
+
+    def level_response(self, l, n):
+        g = self._geo
+        out = np.zeros((g["cell_h"][l], g["cell_w"][l]), np.float32)
+        self._chk(self.L.pbd_get_level_response(self.h, l, n, _p(out, C.c_float)))
+        return out
+
+    def set_level_response(self, l, n, r):
+        r = np.ascontiguousarray(r, np.float32)
+        self._chk(self.L.pbd_set_level_response(self.h, l, n, _p(r, C.c_float)))
+
+    def dp_min(self):
+        self._chk(self.L.pbd_dp_min(self.h))
+
+    def dp_pointers(self, l, c, p, m):
+        g = self._geo
+        sh = (g["cell_h"][l], g["cell_w"][l])
+        ix, iy, ik = (np.zeros(sh, np.int32) for _ in range(3))
+        self._chk(self.L.pbd_get_dp_pointers(self.h, l, c, p, m, _p(ix, C.c_int32), _p(iy, C.c_int32),
+                                             _p(ik, C.c_int32)))
+        return ix, iy, ik
+
+    def root(self, l, c):
+        g = self._geo
+        sh = (g["cell_h"][l], g["cell_w"][l])
+        rv, ri = np.zeros(sh, np.float32), np.zeros(sh, np.int32)
+        self._chk(self.L.pbd_get_root(self.h, l, c, _p(rv, C.c_float), _p(ri, C.c_int32)))
+        return rv, ri
+
+    def dp_argmin(self, capacity=4096):
+        heads, boxes, locs = self._bufs(capacity)
+        cnt = C.c_int(0)
+        self._chk(self.L.pbd_dp_argmin(self.h, heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32),
+                                       _p(locs, C.c_int32), capacity, C.byref(cnt)))
+        return self._out(heads, boxes, locs, cnt.value)
+
+    # ---- primitives ----------------------------------------------------------------
+    def dt2d(self, a: np.ndarray, ax, bx, ay, by, osx, osy):
+        a = np.ascontiguousarray(a, np.float32)
+        out = np.zeros_like(a)
+        ix, iy = np.zeros(a.shape, np.int32), np.zeros(a.shape, np.int32)
+        self._chk(self.L.pbd_dt2d(self.h, _p(a, C.c_float), a.shape[0], a.shape[1], C.c_double(ax), C.c_double(bx),
+                                  C.c_double(ay), C.c_double(by), osx, osy, _p(out, C.c_float), _p(ix, C.c_int32),
+                                  _p(iy, C.c_int32)))
+        return out, ix, iy
+
+    def hog(self, im: np.ndarray):
+        im = np.ascontiguousarray(im, np.uint8)
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        sb = self.model.sbin
+        buf = np.zeros((hgt // sb + 2) * (w // sb + 2) * 32, np.float32)
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self.L.pbd_hog_u8(self.h, _p(im, C.c_uint8), w, hgt, cn, w * cn, _p(buf, C.c_float), C.byref(a),
+                                    C.byref(b)))
+        return buf[: b.value * a.value * 32].reshape(b.value, a.value, 32).copy()
+
+    def resize(self, im: np.ndarray, ow, oh):
+        im = np.ascontiguousarray(im, np.uint8)
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        out = np.zeros((oh, ow) + ((cn,) if cn > 1 else ()), np.uint8)
+        self._chk(self.L.pbd_resize_u8(self.h, _p(im, C.c_uint8), w, hgt, cn, w * cn, _p(out, C.c_uint8), ow, oh))
+        return out
+
+    def pyrdown(self, im: np.ndarray):
+        im = np.ascontiguousarray(im, np.uint8)
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        out = np.zeros(((hgt + 1) // 2, (w + 1) // 2) + ((cn,) if cn > 1 else ()), np.uint8)
+        self._chk(self.L.pbd_pyrdown_u8(self.h, _p(im, C.c_uint8), w, hgt, cn, w * cn, _p(out, C.c_uint8)))
+        return out
+
+    def nms_map(self, src: np.ndarray, sz: int):
+        src = np.ascontiguousarray(src, np.float32)
+        out = np.zeros(src.shape, np.uint8)
+        self._chk(self.L.pbd_nms_map(self.h, _p(src, C.c_float), src.shape[0], src.shape[1], sz, _p(out, C.c_uint8)))
+        return out
+
+    # ---- instrumentation -------------------------------------------------------------
+    def set_profiling(self, on=True):
+        self._chk(self.L.pbd_set_profiling(self.h, int(on)))
+
+    def stage_ms(self):
+        ms = (C.c_float * 6)()
+        self._chk(self.L.pbd_get_stage_ms(self.h, ms))
+        return dict(zip(["image_pyramid", "hog", "pdf", "dp_min", "argmin", "total"], list(ms)))
+
+    def work(self):
+        wk = (C.c_double * 6)()
+        self._chk(self.L.pbd_get_work(self.h, wk))
+        return dict(zip(["B_hog", "B_pdf", "F_pdf", "B_dp", "cells", "dt_elements"], list(wk)))
+
+    def dp_timer(self, reset=False):
+        ms, n = C.c_double(0), C.c_int(0)
+        self._chk(self.L.pbd_dp_timer(self.h, int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def candidates_sort(heads, boxes, locs):
+    """Candidate::sort (include/Candidate.hpp:91-99) — host code inside the library."""
+    heads, boxes, locs = heads.copy(), np.ascontiguousarray(boxes).copy(), np.ascontiguousarray(locs).copy()
+    mp = boxes.shape[1] if boxes.ndim == 3 else 1
+    rc = lib().pbd_candidates_sort(heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32), _p(locs, C.c_int32),
+                                   len(heads), mp)
+    if rc:
+        raise PbdError(rc, "pbd_candidates_sort")
+    return heads, boxes, locs
+
+
+def candidates_nms(heads, boxes, locs, im_w, im_h, overlap=0.0):
+    """Candidate::nonMaximaSuppression (include/Candidate.hpp:277-304)."""
+    heads, boxes, locs = heads.copy(), np.ascontiguousarray(boxes).copy(), np.ascontiguousarray(locs).copy()
+    mp = boxes.shape[1]
+    kept = C.c_int(0)
+    rc = lib().pbd_candidates_nms(heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32), _p(locs, C.c_int32),
+                                  len(heads), mp, im_w, im_h, C.c_float(overlap), C.byref(kept))
+    if rc:
+        raise PbdError(rc, "pbd_candidates_nms")
+    return heads[:kept.value], boxes[:kept.value], locs[:kept.value]

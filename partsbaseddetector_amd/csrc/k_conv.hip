@@ -1,0 +1,271 @@
+// k_conv.hip — SpatialConvolutionEngine::pdf as one batched filter-bank
+// correlation over all pyramid levels (reference
+// src/SpatialConvolutionEngine.cpp:70-124, Filter2D src/filter.cpp:3879-3924).
+//
+//   resp[l][n](y,x) = sum_c sum_{i,j} w_n[i][j][c] * F_l(y+i-kh/2, x+j-kw/2, c)
+//   "same" size, correlation (no flip), constant border: 0 for c<flen-1,
+//   1 for the last (truncation) channel (:147-155).
+//
+// Two kernels behind the same launcher signature:
+//  * k_conv_exact — VALU, reproduces the reference's summation order bit for
+//    bit: per channel a tap-ordered (row-major) chain of separately rounded
+//    mul + add starting from 0 (filter.cpp:3914-3918), then the channel
+//    partials are added in channel order (`pdf += pdfc`, :92).  Compiled with
+//    -ffp-contract=off so hipcc cannot fuse the mul/add.
+//  * k_conv_mfma  — fp32 MFMA implicit GEMM (M = cells, N = filters, K =
+//    kh*kw*flen = 800): a k-ordered fma chain, |delta| ~1e-6 vs the reference
+//    order; the fast path when nfilters*flen is a real dense contraction.
+// Both stage a (T+kh-1)x(T+kw-1)-cell feature tile with halo in LDS once per
+// workgroup (border values materialised there) and write plane-major outputs.
+#include "pbd_internal.hpp"
+
+#define CT 16        // spatial tile side (cells)
+#define CSTR 33      // LDS floats per cell (32 + 1 pad: conflict-free across x)
+#define NFG 8        // filters held in registers per pass (exact kernel)
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void k_conv_exact(const ConvTile* __restrict__ tiles,
+                                                    const LevelDev* __restrict__ levels,
+                                                    const float* __restrict__ feat, const float* __restrict__ wT,
+                                                    float* __restrict__ resp, int nf, int nfpad, int groups_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ft = (float*)smem;  // [(CT+KH-1)][(CT+KW-1)][CSTR]
+  const ConvTile t = tiles[blockIdx.x];
+  const LevelDev lv = levels[t.level];
+  const int H = lv.ch, W = lv.cw;
+  const int TW = CT + KW - 1, TH = CT + KH - 1;
+  const int tid = threadIdx.x;
+  const float* F = feat + lv.cell_off * PBD_FLEN;
+  // stage the tile: 8 lanes x float4 per cell -> coalesced 128 B per cell
+  for (int i = tid; i < TH * TW * 8; i += 256) {
+    const int cell = i >> 3, q = i & 7;
+    const int ty = cell / TW, tx = cell - ty * TW;
+    const int y = t.y0 + ty - KH / 2, x = t.x0 + tx - KW / 2;
+    float4 v;
+    if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(F + ((size_t)y * W + x) * PBD_FLEN + q * 4);
+    else v = make_float4(0.f, 0.f, 0.f, q == 7 ? 1.f : 0.f);  // border: last channel = 1
+    float* d = ft + cell * CSTR + q * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  const int oy = t.y0 + ly, ox = t.x0 + lx;
+  const bool valid = (oy < H && ox < W);
+  const float* fbase = ft + (ly * TW + lx) * CSTR;
+  float* R = resp + lv.cell_off * nf;  // level base, plane n at + n*H*W
+  const int g0 = blockIdx.y * groups_per_wg;
+  for (int g = g0; g < g0 + groups_per_wg; ++g) {
+    const int n0 = g * NFG;
+    if (n0 >= nf) break;
+    float tot[NFG];
+#pragma unroll
+    for (int n = 0; n < NFG; ++n) tot[n] = 0.f;
+    for (int c = 0; c < PBD_FLEN; ++c) {
+      float acc[NFG];
+#pragma unroll
+      for (int n = 0; n < NFG; ++n) acc[n] = 0.f;
+#pragma unroll
+      for (int i = 0; i < KH; ++i) {
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+          const float f = fbase[(i * TW + j) * CSTR + c];
+          const float* w = wT + ((size_t)(i * KW + j) * PBD_FLEN + c) * nfpad + n0;  // wave-uniform
+#pragma unroll
+          for (int n = 0; n < NFG; ++n) acc[n] += w[n] * f;
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NFG; ++n) tot[n] += acc[n];
+    }
+    if (valid) {
+#pragma unroll
+      for (int n = 0; n < NFG; ++n)
+        if (n0 + n < nf) R[(size_t)(n0 + n) * H * W + (size_t)oy * W + ox] = tot[n];
+    }
+  }
+}
+
+// generic-size fallback (runtime kh, kw <= 9)
+__global__ __launch_bounds__(256) void k_conv_exact_generic(const ConvTile* __restrict__ tiles,
+                                                            const LevelDev* __restrict__ levels,
+                                                            const float* __restrict__ feat,
+                                                            const float* __restrict__ wT, float* __restrict__ resp,
+                                                            int nf, int nfpad, int KH, int KW) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ft = (float*)smem;
+  const ConvTile t = tiles[blockIdx.x];
+  const LevelDev lv = levels[t.level];
+  const int H = lv.ch, W = lv.cw;
+  const int TW = CT + KW - 1, TH = CT + KH - 1;
+  const int tid = threadIdx.x;
+  const float* F = feat + lv.cell_off * PBD_FLEN;
+  for (int i = tid; i < TH * TW * 8; i += 256) {
+    const int cell = i >> 3, q = i & 7;
+    const int ty = cell / TW, tx = cell - ty * TW;
+    const int y = t.y0 + ty - KH / 2, x = t.x0 + tx - KW / 2;
+    float4 v;
+    if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(F + ((size_t)y * W + x) * PBD_FLEN + q * 4);
+    else v = make_float4(0.f, 0.f, 0.f, q == 7 ? 1.f : 0.f);
+    float* d = ft + cell * CSTR + q * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  const int oy = t.y0 + ly, ox = t.x0 + lx;
+  const bool valid = (oy < H && ox < W);
+  const float* fbase = ft + (ly * TW + lx) * CSTR;
+  float* R = resp + lv.cell_off * nf;
+  for (int n = blockIdx.y; n < nf; n += gridDim.y) {
+    float tot = 0.f;
+    for (int c = 0; c < PBD_FLEN; ++c) {
+      float acc = 0.f;
+      for (int i = 0; i < KH; ++i)
+        for (int j = 0; j < KW; ++j)
+          acc += wT[((size_t)(i * KW + j) * PBD_FLEN + c) * nfpad + n] * fbase[(i * TW + j) * CSTR + c];
+      tot += acc;
+    }
+    if (valid) R[(size_t)n * H * W + (size_t)oy * W + ox] = tot;
+  }
+}
+
+void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
+                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
+  if (ntiles <= 0) return;
+  const size_t lds = sizeof(float) * (CT + kh - 1) * (CT + kw - 1) * CSTR;
+  if (kh == 5 && kw == 5) {
+    static bool cfg = false;
+    if (!cfg) { hipFuncSetAttribute((const void*)k_conv_exact<5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+    const int groups = (nf + NFG - 1) / NFG;
+    const int gpw = 4;
+    dim3 grid(ntiles, (groups + gpw - 1) / gpw);
+    hipLaunchKernelGGL((k_conv_exact<5, 5>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, gpw);
+  } else {
+    hipFuncSetAttribute((const void*)k_conv_exact_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(ntiles, nf < 16 ? nf : 16);
+    hipLaunchKernelGGL(k_conv_exact_generic, grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, kh, kw);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32).
+// Workgroup = 256 threads = 4 waves, tile = 16x16 cells (M = 256) x NB_N
+// filters.  Wave w owns cell rows 4w..4w+3 (M = 64 = two 32-row MFMA tiles:
+// 2 cell rows x 16 cols each) and all NT n-tiles of 32 filters:
+// acc[2][NT] f32x16.  K loop: tap-major, channel-minor; per k-step (2
+// channels of one tap): 2 A reads (ds_read_b32, cell stride 33 -> conflict
+// free), NT B reads ([k][n] row, n contiguous), 2*NT MFMAs.
+// B (weights) for the current tap (32 x nfpad floats) is staged in LDS.
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KH, int KW, int NT>
+__global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ tiles,
+                                                   const LevelDev* __restrict__ levels,
+                                                   const float* __restrict__ feat, const float* __restrict__ wT,
+                                                   float* __restrict__ resp, int nf, int nfpad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TW = CT + KW - 1, TH = CT + KH - 1;
+  constexpr int NW = NT * 32;               // filters handled by this workgroup
+  float* ft = (float*)smem;                 // [TH][TW][CSTR]
+  float* wb = ft + TH * TW * CSTR;          // [2][32][NW] double-buffered weights of one tap
+  const ConvTile t = tiles[blockIdx.x];
+  const LevelDev lv = levels[t.level];
+  const int H = lv.ch, W = lv.cw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nbase = blockIdx.y * NW;
+  const float* F = feat + lv.cell_off * PBD_FLEN;
+  for (int i = tid; i < TH * TW * 8; i += 256) {
+    const int cell = i >> 3, q = i & 7;
+    const int ty = cell / TW, tx = cell - ty * TW;
+    const int y = t.y0 + ty - KH / 2, x = t.x0 + tx - KW / 2;
+    float4 v;
+    if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(F + ((size_t)y * W + x) * PBD_FLEN + q * 4);
+    else v = make_float4(0.f, 0.f, 0.f, q == 7 ? 1.f : 0.f);
+    float* d = ft + cell * CSTR + q * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  // weights of tap 0 -> wb[0]
+  auto stage_w = [&](int tap, int buf) {
+    const float* src = wT + (size_t)tap * PBD_FLEN * nfpad + nbase;
+    float* dst = wb + buf * 32 * NW;
+    for (int i = tid; i < 32 * NW / 4; i += 256) {
+      const int c = i / (NW / 4), n4 = i - c * (NW / 4);
+      *(float4*)(dst + c * NW + n4 * 4) = *(const float4*)(src + (size_t)c * nfpad + n4 * 4);
+    }
+  };
+  stage_w(0, 0);
+  __syncthreads();
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // A operand of v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5]
+  const int ai = lane & 31, ak = lane >> 5;
+  // M-tile m of this wave: cell rows 4*wave + 2*m + (ai>>4), col ai&15
+  const int arow0 = 4 * wave + (ai >> 4), acol = ai & 15;
+  const float* abase0 = ft + ((arow0)*TW + acol) * CSTR + ak;
+  const float* abase1 = ft + ((arow0 + 2) * TW + acol) * CSTR + ak;
+  const int bj = lane & 31;  // B[k = l>>5][j = l&31]
+
+  for (int tap = 0; tap < KH * KW; ++tap) {
+    const int buf = tap & 1;
+    if (tap + 1 < KH * KW) stage_w(tap + 1, buf ^ 1);
+    const int ti = tap / KW, tj = tap - ti * KW;
+    const float* a0 = abase0 + (ti * TW + tj) * CSTR;
+    const float* a1 = abase1 + (ti * TW + tj) * CSTR;
+    const float* b = wb + buf * 32 * NW + ak * NW + bj;
+#pragma unroll 4
+    for (int c = 0; c < 32; c += 2) {
+      const float av0 = a0[c], av1 = a1[c];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float bv = b[c * NW + n * 32];
+        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc[0][n], 0, 0, 0);
+        acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv, acc[1][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // Epilogue.  C/D layout 32x32: col(j) = lane&31, row(i) = (reg&3) + 8*(reg>>2) + 4*(lane>>5),
+  // i.e. a lane holds ONE filter and 16 scattered cells: storing that directly would be 4-byte
+  // scatters across 32 response planes.  Transpose each 64-cell x 32-filter slab through the
+  // (now free) feature-tile LDS so lanes run along cells: every store instruction then writes
+  // four 64-B row segments of one plane.
+  float* R = resp + lv.cell_off * nf;
+  float* tr = ft + wave * (32 * 65);  // per-wave [32 filters][64 cells + 1]
+  const int py = t.y0 + 4 * wave + (lane >> 4), pxx = t.x0 + (lane & 15);
+  const bool pvalid = (py < H && pxx < W);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        tr[(lane & 31) * 65 + m * 32 + i] = acc[m][n][r];
+      }
+    __syncthreads();
+    for (int j = 0; j < 32; ++j) {
+      const int fn = nbase + n * 32 + j;
+      if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[j * 65 + lane];
+    }
+    __syncthreads();
+  }
+}
+
+void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
+                      const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
+  if (ntiles <= 0) return;
+  if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, kh, kw, s); return; }
+  constexpr int NT = 5;  // 160 filters per workgroup (person model: 156 -> one N pass)
+  const size_t lds = sizeof(float) * ((CT + 4) * (CT + 4) * CSTR + 2 * 32 * NT * 32);
+  static bool cfg = false;
+  if (!cfg) { hipFuncSetAttribute((const void*)k_conv_mfma<5, 5, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+  dim3 grid(ntiles, (nfpad + NT * 32 - 1) / (NT * 32));
+  hipLaunchKernelGGL((k_conv_mfma<5, 5, NT>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
+}

@@ -1,0 +1,224 @@
+// k_hog.hip — fused HOG: gradient + orientation snap + bilinear binning +
+// block energy + 4-way normalisation + 32-feature emit, one workgroup per
+// TC x TC tile of output cells of one pyramid level, all levels in one launch.
+// Reference: HOGFeatures<T>::features<uint8_t>, src/HOGFeatures.cpp:168-341.
+//
+// Bit-exactness plan (compiled with -ffp-contract=off):
+//  * the reference SCATTERS each pixel into <=4 block histograms in raster
+//    order (:262-265); every histogram bin is an independent float
+//    accumulator, so a GATHER in which one thread owns one (block, orientation)
+//    bin and adds its contributing pixels in the same raster order produces
+//    the same bits, with no atomics;
+//  * weights are (wy*wx)*|g| exactly as (:262-265) evaluate them (float
+//    products commute);
+//  * the four normalisers are evaluated in double like the reference's
+//    `1.0f / sqrt(float_sum + eps)` (:293-299), texture gains in double (:331).
+// HBM-bound and small (25 MB algorithmic per 640x480 frame): pixels are read
+// through L2 (each level image is a few hundred KB), per-pixel (|g|, bin) and
+// the tile's histograms live in LDS, the output is written cell-major with 32
+// consecutive lanes covering one cell's 128 B.
+#include "pbd_internal.hpp"
+
+struct HogLds {
+  int PT;        // pixel window side
+  int NB;        // blocks per side (TC+2)
+  size_t mag_off, bin_off, hist_off, norm_off, ninv_off, tab_off, total;
+};
+
+__host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc) {
+  HogLds L;
+  L.NB = tc + 2;
+  L.PT = L.NB * sbin + sbin + 2;
+  size_t o = 0;
+  L.mag_off = o; o += sizeof(float) * L.PT * L.PT;
+  L.hist_off = o; o += sizeof(float) * L.NB * L.NB * PBD_NORIENT;
+  L.norm_off = o; o += sizeof(float) * L.NB * L.NB;
+  L.ninv_off = o; o += sizeof(float) * (tc + 1) * (tc + 1);
+  L.tab_off = o; o += (sizeof(float) * 2 + sizeof(int)) * 2 * L.PT;  // w0,w1,ip for y and x
+  L.bin_off = o; o += L.PT * L.PT;
+  L.total = (o + 15) & ~(size_t)15;
+  return L;
+}
+size_t hog_lds_bytes(int sbin, int tc) { return hog_lds_layout(sbin, tc).total; }
+
+__global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
+                                             const uint8_t* __restrict__ pyr, float* __restrict__ feat, int cn,
+                                             int sbin, int tc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const HogTile t = tiles[blockIdx.x];
+  const LevelDev lv = levels[t.level];
+  const HogLds L = hog_lds_layout(sbin, tc);
+  float* mag = (float*)(smem + L.mag_off);
+  uint8_t* bin = (uint8_t*)(smem + L.bin_off);
+  float* hist = (float*)(smem + L.hist_off);
+  float* norm = (float*)(smem + L.norm_off);
+  float* ninv = (float*)(smem + L.ninv_off);
+  float* wy0 = (float*)(smem + L.tab_off);  // vy0 per window row
+  float* wy1 = wy0 + L.PT;
+  float* wx0 = wy1 + L.PT;
+  float* wx1 = wx0 + L.PT;
+  int* ipy = (int*)(wx1 + L.PT);
+  int* ipx = ipy + L.PT;
+  const int PT = L.PT, NB = L.NB, tid = threadIdx.x;
+  const int w = lv.iw, h = lv.ih, bw = lv.bw, bh = lv.bh;
+  const int vw = bw * sbin, vh = bh * sbin;  // :176 visible
+  const uint8_t* im = pyr + lv.img_off;
+  const int stride = w * cn;
+  // pixel window origin: first pixel that can touch block (cy0, cx0), minus one for safety
+  const int py0 = t.cy0 * sbin - sbin / 2 - 1, px0 = t.cx0 * sbin - sbin / 2 - 1;
+
+  // ---- interpolation tables per window row / column (:252-260) ----
+  for (int i = tid; i < 2 * PT; i += 256) {
+    const bool isx = i >= PT;
+    const int j = isx ? i - PT : i;
+    const int p = (isx ? px0 : py0) + j;
+    float pp = (float)(((double)(float)p + 0.5) / (double)(float)sbin - 0.5);
+    int ip = (int)floorf(pp);
+    float v0 = pp - (float)ip;
+    float v1 = (float)(1.0 - (double)v0);
+    if (isx) { wx0[j] = v0; wx1[j] = v1; ipx[j] = ip; }
+    else { wy0[j] = v0; wy1[j] = v1; ipy[j] = ip; }
+  }
+
+  // ---- per-pixel gradient magnitude + orientation bin (:202-249) ----
+  const float uu[9] = {1.000, 0.9397, 0.7660, 0.5000, 0.1736, -0.1736, -0.5000, -0.7660, -0.9397};
+  const float vv[9] = {0.000, 0.3420, 0.6428, 0.8660, 0.9848, 0.9848, 0.8660, 0.6428, 0.3420};
+  for (int i = tid; i < PT * PT; i += 256) {
+    const int wy = i / PT, wx = i - wy * PT;
+    const int y = py0 + wy, x = px0 + wx;
+    float m = 0.f;
+    int b = 255;
+    if (y >= 1 && y < vh - 1 && x >= 1 && x < vw - 1) {
+      const int sx = min(x, w - 2), sy = min(y, h - 2);
+      float dx, dy, v;
+      if (cn == 1) {
+        const uint8_t* s = im + sx + (size_t)sy * stride;
+        dy = (float)((int)s[stride] - (int)s[-stride]);
+        dx = (float)((int)s[1] - (int)s[-1]);
+        v = dx * dx + dy * dy;
+      } else {
+        const uint8_t* s = im + 3 * sx + (size_t)sy * stride;
+        float dyb = (float)((int)s[stride] - (int)s[-stride]);
+        float dxb = (float)((int)s[3] - (int)s[-3]);
+        float vb = dxb * dxb + dyb * dyb;
+        float dyg = (float)((int)s[stride + 1] - (int)s[-stride + 1]);
+        float dxg = (float)((int)s[4] - (int)s[-2]);
+        float vg = dxg * dxg + dyg * dyg;
+        dy = (float)((int)s[stride + 2] - (int)s[-stride + 2]);
+        dx = (float)((int)s[5] - (int)s[-1]);
+        v = dx * dx + dy * dy;
+        if (vg > v) { v = vg; dx = dxg; dy = dyg; }
+        if (vb > v) { v = vb; dx = dxb; dy = dyb; }
+      }
+      float best_dot = 0;
+      int best_o = 0;
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        float dot = uu[o] * dx + vv[o] * dy;
+        if (dot > best_dot) { best_dot = dot; best_o = o; }
+        else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
+      }
+      m = sqrtf(v);
+      b = best_o;
+    }
+    mag[i] = m;
+    bin[i] = (uint8_t)b;
+  }
+  __syncthreads();
+
+  // ---- histogram gather: one thread per (block, orientation) bin (:262-265) ----
+  for (int i = tid; i < NB * NB * PBD_NORIENT; i += 256) {
+    const int o = i % PBD_NORIENT;
+    const int bl = i / PBD_NORIENT;
+    const int lby = bl / NB, lbx = bl - lby * NB;
+    const int by = t.cy0 + lby, bx = t.cx0 + lbx;
+    float acc = 0.f;
+    if (by < bh && bx < bw) {
+      // candidate window rows/cols: every pixel with ip in {b-1, b}
+      const int wy_lo = lby * sbin, wx_lo = lbx * sbin;  // (py0 offset makes this a superset start)
+      const int span = 2 * sbin + 2;
+      for (int dy = 0; dy < span; ++dy) {
+        const int wy = wy_lo + dy;
+        if (wy >= PT) break;
+        const int iy = ipy[wy];
+        float fy;
+        if (iy == by) fy = wy1[wy]; else if (iy == by - 1) fy = wy0[wy]; else continue;
+        for (int dx = 0; dx < span; ++dx) {
+          const int wx = wx_lo + dx;
+          if (wx >= PT) break;
+          if (bin[wy * PT + wx] != o) continue;
+          const int ix = ipx[wx];
+          float fx;
+          if (ix == bx) fx = wx1[wx]; else if (ix == bx - 1) fx = wx0[wx]; else continue;
+          acc += (fy * fx) * mag[wy * PT + wx];
+        }
+      }
+    }
+    hist[i] = acc;
+  }
+  __syncthreads();
+
+  // ---- block energy (:270-283) ----
+  for (int i = tid; i < NB * NB; i += 256) {
+    const float* hsrc = hist + i * PBD_NORIENT;
+    float acc = 0.f;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      float s = hsrc[o] + hsrc[o + 9];
+      acc += s * s;
+    }
+    norm[i] = acc;
+  }
+  __syncthreads();
+
+  // ---- normalisers on the (TC+1)^2 block corners (:292-299) ----
+  const int NC = tc + 1;
+  for (int i = tid; i < NC * NC; i += 256) {
+    const int y = i / NC, x = i - y * NC;
+    const float* p = norm + y * NB + x;
+    float s = p[0] + p[1] + p[NB] + p[NB + 1];
+    ninv[i] = (float)(1.0f / sqrt((double)s + 0.0001));
+  }
+  __syncthreads();
+
+  // ---- 32 features per cell, one lane per feature (:301-338) ----
+  float* out = feat + lv.cell_off * PBD_FLEN;
+  for (int i = tid; i < tc * tc * PBD_FLEN; i += 256) {
+    const int k = i & 31;
+    const int cell = i >> 5;
+    const int ly = cell / tc, lx = cell - ly * tc;
+    const int cy = t.cy0 + ly, cx = t.cx0 + lx;
+    if (cy >= lv.ch || cx >= lv.cw) continue;
+    const float n1 = ninv[(ly + 1) * NC + lx + 1], n2 = ninv[ly * NC + lx + 1];
+    const float n3 = ninv[(ly + 1) * NC + lx], n4 = ninv[ly * NC + lx];
+    const float* hsrc = hist + ((ly + 1) * NB + lx + 1) * PBD_NORIENT;
+    float r;
+    if (k < 27) {
+      float val = (k < 18) ? hsrc[k] : hsrc[k - 18] + hsrc[k - 9];
+      float h1 = fminf(val * n1, 0.2f), h2 = fminf(val * n2, 0.2f);
+      float h3 = fminf(val * n3, 0.2f), h4 = fminf(val * n4, 0.2f);
+      r = (float)(0.5 * (double)(h1 + h2 + h3 + h4));
+    } else if (k < 31) {
+      const float n = (k == 27) ? n1 : (k == 28) ? n2 : (k == 29) ? n3 : n4;
+      float tsum = 0.f;
+#pragma unroll
+      for (int o = 0; o < PBD_NORIENT; ++o) tsum += fminf(hsrc[o] * n, 0.2f);
+      r = (float)(0.2357 * (double)tsum);
+    } else {
+      r = 0.f;
+    }
+    out[((size_t)cy * lv.cw + cx) * PBD_FLEN + k] = r;
+  }
+}
+
+void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, float* feat,
+                int cn, int sbin, int tc, hipStream_t s) {
+  if (ntiles <= 0) return;
+  size_t lds = hog_lds_bytes(sbin, tc);
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipFuncSetAttribute((const void*)k_hog, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = lds;
+  }
+  hipLaunchKernelGGL(k_hog, dim3(ntiles), dim3(256), lds, s, tiles, levels, pyr, feat, cn, sbin, tc);
+}

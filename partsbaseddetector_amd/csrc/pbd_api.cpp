@@ -1,0 +1,1090 @@
+// pbd_api.cpp — host side of libpbd_hip.so: model ingestion, part-tree round
+// scheduling, per-geometry frame plan (buffers + kernel work tables), stage
+// orchestration and the C ABI of include/pbd_c.h.
+//
+// The product path never falls back to a CPU implementation: every stage is a
+// HIP kernel launch; host code only plans, launches and (for the few hundred
+// candidates of a frame) orders the output like a single-threaded reference run.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include "pbd_internal.hpp"
+
+#define HIPCHK(h, call)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return PBD_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+static int fail(pbd_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+// ---------------------------------------------------------------------------
+// pyramid geometry — HOGFeatures<T>::pyramid, src/HOGFeatures.cpp:98-127,174-175
+// ---------------------------------------------------------------------------
+static inline int cv_round_f(float v) { return (int)std::lrint((double)v); }
+
+static int compute_geometry(int w, int h, int sbin, int interval, int* nlevels, Level* lv) {
+  const float sf = (float)std::pow(2.0, (double)(1.0f / (float)interval));  // HOGFeatures.hpp:78
+  const float fw = (float)w, fh = (float)h;
+  const float mn = fh < fw ? fh : fw;
+  const float r = std::log(mn / (5.0f * (float)sbin)) / std::log(sf);          // :99 (float math)
+  const int n = (int)(1.0f + std::floor(r));
+  if (n < interval || n > PBD_MAX_LEVELS) return -1;
+  for (int i = 0; i < interval; ++i) {
+    const float f = (float)(1.0f / std::pow((double)sf, (double)i));            // :116
+    lv[i].iw = cv_round_f(fw * f);
+    lv[i].ih = cv_round_f(fh * f);
+    lv[i].scale = (float)(std::pow((double)sf, (double)i) * (double)sbin);      // :118
+    for (int j = i + interval; j < n; j += interval) {
+      lv[j].iw = (lv[j - interval].iw + 1) / 2;                                 // :122 pyrDown
+      lv[j].ih = (lv[j - interval].ih + 1) / 2;
+      lv[j].scale = 2 * lv[j - interval].scale;                                 // :124
+    }
+  }
+  for (int l = 0; l < n; ++l) {
+    lv[l].bw = (int)std::round((float)lv[l].iw / (float)sbin);                  // :174
+    lv[l].bh = (int)std::round((float)lv[l].ih / (float)sbin);
+    lv[l].cw = std::max(lv[l].bw - 2, 0);                                       // :175
+    lv[l].ch = std::max(lv[l].bh - 2, 0);
+  }
+  *nlevels = n;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------
+static int nmix_of(const pbd_handle* h, int fp) { return h->mix_offset[fp + 1] - h->mix_offset[fp]; }
+
+static int ingest_model(pbd_handle* h, const pbd_model_desc* m) {
+  if (!m || !m->filters || !m->defw || !m->anchors || !m->biasw || !m->part_offset || !m->parentid ||
+      !m->mix_offset || !m->filterid || !m->defid || !m->biasid)
+    return fail(h, PBD_ERR_ARG, "model: null pointer");
+  if (m->flen != PBD_FLEN || m->norient != PBD_NORIENT)
+    return fail(h, PBD_ERR_UNSUPPORTED, "model: only flen=32 / norient=18 HOG is supported");
+  if (m->nfilters <= 0 || m->kh <= 0 || m->kw <= 0 || m->kh > 9 || m->kw > 9 || m->sbin <= 0 || m->interval <= 0 ||
+      m->interval > 16 || m->ncomponents <= 0)
+    return fail(h, PBD_ERR_ARG, "model: bad sizes");
+  const int nc = m->ncomponents;
+  h->part_offset.assign(m->part_offset, m->part_offset + nc + 1);
+  const int np = h->part_offset[nc];
+  h->parentid.assign(m->parentid, m->parentid + np);
+  h->mix_offset.assign(m->mix_offset, m->mix_offset + np + 1);
+  const int nm = h->mix_offset[np];
+  h->filterid.assign(m->filterid, m->filterid + nm);
+  h->defid.assign(m->defid, m->defid + nm);
+  h->biasid.assign(m->biasid, m->biasid + nm);
+  h->filters.assign(m->filters, m->filters + (size_t)m->nfilters * m->kh * m->kw * m->flen);
+  h->defw.assign(m->defw, m->defw + (size_t)m->ndefs * 4);
+  h->anchors.assign(m->anchors, m->anchors + (size_t)m->ndefs * 2);
+  h->biasw.assign(m->biasw, m->biasw + m->nbias);
+  h->md = *m;
+  h->md.filters = h->filters.data(); h->md.defw = h->defw.data(); h->md.anchors = h->anchors.data();
+  h->md.biasw = h->biasw.data(); h->md.part_offset = h->part_offset.data(); h->md.parentid = h->parentid.data();
+  h->md.mix_offset = h->mix_offset.data(); h->md.filterid = h->filterid.data(); h->md.defid = h->defid.data();
+  h->md.biasid = h->biasid.data();
+
+  h->parts.resize(np);
+  h->comp_plane0.assign(nc + 1, 0);
+  h->max_parts = 0;
+  int slot_next = 0, plane_next = 0;
+  bool aliasing = false;
+  for (int c = 0; c < nc; ++c) {
+    const int p0 = h->part_offset[c], cnp = h->part_offset[c + 1] - p0;
+    if (cnp <= 0) return fail(h, PBD_ERR_ARG, "model: empty component");
+    h->max_parts = std::max(h->max_parts, cnp);
+    h->comp_plane0[c] = plane_next;
+    std::map<int, int> slot_of;   // filter id -> slot (ncscores is indexed by filter id, DynamicProgram.cpp:93)
+    std::map<int, int> uses;
+    std::vector<int> nchild(cnp, 0);
+    for (int p = 1; p < cnp; ++p) {
+      const int par = h->parentid[p0 + p];
+      if (par < 0 || par >= p) return fail(h, PBD_ERR_ARG, "model: parts must be ordered parent < child");
+      nchild[par]++;
+    }
+    for (int p = 0; p < cnp; ++p) {
+      PartInfo& P = h->parts[p0 + p];
+      P.comp = c; P.p = p; P.parent = (p == 0) ? -1 : h->parentid[p0 + p];
+      P.K = nmix_of(h, p0 + p);
+      if (P.K <= 0 || P.K > PBD_MAX_MIX) return fail(h, PBD_ERR_UNSUPPORTED, "model: 1..16 mixtures per part");
+      P.leaf = (nchild[p] == 0);
+      const int fm0 = h->mix_offset[p0 + p];
+      for (int m2 = 0; m2 < P.K; ++m2) {
+        const int fid = h->filterid[fm0 + m2];
+        if (fid < 0 || fid >= m->nfilters) return fail(h, PBD_ERR_ARG, "model: filterid out of range");
+        P.filterid.push_back(fid);
+        P.defid.push_back(h->defid[fm0 + m2]);
+        P.biasid.push_back(h->biasid[fm0 + m2]);
+        if (!slot_of.count(fid)) slot_of[fid] = slot_next++;
+        P.slot.push_back(slot_of[fid]);
+        if (++uses[fid] > 1) aliasing = true;
+        if (p > 0) {
+          const int did = h->defid[fm0 + m2];
+          if (did < 0 || did >= m->ndefs) return fail(h, PBD_ERR_ARG, "model: defid out of range");
+          if (h->defw[did * 4] == 0.f || h->defw[did * 4 + 2] == 0.f)
+            return fail(h, PBD_ERR_ARG, "model: quadratic deformation weights must be non-zero "
+                                        "(include/DistanceTransform.hpp:99 divides by 2a)");
+        }
+        const int bid = h->biasid[fm0 + m2];
+        const int L = (p == 0) ? 1 : nmix_of(h, p0 + h->parentid[p0 + p]);
+        if (bid < 0 || bid + L > m->nbias) return fail(h, PBD_ERR_ARG, "model: biasid out of range");
+      }
+      P.plane0 = -1;
+      if (p > 0) {
+        P.plane0 = plane_next;
+        plane_next += nmix_of(h, p0 + P.parent);
+      }
+    }
+  }
+  h->comp_plane0[nc] = plane_next;
+  h->nslots = slot_next;
+  h->nplanes = plane_next;
+
+  // ---- round schedule -------------------------------------------------------
+  // A part is transformed once all its children have sent their message
+  // (DynamicProgram.cpp:95 walks p = P-1..1 and parent < child).  Messages into
+  // one parent are float adds in descending child order (:156), so siblings are
+  // serialised in that order; everything else in a round is independent.
+  h->rounds.clear();
+  std::vector<int> done(np, 0);
+  if (aliasing) {  // shared filter ids inside a component: keep the reference's sequential order
+    for (int c = 0; c < nc; ++c)
+      for (int p = h->part_offset[c + 1] - h->part_offset[c] - 1; p > 0; --p)
+        h->rounds.push_back(std::vector<int>(1, h->part_offset[c] + p));
+  } else {
+    int remaining = 0;
+    for (int fp = 0; fp < np; ++fp) if (h->parts[fp].p > 0) remaining++;
+    while (remaining > 0) {
+      std::vector<int> rnd;
+      for (int fp = 0; fp < np; ++fp) {
+        const PartInfo& P = h->parts[fp];
+        if (P.p == 0 || done[fp]) continue;
+        const int p0 = h->part_offset[P.comp], cnp = h->part_offset[P.comp + 1] - p0;
+        bool ready = true;
+        for (int q = P.p + 1; q < cnp && ready; ++q) {
+          if (done[p0 + q]) continue;
+          if (h->parts[p0 + q].parent == P.p) ready = false;          // a child not yet processed
+          if (h->parts[p0 + q].parent == P.parent) ready = false;     // a later sibling not yet processed
+        }
+        if (ready) rnd.push_back(fp);
+      }
+      if (rnd.empty()) return fail(h, PBD_ERR_ARG, "model: part tree cannot be scheduled");
+      for (int fp : rnd) done[fp] = 1;
+      remaining -= (int)rnd.size();
+      h->rounds.push_back(rnd);
+    }
+  }
+  return PBD_OK;
+}
+
+static int upload_model(pbd_handle* h) {
+  const pbd_model_desc& m = h->md;
+  // filters transposed to [tap][c][nfpad] (n contiguous): scalar loads in the VALU kernel,
+  // B-operand rows in the MFMA kernel.  nfpad is a multiple of 160 (5 x 32-wide MFMA n-tiles).
+  h->nfpad = ((m.nfilters + 159) / 160) * 160;
+  std::vector<float> wT((size_t)m.kh * m.kw * m.flen * h->nfpad, 0.f);
+  for (int n = 0; n < m.nfilters; ++n)
+    for (int i = 0; i < m.kh; ++i)
+      for (int j = 0; j < m.kw; ++j)
+        for (int c = 0; c < m.flen; ++c)
+          wT[((size_t)(i * m.kw + j) * m.flen + c) * h->nfpad + n] =
+              h->filters[(((size_t)n * m.kh + i) * m.kw + j) * m.flen + c];
+  HIPCHK(h, hipMalloc(&h->d_wT, wT.size() * sizeof(float)));
+  HIPCHK(h, hipMemcpy(h->d_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
+  // biasw plus one trailing 0 (used by the stand-alone pbd_dt2d)
+  std::vector<float> bw(h->biasw);
+  bw.push_back(0.f);
+  HIPCHK(h, hipMalloc(&h->d_biasw, bw.size() * sizeof(float)));
+  HIPCHK(h, hipMemcpy(h->d_biasw, bw.data(), bw.size() * sizeof(float), hipMemcpyHostToDevice));
+  const int nc = m.ncomponents, mp = h->max_parts;
+  std::vector<int> par(nc * mp, 0), pl0(nc * mp, 0), npv(nc, 0);
+  for (int c = 0; c < nc; ++c) {
+    const int p0 = h->part_offset[c], cnp = h->part_offset[c + 1] - p0;
+    npv[c] = cnp;
+    for (int p = 0; p < cnp; ++p) {
+      par[c * mp + p] = h->parts[p0 + p].parent;
+      pl0[c * mp + p] = (p > 0) ? h->parts[p0 + p].plane0 - h->comp_plane0[c] : 0;
+    }
+  }
+  HIPCHK(h, hipMalloc(&h->d_parent, par.size() * sizeof(int)));
+  HIPCHK(h, hipMalloc(&h->d_plane0, pl0.size() * sizeof(int)));
+  HIPCHK(h, hipMalloc(&h->d_nparts, npv.size() * sizeof(int)));
+  HIPCHK(h, hipMemcpy(h->d_parent, par.data(), par.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_plane0, pl0.data(), pl0.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_nparts, npv.data(), npv.size() * sizeof(int), hipMemcpyHostToDevice));
+  // candidates
+  const int cap = h->opt.max_candidates;
+  h->cand_stride = sizeof(pbd_candidate_head) + (size_t)mp * 28;
+  HIPCHK(h, hipMalloc(&h->d_cand_count, sizeof(int)));
+  HIPCHK(h, hipMalloc(&h->d_cand_rec, sizeof(CandRec) * cap));
+  HIPCHK(h, hipMalloc(&h->d_cand_out, h->cand_stride * cap));
+  HIPCHK(h, hipHostMalloc((void**)&h->h_cand_out, h->cand_stride * cap));
+  HIPCHK(h, hipHostMalloc((void**)&h->h_cand_count, sizeof(int) * 4));
+  return PBD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// frame plan
+// ---------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(pbd_handle* h, T** p, size_t n) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) { h->err = std::string("hipMalloc: ") + hipGetErrorString(e); return PBD_ERR_HIP; }
+  h->frame_allocs.push_back(q);
+  *p = (T*)q;
+  return PBD_OK;
+}
+template <typename T>
+static int dev_upload(pbd_handle* h, T** p, const std::vector<T>& v) {
+  int rc = dev_alloc(h, p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(h, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PBD_OK;
+}
+
+static void free_frame(pbd_handle* h) {
+  for (void* p : h->frame_allocs) hipFree(p);
+  h->frame_allocs.clear();
+  h->fw = h->fh = h->fcn = 0;
+  h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
+}
+
+static int dt_class_of(int len) { return len >= 256 ? 0 : (len >= 80 ? 1 : (len >= 32 ? 2 : 3)); }
+
+static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
+  if (h->fw == w && h->fh == hgt && h->fcn == cn) return PBD_OK;
+  if (cn != 1 && cn != 3) return fail(h, PBD_ERR_UNSUPPORTED, "image: 1 or 3 channels of 8 bits");
+  hipStreamSynchronize(h->stream);
+  free_frame(h);
+  const pbd_model_desc& m = h->md;
+  int n = 0;
+  if (w < 3 || hgt < 3 || compute_geometry(w, hgt, m.sbin, m.interval, &n, h->lv))
+    return fail(h, PBD_ERR_ARG, "image too small: the pyramid needs at least `interval` levels "
+                                "(src/HOGFeatures.cpp:99,114)");
+  h->nlevels = n;
+  int lb = h->opt.level_begin, le = h->opt.level_end;
+  if (le <= 0 || le > n) le = n;
+  if (lb < 0) lb = 0;
+  size_t cells = 0, pyr = 0;
+  for (int l = 0; l < n; ++l) {
+    Level& L = h->lv[l];
+    L.active = (l >= lb && l < le);
+    if (L.cw > 32767 || L.ch > 32767) return fail(h, PBD_ERR_UNSUPPORTED, "level too large for 16-bit pointers");
+    L.img_off = pyr; pyr += (size_t)L.iw * L.ih * cn;
+    L.cell_off = cells; cells += (size_t)L.cw * L.ch;
+  }
+  h->cells = cells; h->pyr_bytes = pyr;
+  if (cells >= (1u << 31)) return fail(h, PBD_ERR_UNSUPPORTED, "frame too large");
+  int rc;
+  if ((rc = dev_alloc(h, &h->d_img, (size_t)w * hgt * cn))) return rc;
+  if ((rc = dev_alloc(h, &h->d_pyr, pyr))) return rc;
+  if ((rc = dev_alloc(h, &h->d_feat, cells * PBD_FLEN))) return rc;
+  if ((rc = dev_alloc(h, &h->d_resp, cells * m.nfilters))) return rc;
+  if ((rc = dev_alloc(h, &h->d_acc, cells * h->nslots))) return rc;
+  if ((rc = dev_alloc(h, &h->d_px, cells * std::max(h->nplanes, 1)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_py, cells * std::max(h->nplanes, 1)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_pk, cells * std::max(h->nplanes, 1)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_rootv, cells * m.ncomponents))) return rc;
+  if ((rc = dev_alloc(h, &h->d_rooti, cells * m.ncomponents))) return rc;
+
+  std::vector<LevelDev> ld(n);
+  for (int l = 0; l < n; ++l) {
+    const Level& L = h->lv[l];
+    ld[l] = LevelDev{L.iw, L.ih, L.bw, L.bh, L.cw, L.ch, (unsigned long long)L.img_off, (unsigned long long)L.cell_off};
+  }
+  if ((rc = dev_upload(h, &h->d_levels, ld))) return rc;
+
+  // HOG tiles: TC x TC cells; shrink the tile until its LDS footprint fits
+  h->hog_tc = 16;
+  while (h->hog_tc > 2 && hog_lds_bytes(m.sbin, h->hog_tc) > 150 * 1024) h->hog_tc /= 2;
+  if (hog_lds_bytes(m.sbin, h->hog_tc) > 150 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "sbin too large");
+  std::vector<HogTile> ht;
+  std::vector<ConvTile> ct;
+  for (int l = 0; l < n; ++l) {
+    const Level& L = h->lv[l];
+    if (!L.active || L.cw == 0 || L.ch == 0) continue;
+    for (int y = 0; y < L.ch; y += h->hog_tc)
+      for (int x = 0; x < L.cw; x += h->hog_tc) ht.push_back(HogTile{l, y, x, 0});
+    for (int y = 0; y < L.ch; y += 16)
+      for (int x = 0; x < L.cw; x += 16) ct.push_back(ConvTile{l, y, x, 0});
+  }
+  h->n_hog_tiles = (int)ht.size();
+  h->n_conv_tiles = (int)ct.size();
+  if ((rc = dev_upload(h, &h->d_hog_tiles, ht))) return rc;
+  if ((rc = dev_upload(h, &h->d_conv_tiles, ct))) return rc;
+
+  // ---- DP tables ---------------------------------------------------------------
+  // scratch capacity: max over rounds of sum_{parts in round} K * cells(active)
+  size_t act_cells = 0;
+  for (int l = 0; l < n; ++l) if (h->lv[l].active) act_cells += (size_t)h->lv[l].cw * h->lv[l].ch;
+  size_t maxmaps = 1;
+  for (auto& rnd : h->rounds) { size_t k = 0; for (int fp : rnd) k += h->parts[fp].K; maxmaps = std::max(maxmaps, k); }
+  h->dt_cap_elems = maxmaps * act_cells;
+  if ((rc = dev_alloc(h, &h->d_dt_tmpT, h->dt_cap_elems))) return rc;
+  if ((rc = dev_alloc(h, &h->d_dt_sdt, h->dt_cap_elems))) return rc;
+  if ((rc = dev_alloc(h, &h->d_dt_ixT, h->dt_cap_elems))) return rc;
+  if ((rc = dev_alloc(h, &h->d_dt_iy, h->dt_cap_elems))) return rc;
+
+  // DT size classes: one launch per class so short lines do not inherit the LDS footprint of long ones
+  for (int p = 0; p < 2; ++p) for (int c = 0; c < 4; ++c) { h->dt_stride[p][c] = 0; h->dt_lpb[p][c] = 64; }
+  for (int l = 0; l < n; ++l) {
+    const Level& L = h->lv[l];
+    if (!L.active || L.cw == 0 || L.ch == 0) continue;
+    int& sx = h->dt_stride[0][dt_class_of(L.cw)]; sx = std::max(sx, (L.cw + 1) | 1);
+    int& sy = h->dt_stride[1][dt_class_of(L.ch)]; sy = std::max(sy, (L.ch + 1) | 1);
+  }
+  for (int p = 0; p < 2; ++p)
+    for (int c = 0; c < 4; ++c) {
+      int& lpb = h->dt_lpb[p][c];
+      while (lpb > 8 && dt_lds_bytes(h->dt_stride[p][c], lpb) > 160 * 1024) lpb /= 2;
+      if (dt_lds_bytes(h->dt_stride[p][c], lpb) > 160 * 1024)
+        return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
+    }
+  std::vector<DtMap> maps;
+  std::vector<DtGroup> groups;
+  std::vector<DtTask> tasks;
+  std::vector<ReduceJob> red;
+  h->rl.clear();
+  std::vector<char> slot_init((size_t)h->nslots, 0);  // ncscores[fid].empty() emulation (same for every level)
+  for (auto& rnd : h->rounds) {
+    pbd_handle::RoundLaunch R{};
+    // tasks of this round, bucketed by size class for both passes
+    std::vector<DtTask> xt[4], yt[4];
+    R.red0 = (int)red.size();
+    unsigned red_cells = 0;
+    size_t scratch = 0;
+    std::vector<char> slot_after = slot_init;
+    for (int l = 0; l < n; ++l) {
+      const Level& L = h->lv[l];
+      if (!L.active || L.cw == 0 || L.ch == 0) continue;
+      const size_t HW = (size_t)L.cw * L.ch;
+      DtGroup gx{(int)maps.size(), 0, L.ch, L.cw};
+      std::vector<DtMap> ymaps;
+      for (int fp : rnd) {
+        const PartInfo& P = h->parts[fp];
+        const PartInfo& Par = h->parts[h->part_offset[P.comp] + P.parent];
+        ReduceJob J{};
+        J.sdt = h->d_dt_sdt + scratch;
+        J.ixT = h->d_dt_ixT + scratch;
+        J.iy = h->d_dt_iy + scratch;
+        J.H = L.ch; J.W = L.cw; J.K = P.K; J.L = Par.K;
+        J.cell0 = red_cells;
+        for (int mm = 0; mm < P.K; ++mm) {
+          const int fid = P.filterid[mm], did = P.defid[mm];
+          const float* src = slot_init[P.slot[mm]] ? h->d_acc + L.cell_off * h->nslots + (size_t)P.slot[mm] * HW
+                                                   : h->d_resp + L.cell_off * m.nfilters + (size_t)fid * HW;
+          const float* wv = &h->defw[(size_t)did * 4];
+          DtMap mx{src, h->d_dt_tmpT + scratch, h->d_dt_ixT + scratch, -(double)wv[0], -(double)wv[1],
+                   h->anchors[did * 2], 0};
+          DtMap my{h->d_dt_tmpT + scratch, h->d_dt_sdt + scratch, h->d_dt_iy + scratch, -(double)wv[2],
+                   -(double)wv[3], h->anchors[did * 2 + 1], 0};
+          maps.push_back(mx);
+          ymaps.push_back(my);
+          gx.nmaps++;
+          J.bias_off[mm] = P.biasid[mm];
+          scratch += HW;
+        }
+        for (int pm = 0; pm < Par.K; ++pm) {
+          const int pslot = Par.slot[pm], pfid = Par.filterid[pm];
+          float* accp = h->d_acc + L.cell_off * h->nslots + (size_t)pslot * HW;
+          J.par_in[pm] = slot_after[pslot] ? accp : h->d_resp + L.cell_off * m.nfilters + (size_t)pfid * HW;
+          J.par_out[pm] = accp;
+          const size_t po = L.cell_off * h->nplanes + (size_t)(P.plane0 + pm) * HW;
+          J.ox[pm] = h->d_px + po; J.oy[pm] = h->d_py + po; J.ok[pm] = h->d_pk + po;
+        }
+        red.push_back(J);
+        red_cells += (unsigned)HW;
+      }
+      DtGroup gy{(int)maps.size(), gx.nmaps, L.cw, L.ch};
+      for (auto& my : ymaps) maps.push_back(my);
+      const int gxi = (int)groups.size();
+      groups.push_back(gx);
+      const int gyi = (int)groups.size();
+      groups.push_back(gy);
+      const int cx = dt_class_of(gx.len), cy = dt_class_of(gy.len);
+      for (int g0 = 0; g0 < gx.nmaps * gx.nlines; g0 += h->dt_lpb[0][cx]) xt[cx].push_back(DtTask{gxi, g0});
+      for (int g0 = 0; g0 < gy.nmaps * gy.nlines; g0 += h->dt_lpb[1][cy]) yt[cy].push_back(DtTask{gyi, g0});
+    }
+    // after this round the parents' slots hold accumulated scores
+    for (int fp : rnd) {
+      const PartInfo& P = h->parts[fp];
+      const PartInfo& Par = h->parts[h->part_offset[P.comp] + P.parent];
+      for (int pm = 0; pm < Par.K; ++pm) slot_init[Par.slot[pm]] = 1;
+    }
+    (void)slot_after;
+    for (int c = 0; c < 4; ++c) {
+      R.xtask0[c] = (int)tasks.size(); R.nxtasks[c] = (int)xt[c].size();
+      tasks.insert(tasks.end(), xt[c].begin(), xt[c].end());
+    }
+    for (int c = 0; c < 4; ++c) {
+      R.ytask0[c] = (int)tasks.size(); R.nytasks[c] = (int)yt[c].size();
+      tasks.insert(tasks.end(), yt[c].begin(), yt[c].end());
+    }
+    R.nred = (int)red.size() - R.red0;
+    R.red_cells = red_cells;
+    h->rl.push_back(R);
+  }
+  if ((rc = dev_upload(h, &h->d_dtmaps, maps))) return rc;
+  if ((rc = dev_upload(h, &h->d_dtgroups, groups))) return rc;
+  if ((rc = dev_upload(h, &h->d_dttasks, tasks))) return rc;
+  if ((rc = dev_upload(h, &h->d_redjobs, red))) return rc;
+
+  // root jobs + backtracking info
+  std::vector<RootJob> rj;
+  std::vector<BackLevel> bl((size_t)n * m.ncomponents);
+  unsigned rcells = 0;
+  for (int l = 0; l < n; ++l) {
+    const Level& L = h->lv[l];
+    const size_t HW = (size_t)L.cw * L.ch;
+    for (int c = 0; c < m.ncomponents; ++c) {
+      BackLevel& B = bl[(size_t)l * m.ncomponents + c];
+      const size_t po = L.cell_off * h->nplanes + (size_t)h->comp_plane0[c] * HW;
+      B.px = h->d_px + po; B.py = h->d_py + po; B.pk = h->d_pk + po;
+      B.rootv = h->d_rootv + L.cell_off * m.ncomponents + (size_t)c * HW;
+      B.rooti = h->d_rooti + L.cell_off * m.ncomponents + (size_t)c * HW;
+      B.H = L.ch; B.W = L.cw; B.scale = L.scale;
+      if (!L.active || HW == 0) continue;
+      const PartInfo& R0 = h->parts[h->part_offset[c]];
+      RootJob J{};
+      for (int k = 0; k < R0.K; ++k)
+        J.score[k] = slot_init[R0.slot[k]] ? h->d_acc + L.cell_off * h->nslots + (size_t)R0.slot[k] * HW
+                                           : h->d_resp + L.cell_off * m.nfilters + (size_t)R0.filterid[k] * HW;
+      J.rootv = (float*)B.rootv; J.rooti = (int*)B.rooti;
+      J.H = L.ch; J.W = L.cw; J.K = R0.K; J.level = l; J.comp = c;
+      J.bias = h->biasw[R0.biasid[0]];  // root.bias(0)[0], DynamicProgram.cpp:165
+      J.cell0 = rcells;
+      rcells += (unsigned)HW;
+      rj.push_back(J);
+    }
+  }
+  h->n_rootjobs = (int)rj.size();
+  h->root_cells = rcells;
+  if ((rc = dev_upload(h, &h->d_rootjobs, rj))) return rc;
+  if ((rc = dev_upload(h, &h->d_back, bl))) return rc;
+  h->fw = w; h->fh = hgt; h->fcn = cn;
+  return PBD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stages
+// ---------------------------------------------------------------------------
+static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
+  const pbd_model_desc& m = h->md;
+  ResizeArgs ra{};
+  ra.n = m.interval; ra.sw = h->fw; ra.sh = h->fh; ra.cn = h->fcn; ra.sstride = stride;
+  for (int i = 0; i < m.interval; ++i) { ra.dw[i] = h->lv[i].iw; ra.dh[i] = h->lv[i].ih; ra.off[i] = h->lv[i].img_off; }
+  launch_resize(ra, d_src, h->d_pyr, h->stream);
+  for (int base = m.interval; base < h->nlevels; base += m.interval) {
+    PyrDownArgs pa{};
+    pa.cn = h->fcn;
+    for (int j = base; j < std::min(base + m.interval, h->nlevels); ++j) {
+      const int k = pa.n++;
+      pa.sw[k] = h->lv[j - m.interval].iw; pa.sh[k] = h->lv[j - m.interval].ih;
+      pa.soff[k] = h->lv[j - m.interval].img_off; pa.doff[k] = h->lv[j].img_off;
+    }
+    launch_pyrdown(pa, h->d_pyr, h->stream);
+  }
+  h->have_pyr = true;
+  return PBD_OK;
+}
+
+static int run_hog(pbd_handle* h) {
+  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->fcn, h->md.sbin, h->hog_tc, h->stream);
+  h->have_feat = true;
+  return PBD_OK;
+}
+
+static int run_pdf(pbd_handle* h) {
+  const pbd_model_desc& m = h->md;
+  if (h->conv_mode == PBD_CONV_MFMA)
+    launch_conv_mfma(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat, h->d_wT, h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
+  else
+    launch_conv_exact(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat, h->d_wT, h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
+  h->have_resp = true;
+  return PBD_OK;
+}
+
+static int run_dp_min(pbd_handle* h) {
+  if (h->dp_timer_on) hipEventRecord(h->ev_dp0, h->stream);
+  for (auto& R : h->rl) {
+    for (int c = 0; c < 4; ++c)
+      launch_dt_pass(h->d_dttasks + R.xtask0[c], R.nxtasks[c], h->d_dtgroups, h->d_dtmaps, h->dt_stride[0][c], h->dt_lpb[0][c], h->stream);
+    for (int c = 0; c < 4; ++c)
+      launch_dt_pass(h->d_dttasks + R.ytask0[c], R.nytasks[c], h->d_dtgroups, h->d_dtmaps, h->dt_stride[1][c], h->dt_lpb[1][c], h->stream);
+    launch_reduce(h->d_redjobs + R.red0, R.nred, R.red_cells, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
+  }
+  hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
+  launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
+              h->opt.max_candidates, h->stream);
+  if (h->dp_timer_on) hipEventRecord(h->ev_dp1, h->stream);
+  h->have_dp = true;
+  return PBD_OK;
+}
+
+static const int kFirstCopy = 192;  // records fetched together with the count
+
+static int run_argmin_enqueue(pbd_handle* h) {
+  launch_backtrack(h->d_cand_count, h->d_cand_rec, h->opt.max_candidates, h->d_back, h->md.ncomponents, h->d_parent,
+                   h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, h->d_cand_out, h->cand_stride, h->stream);
+  HIPCHK(h, hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  const int first = std::min(kFirstCopy, h->opt.max_candidates);
+  HIPCHK(h, hipMemcpyAsync(h->h_cand_out, h->d_cand_out, h->cand_stride * first, hipMemcpyDeviceToHost, h->stream));
+  h->pending = true;
+  return PBD_OK;
+}
+
+static int collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
+  if (!h->pending) return fail(h, PBD_ERR_STATE, "collect without a pending detect");
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->pending = false;
+  if (h->dp_timer_on && h->have_dp) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev_dp0, h->ev_dp1) == hipSuccess) { h->dp_ms_sum += ms; h->dp_frames++; }
+  }
+  const int found = h->h_cand_count[0];
+  const int n = std::min(found, h->opt.max_candidates);
+  const int first = std::min(kFirstCopy, h->opt.max_candidates);
+  if (n > first) {
+    HIPCHK(h, hipMemcpyAsync(h->h_cand_out + h->cand_stride * first, h->d_cand_out + h->cand_stride * first,
+                             h->cand_stride * (n - first), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  if (count) *count = found;
+  if (found > h->opt.max_candidates) return fail(h, PBD_ERR_CAPACITY, "device candidate capacity exceeded; raise pbd_options.max_candidates");
+  // order like a single-threaded reference run: level, component, row-major root location
+  const int mp = h->max_parts;
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  auto key = [&](int i, int k) -> int {
+    const char* o = h->h_cand_out + h->cand_stride * i;
+    const pbd_candidate_head* hd = (const pbd_candidate_head*)o;
+    const int32_t* lc = (const int32_t*)(o + sizeof(pbd_candidate_head)) + (size_t)mp * 4;
+    return k == 0 ? hd->level : k == 1 ? hd->component : k == 2 ? lc[1] : lc[0];
+  };
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    for (int k = 0; k < 4; ++k) { int ka = key(a, k), kb = key(b, k); if (ka != kb) return ka < kb; }
+    return false;
+  });
+  if (n > capacity) return fail(h, PBD_ERR_CAPACITY, "output capacity too small");
+  for (int i = 0; i < n; ++i) {
+    const char* o = h->h_cand_out + h->cand_stride * order[i];
+    if (heads) heads[i] = *(const pbd_candidate_head*)o;
+    const int32_t* b = (const int32_t*)(o + sizeof(pbd_candidate_head));
+    if (boxes) memcpy(boxes + (size_t)i * mp * 4, b, sizeof(int32_t) * mp * 4);
+    if (locs) memcpy(locs + (size_t)i * mp * 3, b + (size_t)mp * 4, sizeof(int32_t) * mp * 3);
+  }
+  return PBD_OK;
+}
+
+static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
+  int rc;
+  const bool prof = h->profiling;
+  if (prof) hipEventRecord(h->ev[0], h->stream);
+  if ((rc = run_image_pyramid(h, d_src, stride))) return rc;
+  if (prof) hipEventRecord(h->ev[1], h->stream);
+  if ((rc = run_hog(h))) return rc;
+  if (prof) hipEventRecord(h->ev[2], h->stream);
+  if ((rc = run_pdf(h))) return rc;
+  if (prof) hipEventRecord(h->ev[3], h->stream);
+  if ((rc = run_dp_min(h))) return rc;
+  if (prof) hipEventRecord(h->ev[4], h->stream);
+  if ((rc = run_argmin_enqueue(h))) return rc;
+  if (prof) hipEventRecord(h->ev[5], h->stream);
+  return PBD_OK;
+}
+
+static void read_stage_times(pbd_handle* h) {
+  if (!h->profiling) return;
+  for (int i = 0; i < 5; ++i) hipEventElapsedTime(&h->stage_ms[i], h->ev[i], h->ev[i + 1]);
+  hipEventElapsedTime(&h->stage_ms[5], h->ev[0], h->ev[5]);
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+#pragma GCC visibility push(default)
+extern "C" {
+
+int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle** out) {
+  if (!out) return PBD_ERR_ARG;
+  *out = nullptr;
+  pbd_handle* h = new (std::nothrow) pbd_handle();
+  if (!h) return PBD_ERR_ARG;
+  *out = h;  // returned even on failure so that pbd_last_error() can be read; destroy it either way
+  pbd_options o{};
+  if (opt) o = *opt;
+  if (o.max_candidates <= 0) o.max_candidates = 4096;
+  h->opt = o;
+  int rc = ingest_model(h, model);
+  if (rc) return rc;
+  h->conv_mode = o.conv_mode;
+  if (h->conv_mode == PBD_CONV_AUTO)  // a dense contraction when N x K is GEMM-sized
+    h->conv_mode = ((size_t)model->nfilters * model->kh * model->kw * model->flen >= 32 * 800 && model->kh == 5 && model->kw == 5)
+                       ? PBD_CONV_MFMA : PBD_CONV_EXACT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(h, PBD_ERR_HIP, "no HIP device visible");
+  if (o.device < 0 || o.device >= ndev) return fail(h, PBD_ERR_ARG, "bad device ordinal");
+  HIPCHK(h, hipSetDevice(o.device));
+  HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->own_stream = true;
+  for (int i = 0; i < 8; ++i) HIPCHK(h, hipEventCreate(&h->ev[i]));
+  HIPCHK(h, hipEventCreate(&h->ev_dp0));
+  HIPCHK(h, hipEventCreate(&h->ev_dp1));
+  return upload_model(h);
+}
+
+int pbd_destroy(pbd_handle* h) {
+  if (!h) return PBD_ERR_ARG;
+  if (h->stream) hipStreamSynchronize(h->stream);
+  free_frame(h);
+  hipFree(h->d_wT); hipFree(h->d_biasw); hipFree(h->d_parent); hipFree(h->d_plane0); hipFree(h->d_nparts);
+  hipFree(h->d_cand_count); hipFree(h->d_cand_rec); hipFree(h->d_cand_out);
+  if (h->h_cand_out) hipHostFree(h->h_cand_out);
+  if (h->h_cand_count) hipHostFree(h->h_cand_count);
+  for (int i = 0; i < 8; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  if (h->ev_dp0) hipEventDestroy(h->ev_dp0);
+  if (h->ev_dp1) hipEventDestroy(h->ev_dp1);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return PBD_OK;
+}
+
+const char* pbd_last_error(const pbd_handle* h) { return h ? h->err.c_str() : "null handle"; }
+int pbd_max_parts(const pbd_handle* h) { return h ? h->max_parts : 0; }
+
+int pbd_set_stream(pbd_handle* h, void* s) {
+  if (!h) return PBD_ERR_ARG;
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  h->stream = (hipStream_t)s;
+  h->own_stream = false;
+  return PBD_OK;
+}
+
+int pbd_detect_enqueue_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, int cn, int stride) {
+  if (!h || !d_im) return PBD_ERR_ARG;
+  if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
+  if (stride < w * cn) return fail(h, PBD_ERR_ARG, "stride < w*cn");
+  HIPCHK(h, hipSetDevice(h->opt.device));
+  int rc = plan_frame(h, w, hgt, cn);
+  if (rc) return rc;
+  return enqueue_all(h, (const uint8_t*)d_im, stride);
+}
+
+int pbd_detect_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
+  if (!h) return PBD_ERR_ARG;
+  int rc = collect(h, heads, boxes, locs, capacity, count);
+  read_stage_times(h);
+  return rc;
+}
+
+int pbd_detect_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, int cn, int stride, pbd_candidate_head* heads,
+                      int32_t* boxes, int32_t* locs, int capacity, int* count) {
+  int rc = pbd_detect_enqueue_dev_u8(h, d_im, w, hgt, cn, stride);
+  if (rc) return rc;
+  return pbd_detect_collect(h, heads, boxes, locs, capacity, count);
+}
+
+static int upload_image(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride) {
+  if (stride < w * cn) return fail(h, PBD_ERR_ARG, "stride < w*cn");
+  HIPCHK(h, hipSetDevice(h->opt.device));
+  int rc = plan_frame(h, w, hgt, cn);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpy2DAsync(h->d_img, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice, h->stream));
+  return PBD_OK;
+}
+
+int pbd_detect_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, pbd_candidate_head* heads,
+                  int32_t* boxes, int32_t* locs, int capacity, int* count) {
+  if (!h || !im) return PBD_ERR_ARG;
+  if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
+  int rc = upload_image(h, im, w, hgt, cn, stride);
+  if (rc) return rc;
+  if ((rc = enqueue_all(h, h->d_img, w * cn))) return rc;
+  return pbd_detect_collect(h, heads, boxes, locs, capacity, count);
+}
+
+// ---- stage entry points -----------------------------------------------------
+int pbd_pyramid_geometry(const pbd_handle* h, int w, int hgt, int* nlevels, int32_t* img_w, int32_t* img_h,
+                         int32_t* cell_w, int32_t* cell_h, float* scales) {
+  if (!h || !nlevels) return PBD_ERR_ARG;
+  static thread_local Level lv[PBD_MAX_LEVELS];
+  int n = 0;
+  if (w < 3 || hgt < 3 || compute_geometry(w, hgt, h->md.sbin, h->md.interval, &n, lv)) return PBD_ERR_ARG;
+  *nlevels = n;
+  for (int l = 0; l < n; ++l) {
+    if (img_w) img_w[l] = lv[l].iw;
+    if (img_h) img_h[l] = lv[l].ih;
+    if (cell_w) cell_w[l] = lv[l].cw;
+    if (cell_h) cell_h[l] = lv[l].ch;
+    if (scales) scales[l] = lv[l].scale;
+  }
+  return PBD_OK;
+}
+
+int pbd_begin_frame(pbd_handle* h, int w, int hgt, int cn) {
+  if (!h) return PBD_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->opt.device));
+  int rc = plan_frame(h, w, hgt, cn);
+  if (rc) return rc;
+  h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
+  return PBD_OK;
+}
+
+int pbd_pyramid_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride) {
+  if (!h || !im) return PBD_ERR_ARG;
+  int rc = upload_image(h, im, w, hgt, cn, stride);
+  if (rc) return rc;
+  if ((rc = run_image_pyramid(h, h->d_img, w * cn))) return rc;
+  if ((rc = run_hog(h))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PBD_OK;
+}
+
+#define CHECK_LEVEL(h, level)                                                     \
+  if (!(h)) return PBD_ERR_ARG;                                                   \
+  if ((h)->fw == 0) return fail(h, PBD_ERR_STATE, "no frame geometry");           \
+  if ((level) < 0 || (level) >= (h)->nlevels) return fail(h, PBD_ERR_ARG, "level out of range");
+
+int pbd_get_level_image(pbd_handle* h, int level, uint8_t* out) {
+  CHECK_LEVEL(h, level);
+  if (!h->have_pyr) return fail(h, PBD_ERR_STATE, "pyramid not computed");
+  const Level& L = h->lv[level];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_pyr + L.img_off, (size_t)L.iw * L.ih * h->fcn, hipMemcpyDeviceToHost));
+  return PBD_OK;
+}
+int pbd_get_level_features(pbd_handle* h, int level, float* out) {
+  CHECK_LEVEL(h, level);
+  if (!h->have_feat) return fail(h, PBD_ERR_STATE, "features not computed");
+  const Level& L = h->lv[level];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_feat + L.cell_off * PBD_FLEN, (size_t)L.cw * L.ch * PBD_FLEN * 4, hipMemcpyDeviceToHost));
+  return PBD_OK;
+}
+int pbd_set_level_features(pbd_handle* h, int level, const float* in) {
+  CHECK_LEVEL(h, level);
+  const Level& L = h->lv[level];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->d_feat + L.cell_off * PBD_FLEN, in, (size_t)L.cw * L.ch * PBD_FLEN * 4, hipMemcpyHostToDevice));
+  h->have_feat = true;
+  return PBD_OK;
+}
+int pbd_pdf(pbd_handle* h) {
+  if (!h) return PBD_ERR_ARG;
+  if (!h->have_feat) return fail(h, PBD_ERR_STATE, "pdf() before pyramid()");
+  int rc = run_pdf(h);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PBD_OK;
+}
+int pbd_get_level_response(pbd_handle* h, int level, int filter, float* out) {
+  CHECK_LEVEL(h, level);
+  if (!h->have_resp) return fail(h, PBD_ERR_STATE, "responses not computed");
+  if (filter < 0 || filter >= h->md.nfilters) return fail(h, PBD_ERR_ARG, "filter out of range");
+  const Level& L = h->lv[level];
+  const size_t HW = (size_t)L.cw * L.ch;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_resp + L.cell_off * h->md.nfilters + filter * HW, HW * 4, hipMemcpyDeviceToHost));
+  return PBD_OK;
+}
+int pbd_set_level_response(pbd_handle* h, int level, int filter, const float* in) {
+  CHECK_LEVEL(h, level);
+  if (filter < 0 || filter >= h->md.nfilters) return fail(h, PBD_ERR_ARG, "filter out of range");
+  const Level& L = h->lv[level];
+  const size_t HW = (size_t)L.cw * L.ch;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->d_resp + L.cell_off * h->md.nfilters + filter * HW, in, HW * 4, hipMemcpyHostToDevice));
+  h->have_resp = true;
+  return PBD_OK;
+}
+int pbd_dp_min(pbd_handle* h) {
+  if (!h) return PBD_ERR_ARG;
+  if (!h->have_resp) return fail(h, PBD_ERR_STATE, "min() before pdf()");
+  int rc = run_dp_min(h);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PBD_OK;
+}
+int pbd_get_dp_pointers(pbd_handle* h, int level, int component, int part, int parent_mix, int32_t* ix, int32_t* iy, int32_t* ik) {
+  CHECK_LEVEL(h, level);
+  if (!h->have_dp) return fail(h, PBD_ERR_STATE, "min() not run");
+  if (component < 0 || component >= h->md.ncomponents) return fail(h, PBD_ERR_ARG, "component out of range");
+  const int p0 = h->part_offset[component], cnp = h->part_offset[component + 1] - p0;
+  if (part < 1 || part >= cnp) return fail(h, PBD_ERR_ARG, "part out of range (1..nparts-1)");
+  const PartInfo& P = h->parts[p0 + part];
+  const int L_ = h->parts[p0 + P.parent].K;
+  if (parent_mix < 0 || parent_mix >= L_) return fail(h, PBD_ERR_ARG, "parent mixture out of range");
+  const Level& L = h->lv[level];
+  const size_t HW = (size_t)L.cw * L.ch;
+  const size_t po = L.cell_off * h->nplanes + (size_t)(P.plane0 + parent_mix) * HW;
+  std::vector<int16_t> a(HW), b(HW);
+  std::vector<uint8_t> c(HW);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(a.data(), h->d_px + po, HW * 2, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(b.data(), h->d_py + po, HW * 2, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(c.data(), h->d_pk + po, HW, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < HW; ++i) { if (ix) ix[i] = a[i]; if (iy) iy[i] = b[i]; if (ik) ik[i] = c[i]; }
+  return PBD_OK;
+}
+int pbd_get_root(pbd_handle* h, int level, int component, float* rootv, int32_t* rooti) {
+  CHECK_LEVEL(h, level);
+  if (!h->have_dp) return fail(h, PBD_ERR_STATE, "min() not run");
+  if (component < 0 || component >= h->md.ncomponents) return fail(h, PBD_ERR_ARG, "component out of range");
+  const Level& L = h->lv[level];
+  const size_t HW = (size_t)L.cw * L.ch;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (rootv) HIPCHK(h, hipMemcpy(rootv, h->d_rootv + L.cell_off * h->md.ncomponents + component * HW, HW * 4, hipMemcpyDeviceToHost));
+  if (rooti) HIPCHK(h, hipMemcpy(rooti, h->d_rooti + L.cell_off * h->md.ncomponents + component * HW, HW * 4, hipMemcpyDeviceToHost));
+  return PBD_OK;
+}
+int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
+  if (!h) return PBD_ERR_ARG;
+  if (!h->have_dp) return fail(h, PBD_ERR_STATE, "argmin() before min()");
+  int rc = run_argmin_enqueue(h);
+  if (rc) return rc;
+  return collect(h, heads, boxes, locs, capacity, count);
+}
+
+// ---- stand-alone primitives -------------------------------------------------
+int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, double bx, double ay, double by, int osx,
+             int osy, float* out, int32_t* ix, int32_t* iy) {
+  if (!h || !in || rows <= 0 || cols <= 0 || rows > 32767 || cols > 32767) return PBD_ERR_ARG;
+  if (ax == 0 || ay == 0) return fail(h, PBD_ERR_ARG, "a must be non-zero");
+  HIPCHK(h, hipSetDevice(h->opt.device));
+  const size_t HW = (size_t)rows * cols;
+  float *d_in, *d_tmp, *d_sdt, *d_zero, *d_out;
+  int16_t *d_ixT, *d_iy, *d_ox, *d_oy;
+  uint8_t* d_ok;
+  HIPCHK(h, hipMalloc(&d_in, HW * 4)); HIPCHK(h, hipMalloc(&d_tmp, HW * 4)); HIPCHK(h, hipMalloc(&d_sdt, HW * 4));
+  HIPCHK(h, hipMalloc(&d_zero, HW * 4)); HIPCHK(h, hipMalloc(&d_out, HW * 4));
+  HIPCHK(h, hipMalloc(&d_ixT, HW * 2)); HIPCHK(h, hipMalloc(&d_iy, HW * 2));
+  HIPCHK(h, hipMalloc(&d_ox, HW * 2)); HIPCHK(h, hipMalloc(&d_oy, HW * 2)); HIPCHK(h, hipMalloc(&d_ok, HW));
+  HIPCHK(h, hipMemcpyAsync(d_in, in, HW * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemsetAsync(d_zero, 0, HW * 4, h->stream));
+  DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 0}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
+  DtGroup groups[2] = {{0, 1, rows, cols}, {1, 1, cols, rows}};
+  std::vector<DtTask> tasks;
+  int lpbx = 64, lpby = 64;
+  while (lpbx > 8 && dt_lds_bytes((cols + 1) | 1, lpbx) > 160 * 1024) lpbx /= 2;
+  while (lpby > 8 && dt_lds_bytes((rows + 1) | 1, lpby) > 160 * 1024) lpby /= 2;
+  for (int g0 = 0; g0 < rows; g0 += lpbx) tasks.push_back(DtTask{0, g0});
+  const int nx = (int)tasks.size();
+  for (int g0 = 0; g0 < cols; g0 += lpby) tasks.push_back(DtTask{1, g0});
+  DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks; ReduceJob* d_job;
+  HIPCHK(h, hipMalloc(&d_maps, sizeof(maps))); HIPCHK(h, hipMalloc(&d_groups, sizeof(groups)));
+  HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size())); HIPCHK(h, hipMalloc(&d_job, sizeof(ReduceJob)));
+  ReduceJob J{};
+  J.sdt = d_sdt; J.ixT = d_ixT; J.iy = d_iy; J.H = rows; J.W = cols; J.K = 1; J.L = 1;
+  J.bias_off[0] = (int)h->biasw.size();  // the trailing 0.0f
+  J.par_in[0] = d_zero; J.par_out[0] = d_out; J.ox[0] = d_ox; J.oy[0] = d_oy; J.ok[0] = d_ok; J.cell0 = 0;
+  HIPCHK(h, hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_groups, groups, sizeof(groups), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_job, &J, sizeof(J), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
+  if (dt_lds_bytes((cols + 1) | 1, lpbx) > 160 * 1024 || dt_lds_bytes((rows + 1) | 1, lpby) > 160 * 1024) {
+    h->err = "map too large for the LDS-resident distance transform";
+    return PBD_ERR_UNSUPPORTED;
+  }
+  launch_dt_pass(d_tasks, nx, d_groups, d_maps, (cols + 1) | 1, lpbx, h->stream);
+  launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, (rows + 1) | 1, lpby, h->stream);
+  launch_reduce(d_job, 1, (unsigned)HW, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
+  std::vector<int16_t> hx(HW), hy(HW);
+  HIPCHK(h, hipMemcpyAsync(out, d_out, HW * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(hx.data(), d_ox, HW * 2, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(hy.data(), d_oy, HW * 2, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < HW; ++i) { if (ix) ix[i] = hx[i]; if (iy) iy[i] = hy[i]; }
+  hipFree(d_in); hipFree(d_tmp); hipFree(d_sdt); hipFree(d_zero); hipFree(d_out); hipFree(d_ixT); hipFree(d_iy);
+  hipFree(d_ox); hipFree(d_oy); hipFree(d_ok); hipFree(d_maps); hipFree(d_groups); hipFree(d_tasks); hipFree(d_job);
+  return PBD_OK;
+}
+
+int pbd_hog_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, float* out, int* cell_w, int* cell_h) {
+  if (!h || !im || w < 3 || hgt < 3 || (cn != 1 && cn != 3) || stride < w * cn) return PBD_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->opt.device));
+  const int sbin = h->md.sbin;
+  LevelDev L{};
+  L.iw = w; L.ih = hgt;
+  L.bw = (int)std::round((float)w / (float)sbin); L.bh = (int)std::round((float)hgt / (float)sbin);
+  L.cw = std::max(L.bw - 2, 0); L.ch = std::max(L.bh - 2, 0);
+  if (cell_w) *cell_w = L.cw;
+  if (cell_h) *cell_h = L.ch;
+  if (L.cw == 0 || L.ch == 0) return PBD_OK;
+  int tc = 16;
+  while (tc > 2 && hog_lds_bytes(sbin, tc) > 150 * 1024) tc /= 2;
+  std::vector<HogTile> tiles;
+  for (int y = 0; y < L.ch; y += tc) for (int x = 0; x < L.cw; x += tc) tiles.push_back(HogTile{0, y, x, 0});
+  uint8_t* d_im; float* d_feat; LevelDev* d_lv; HogTile* d_tiles;
+  HIPCHK(h, hipMalloc(&d_im, (size_t)w * hgt * cn)); HIPCHK(h, hipMalloc(&d_feat, (size_t)L.cw * L.ch * PBD_FLEN * 4));
+  HIPCHK(h, hipMalloc(&d_lv, sizeof(L))); HIPCHK(h, hipMalloc(&d_tiles, sizeof(HogTile) * tiles.size()));
+  HIPCHK(h, hipMemcpy2D(d_im, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(d_lv, &L, sizeof(L), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(d_tiles, tiles.data(), sizeof(HogTile) * tiles.size(), hipMemcpyHostToDevice));
+  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, cn, sbin, tc, h->stream);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, d_feat, (size_t)L.cw * L.ch * PBD_FLEN * 4, hipMemcpyDeviceToHost));
+  hipFree(d_im); hipFree(d_feat); hipFree(d_lv); hipFree(d_tiles);
+  return PBD_OK;
+}
+
+int pbd_resize_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, uint8_t* out, int ow, int oh) {
+  if (!h || !im || !out || w <= 0 || hgt <= 0 || ow <= 0 || oh <= 0 || (cn != 1 && cn != 3) || stride < w * cn) return PBD_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->opt.device));
+  uint8_t *d_im, *d_out;
+  HIPCHK(h, hipMalloc(&d_im, (size_t)w * hgt * cn)); HIPCHK(h, hipMalloc(&d_out, (size_t)ow * oh * cn));
+  HIPCHK(h, hipMemcpy2D(d_im, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
+  ResizeArgs ra{};
+  ra.n = 1; ra.sw = w; ra.sh = hgt; ra.cn = cn; ra.sstride = w * cn; ra.dw[0] = ow; ra.dh[0] = oh; ra.off[0] = 0;
+  launch_resize(ra, d_im, d_out, h->stream);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, d_out, (size_t)ow * oh * cn, hipMemcpyDeviceToHost));
+  hipFree(d_im); hipFree(d_out);
+  return PBD_OK;
+}
+
+int pbd_pyrdown_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, uint8_t* out) {
+  if (!h || !im || !out || w <= 0 || hgt <= 0 || (cn != 1 && cn != 3) || stride < w * cn) return PBD_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->opt.device));
+  const size_t sb = (size_t)w * hgt * cn, db = (size_t)((w + 1) / 2) * ((hgt + 1) / 2) * cn;
+  uint8_t* d_buf;
+  HIPCHK(h, hipMalloc(&d_buf, sb + db));
+  HIPCHK(h, hipMemcpy2D(d_buf, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
+  PyrDownArgs pa{};
+  pa.n = 1; pa.cn = cn; pa.sw[0] = w; pa.sh[0] = hgt; pa.soff[0] = 0; pa.doff[0] = sb;
+  launch_pyrdown(pa, d_buf, h->stream);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, d_buf + sb, db, hipMemcpyDeviceToHost));
+  hipFree(d_buf);
+  return PBD_OK;
+}
+
+int pbd_nms_map(pbd_handle* h, const float* src, int rows, int cols, int sz, uint8_t* dst) {
+  if (!h || !src || !dst || rows <= 0 || cols <= 0 || sz < 0) return PBD_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->opt.device));
+  float* d_src; uint8_t* d_dst;
+  const size_t n = (size_t)rows * cols;
+  HIPCHK(h, hipMalloc(&d_src, n * 4)); HIPCHK(h, hipMalloc(&d_dst, n));
+  HIPCHK(h, hipMemcpy(d_src, src, n * 4, hipMemcpyHostToDevice));
+  launch_nms_map(d_src, rows, cols, sz, d_dst, h->stream);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(dst, d_dst, n, hipMemcpyDeviceToHost));
+  hipFree(d_src); hipFree(d_dst);
+  return PBD_OK;
+}
+
+// ---- host-side post-processing (include/Candidate.hpp:91-99, 277-304) --------
+int pbd_candidates_sort(pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int count, int mp) {
+  if (!heads || count < 0 || mp <= 0) return PBD_ERR_ARG;
+  std::vector<int> order(count);
+  for (int i = 0; i < count; ++i) order[i] = i;
+  // Candidate::descending; stable, so equal scores keep detect() order (std::sort leaves it unspecified)
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return heads[a].score > heads[b].score; });
+  std::vector<pbd_candidate_head> h2(count);
+  std::vector<int32_t> b2(boxes ? (size_t)count * mp * 4 : 0), l2(locs ? (size_t)count * mp * 3 : 0);
+  for (int i = 0; i < count; ++i) {
+    h2[i] = heads[order[i]];
+    if (boxes) memcpy(&b2[(size_t)i * mp * 4], boxes + (size_t)order[i] * mp * 4, sizeof(int32_t) * mp * 4);
+    if (locs) memcpy(&l2[(size_t)i * mp * 3], locs + (size_t)order[i] * mp * 3, sizeof(int32_t) * mp * 3);
+  }
+  if (count) memcpy(heads, h2.data(), sizeof(pbd_candidate_head) * count);
+  if (boxes && count) memcpy(boxes, b2.data(), b2.size() * sizeof(int32_t));
+  if (locs && count) memcpy(locs, l2.data(), l2.size() * sizeof(int32_t));
+  return PBD_OK;
+}
+
+int pbd_candidates_nms(pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int count, int mp, int im_w, int im_h,
+                       float overlap, int* kept) {
+  if (!heads || !boxes || !kept || count < 0 || mp <= 0 || im_w <= 0 || im_h <= 0) return PBD_ERR_ARG;
+  std::vector<uint8_t> scratch((size_t)im_w * im_h, 0);
+  int keep = 0;
+  for (int n = 0; n < count; ++n) {
+    const int32_t* b = boxes + (size_t)n * mp * 4;
+    int x = b[0], y = b[1], bw = b[2], bh = b[3];  // Candidate::boundingBox(): union of the part rects
+    for (int p = 0; p < heads[n].nparts; ++p) {
+      const int32_t* q = b + p * 4;
+      const int x1 = std::min(x, q[0]), y1 = std::min(y, q[1]);
+      bw = std::max(x + bw, q[0] + q[2]) - x1;
+      bh = std::max(y + bh, q[1] + q[3]) - y1;
+      x = x1; y = y1;
+    }
+    int ix1 = std::max(x, 0), iy1 = std::max(y, 0);  // & bounds
+    int iw = std::min(x + bw, im_w) - ix1, ih = std::min(y + bh, im_h) - iy1;
+    if (iw <= 0 || ih <= 0) ix1 = iy1 = iw = ih = 0;
+    double sum = 0;
+    for (int yy = iy1; yy < iy1 + ih; ++yy)
+      for (int xx = ix1; xx < ix1 + iw; ++xx) sum += scratch[(size_t)yy * im_w + xx];
+    if (sum / (double)(iw * ih) > (double)overlap) continue;  // :296
+    for (int yy = iy1; yy < iy1 + ih; ++yy) memset(&scratch[(size_t)yy * im_w + ix1], 1, iw);
+    if (keep != n) {
+      heads[keep] = heads[n];
+      memmove(boxes + (size_t)keep * mp * 4, boxes + (size_t)n * mp * 4, sizeof(int32_t) * mp * 4);
+      if (locs) memmove(locs + (size_t)keep * mp * 3, locs + (size_t)n * mp * 3, sizeof(int32_t) * mp * 3);
+    }
+    keep++;
+  }
+  *kept = keep;
+  return PBD_OK;
+}
+
+// ---- instrumentation ---------------------------------------------------------
+int pbd_get_stage_ms(const pbd_handle* h, float ms[6]) {
+  if (!h || !ms) return PBD_ERR_ARG;
+  for (int i = 0; i < 6; ++i) ms[i] = h->stage_ms[i];
+  return PBD_OK;
+}
+int pbd_set_profiling(pbd_handle* h, int on) {
+  if (!h) return PBD_ERR_ARG;
+  h->profiling = on != 0;
+  return PBD_OK;
+}
+int pbd_get_work(const pbd_handle* h, double work[6]) {
+  if (!h || !work) return PBD_ERR_ARG;
+  if (h->fw == 0) return PBD_ERR_STATE;
+  const pbd_model_desc& m = h->md;
+  double C = 0, pix = 0;
+  for (int l = 0; l < h->nlevels; ++l) {
+    if (!h->lv[l].active) continue;
+    C += (double)h->lv[l].cw * h->lv[l].ch;
+    pix += (double)h->lv[l].iw * h->lv[l].ih * h->fcn;
+  }
+  // reference element types (float32 scores, int32 pointers)
+  double per_cell = 0, dtmaps = 0;
+  for (int c = 0; c < m.ncomponents; ++c) {
+    const int p0 = h->part_offset[c], cnp = h->part_offset[c + 1] - p0;
+    for (int p = 1; p < cnp; ++p) {
+      const double K = h->parts[p0 + p].K, L = h->parts[p0 + h->parts[p0 + p].parent].K;
+      per_cell += 4 * K + 12 * L + 8 * L;
+      dtmaps += K;
+    }
+    per_cell += 4 * h->parts[p0].K + 8;
+  }
+  work[0] = pix + 128.0 * C;
+  work[1] = 128.0 * C + 4.0 * m.nfilters * C + 4.0 * m.nfilters * m.kh * m.kw * m.flen;
+  work[2] = 2.0 * C * m.nfilters * m.kh * m.kw * m.flen;
+  work[3] = C * per_cell;
+  work[4] = C;
+  work[5] = C * dtmaps;
+  return PBD_OK;
+}
+int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes) {
+  if (!h) return PBD_ERR_ARG;
+  if (avg_ms) *avg_ms = h->dp_frames ? h->dp_ms_sum / h->dp_frames : 0.0;
+  if (nframes) *nframes = h->dp_frames;
+  if (reset) { h->dp_ms_sum = 0; h->dp_frames = 0; }
+  return PBD_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,185 @@
+// pbd_internal.hpp — shared declarations of libpbd_hip.so (gfx950 only).
+//
+// Data layout in HBM for one frame (all buffers owned by the handle, sized on
+// the first frame of a given geometry and reused):
+//   img      u8   source image, tightly packed w*cn
+//   pyr      u8   level images back to back (level l at img_off[l])
+//   feat     f32  HOG: level l at feat_off[l], [ch][cw][32]      (cell-major)
+//   resp     f32  pdf: level l at resp_off[l], [nfilters][ch][cw] (plane-major)
+//   acc      f32  accumulated part scores: level l at acc_off[l], [nslots][ch][cw]
+//   ptrx/y   i16  DP back pointers: level l at ptr_off[l], [nplanes][ch][cw]
+//   ptrk     u8   DP best child mixture, same indexing
+//   rootv/i  f32/i32  level l at root_off[l], [ncomp][ch][cw]
+//   dt_*          per-round scratch of the distance transform
+//   cand          device candidate list (count + records)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/pbd_c.h"
+
+#define PBD_MAX_LEVELS 128
+#define PBD_FLEN 32
+#define PBD_NORIENT 18
+#define PBD_MAX_MIX 16
+
+struct Level {
+  int iw, ih;      // level image size
+  int bw, bh;      // HOG blocks
+  int cw, ch;      // cells (feature map / response size)
+  float scale;     // IFeatures::scales()[l]
+  size_t img_off;  // bytes into pyr
+  size_t cell_off; // prefix sum of cells (over all levels)
+  int active;      // within [level_begin, level_end)
+};
+
+// ---- kernel work tables -----------------------------------------------------
+struct ResizeArgs {  // levels 0..interval-1 (cv::resize) ; by value
+  int n, sw, sh, cn, sstride;
+  int dw[16], dh[16];
+  unsigned long long off[16];
+};
+struct PyrDownArgs { // one octave step: level j from level j-interval
+  int n, cn;
+  int sw[16], sh[16];
+  unsigned long long soff[16], doff[16];
+};
+struct HogTile { int level, cy0, cx0, pad; };
+struct LevelDev {    // per level, device copy
+  int iw, ih, bw, bh, cw, ch;
+  unsigned long long img_off, cell_off;
+};
+struct ConvTile { int level, y0, x0, pad; };
+
+struct DtMap {       // one 1-D pass over one score map
+  const float* src;  // lines contiguous: line i at src + i*len
+  float* dst;        // transposed out: element q of line i at dst + q*nlines + i
+  int16_t* ptr;      // same layout as dst
+  double a, b;       // Quadratic(a, b)
+  int os, pad;
+};
+struct DtGroup { int map0, nmaps, nlines, len; };
+struct DtTask { int group, g0; };
+
+struct ReduceJob {   // one (level, child part): max over child mixtures for each parent mixture
+  const float* sdt;      // [K][H][W] distance-transformed child scores
+  const int16_t* ixT;    // [K][W][H] x pointers (transposed)
+  const int16_t* iy;     // [K][H][W] y pointers
+  int H, W, K, L;
+  int bias_off[PBD_MAX_MIX];       // biasw index of bias(mm)[0] for each child mixture mm (K<=8)
+  const float* par_in[PBD_MAX_MIX];  // parent mixture m: current score (resp plane or acc slot)
+  float* par_out[PBD_MAX_MIX];       // parent mixture m: acc slot
+  int16_t* ox[PBD_MAX_MIX]; int16_t* oy[PBD_MAX_MIX]; uint8_t* ok[PBD_MAX_MIX];  // output pointer planes
+  unsigned cell0;        // prefix of cells of this job within the launch
+};
+struct RootJob {
+  const float* score[PBD_MAX_MIX]; // root mixture m current score
+  float* rootv; int* rooti;
+  int H, W, K, level, comp;
+  float bias;
+  unsigned cell0;
+};
+struct BackLevel {   // per (level, comp) info for backtracking
+  const int16_t* px; const int16_t* py; const uint8_t* pk; // plane 0 of this comp at this level
+  const float* rootv; const int* rooti;
+  int H, W; float scale;
+};
+struct CandRec { int level, comp, y, x; };
+
+// ---- host model -------------------------------------------------------------
+struct PartInfo {
+  int comp, p, parent;       // local indices
+  int K;                     // #mixtures
+  std::vector<int> filterid, defid, biasid;
+  std::vector<int> slot;     // acc slot per mixture (global slot id)
+  int plane0;                // first pointer plane (global plane id), parent's L planes
+  bool leaf;
+};
+
+struct pbd_handle {
+  // model
+  pbd_model_desc md;         // pointers into the vectors below
+  std::vector<float> filters, defw, biasw;
+  std::vector<int> anchors, part_offset, parentid, mix_offset, filterid, defid, biasid;
+  pbd_options opt;
+  int max_parts = 0, nslots = 0, nplanes = 0;
+  std::vector<PartInfo> parts;                 // flat parts
+  std::vector<std::vector<int>> rounds;        // flat part ids per round
+  std::vector<std::vector<char>> first_msg;    // per round/part/parent-mixture: parent slot uninitialised
+  std::vector<int> comp_plane0;
+  std::string err;
+  int conv_mode = PBD_CONV_EXACT;
+
+  // device model
+  float* d_wT = nullptr;     // [kh*kw][flen][nfpad] filters transposed for the conv kernels
+  int nfpad = 0;
+  float* d_biasw = nullptr;
+  int* d_parent = nullptr;   // [ncomp][max_parts] parent of each part
+  int* d_plane0 = nullptr;   // [ncomp][max_parts] local plane0 of each part
+  int* d_nparts = nullptr;
+
+  // frame plan
+  int fw = 0, fh = 0, fcn = 0, nlevels = 0;
+  Level lv[PBD_MAX_LEVELS];
+  size_t cells = 0, pyr_bytes = 0;
+  bool have_pyr = false, have_feat = false, have_resp = false, have_dp = false;
+
+  // device frame buffers
+  uint8_t* d_img = nullptr; size_t img_cap = 0;
+  uint8_t* d_pyr = nullptr;
+  float* d_feat = nullptr; float* d_resp = nullptr; float* d_acc = nullptr;
+  int16_t* d_px = nullptr; int16_t* d_py = nullptr; uint8_t* d_pk = nullptr;
+  float* d_rootv = nullptr; int* d_rooti = nullptr;
+  float* d_dt_tmpT = nullptr; float* d_dt_sdt = nullptr; int16_t* d_dt_ixT = nullptr; int16_t* d_dt_iy = nullptr;
+  size_t dt_cap_elems = 0;
+  LevelDev* d_levels = nullptr;
+  HogTile* d_hog_tiles = nullptr; int n_hog_tiles = 0; int hog_tc = 16;
+  ConvTile* d_conv_tiles = nullptr; int n_conv_tiles = 0;
+  // DP tables (all rounds back to back)
+  DtMap* d_dtmaps = nullptr; DtGroup* d_dtgroups = nullptr; DtTask* d_dttasks = nullptr;
+  ReduceJob* d_redjobs = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
+  struct RoundLaunch {
+    int xtask0[4], nxtasks[4], ytask0[4], nytasks[4];  // per DT size class
+    int red0, nred; unsigned red_cells;
+  };
+  int dt_stride[2][4] = {}, dt_lpb[2][4] = {};      // [pass][class] LDS line stride / lines per block
+  std::vector<RoundLaunch> rl;
+  int n_rootjobs = 0; unsigned root_cells = 0;
+  // candidates
+  int* d_cand_count = nullptr; CandRec* d_cand_rec = nullptr;
+  char* d_cand_out = nullptr; char* h_cand_out = nullptr; int* h_cand_count = nullptr;
+  size_t cand_stride = 0;
+  bool pending = false;
+
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool profiling = false;
+  hipEvent_t ev[8] = {};
+  float stage_ms[6] = {0, 0, 0, 0, 0, 0};
+  hipEvent_t ev_dp0 = nullptr, ev_dp1 = nullptr;
+  double dp_ms_sum = 0; int dp_frames = 0; bool dp_timer_on = true;
+  std::vector<void*> frame_allocs;  // everything freed on re-plan
+};
+
+// ---- kernel launchers (k_*.hip) ----------------------------------------------
+void launch_resize(const ResizeArgs& a, const uint8_t* src, uint8_t* pyr, hipStream_t s);
+void launch_pyrdown(const PyrDownArgs& a, uint8_t* pyr, hipStream_t s);
+void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, float* feat,
+                int cn, int sbin, int tc, hipStream_t s);
+size_t hog_lds_bytes(int sbin, int tc);
+void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
+                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
+void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
+                      const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, int stride, int lpb,
+                    hipStream_t s);
+size_t dt_lds_bytes(int stride, int lpb);
+void launch_reduce(const ReduceJob* jobs, int njobs, unsigned total_cells, const float* biasw, int correct_ptr,
+                   hipStream_t s);
+void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
+                 int capacity, hipStream_t s);
+void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
+                      const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
+                      char* out, size_t out_stride, hipStream_t s);
+void launch_nms_map(const float* src, int rows, int cols, int sz, uint8_t* dst, hipStream_t s);
