@@ -23,6 +23,37 @@
 #define CSTR 33      // LDS floats per cell (32 + 1 pad: conflict-free across x)
 #define NFG 8        // filters held in registers per pass (exact kernel)
 
+// Stage the (CT+KH-1) x (CT+KW-1) cell tile with halo into LDS ([cell][CSTR]).  Eight lanes fetch
+// one cell's 128 B as float4s; NB batches of independent loads are in flight before the first wait
+// (clamped addresses, the border value is selected after the load: 0, or 1 for the last channel).
+template <int KH, int KW>
+__device__ __forceinline__ void stage_feature_tile(float* __restrict__ ft, const float* __restrict__ F, int y0, int x0,
+                                                   int H, int W, int tid) {
+  constexpr int TW = CT + KW - 1, TH = CT + KH - 1, N = TH * TW * 8, NB = (N + 255) / 256;
+  float4 r[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int i = min(tid + j * 256, N - 1);
+    const int cell = i >> 3, q = i & 7;
+    const int ty = cell / TW, tx = cell - ty * TW;
+    const int y = min(max(y0 + ty - KH / 2, 0), H - 1), x = min(max(x0 + tx - KW / 2, 0), W - 1);
+    r[j] = *(const float4*)(F + ((size_t)y * W + x) * PBD_FLEN + q * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int i = tid + j * 256;
+    if (i < N) {
+      const int cell = i >> 3, q = i & 7;
+      const int ty = cell / TW, tx = cell - ty * TW;
+      const int y = y0 + ty - KH / 2, x = x0 + tx - KW / 2;
+      float4 v = r[j];
+      if (!(y >= 0 && y < H && x >= 0 && x < W)) v = make_float4(0.f, 0.f, 0.f, q == 7 ? 1.f : 0.f);
+      float* d = ft + cell * CSTR + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+}
+
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void k_conv_exact(const ConvTile* __restrict__ tiles,
                                                     const LevelDev* __restrict__ levels,
@@ -37,16 +68,7 @@ __global__ __launch_bounds__(256) void k_conv_exact(const ConvTile* __restrict__
   const int tid = threadIdx.x;
   const float* F = feat + lv.cell_off * PBD_FLEN;
   // stage the tile: 8 lanes x float4 per cell -> coalesced 128 B per cell
-  for (int i = tid; i < TH * TW * 8; i += 256) {
-    const int cell = i >> 3, q = i & 7;
-    const int ty = cell / TW, tx = cell - ty * TW;
-    const int y = t.y0 + ty - KH / 2, x = t.x0 + tx - KW / 2;
-    float4 v;
-    if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(F + ((size_t)y * W + x) * PBD_FLEN + q * 4);
-    else v = make_float4(0.f, 0.f, 0.f, q == 7 ? 1.f : 0.f);  // border: last channel = 1
-    float* d = ft + cell * CSTR + q * 4;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
+  stage_feature_tile<KH, KW>(ft, F, t.y0, t.x0, H, W, tid);
   __syncthreads();
   const int ly = tid >> 4, lx = tid & 15;
   const int oy = t.y0 + ly, ox = t.x0 + lx;
@@ -174,26 +196,33 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nbase = blockIdx.y * NW;
   const float* F = feat + lv.cell_off * PBD_FLEN;
-  for (int i = tid; i < TH * TW * 8; i += 256) {
-    const int cell = i >> 3, q = i & 7;
-    const int ty = cell / TW, tx = cell - ty * TW;
-    const int y = t.y0 + ty - KH / 2, x = t.x0 + tx - KW / 2;
-    float4 v;
-    if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(F + ((size_t)y * W + x) * PBD_FLEN + q * 4);
-    else v = make_float4(0.f, 0.f, 0.f, q == 7 ? 1.f : 0.f);
-    float* d = ft + cell * CSTR + q * 4;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
+  stage_feature_tile<KH, KW>(ft, F, t.y0, t.x0, H, W, tid);
   // weights of tap 0 -> wb[0]
-  auto stage_w = [&](int tap, int buf) {
+  // weights of one tap: [32 channels][NW filters]; loads are issued a whole tap ahead of their use
+  constexpr int NV = 32 * NW / 4, NBW = (NV + 255) / 256;
+  float4 wr[NBW];
+  auto load_w = [&](int tap) {
     const float* src = wT + (size_t)tap * PBD_FLEN * nfpad + nbase;
-    float* dst = wb + buf * 32 * NW;
-    for (int i = tid; i < 32 * NW / 4; i += 256) {
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      const int i = min(tid + j * 256, NV - 1);
       const int c = i / (NW / 4), n4 = i - c * (NW / 4);
-      *(float4*)(dst + c * NW + n4 * 4) = *(const float4*)(src + (size_t)c * nfpad + n4 * 4);
+      wr[j] = *(const float4*)(src + (size_t)c * nfpad + n4 * 4);
     }
   };
-  stage_w(0, 0);
+  auto store_w = [&](int buf) {
+    float* dst = wb + buf * 32 * NW;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      const int i = tid + j * 256;
+      if (i < NV) {
+        const int c = i / (NW / 4), n4 = i - c * (NW / 4);
+        *(float4*)(dst + c * NW + n4 * 4) = wr[j];
+      }
+    }
+  };
+  load_w(0);
+  store_w(0);
   __syncthreads();
 
   f32x16 acc[2][NT];
@@ -214,7 +243,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ 
 
   for (int tap = 0; tap < KH * KW; ++tap) {
     const int buf = tap & 1;
-    if (tap + 1 < KH * KW) stage_w(tap + 1, buf ^ 1);
+    if (tap + 1 < KH * KW) load_w(tap + 1);
     const int ti = tap / KW, tj = tap - ti * KW;
     const float* a0 = abase0 + (ti * TW + tj) * CSTR;
     const float* a1 = abase1 + (ti * TW + tj) * CSTR;
@@ -229,6 +258,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ 
         acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv, acc[1][n], 0, 0, 0);
       }
     }
+    if (tap + 1 < KH * KW) store_w(buf ^ 1);
     __syncthreads();
   }
   // Epilogue.  C/D layout 32x32: col(j) = lane&31, row(i) = (reg&3) + 8*(reg>>2) + 4*(lane>>5),

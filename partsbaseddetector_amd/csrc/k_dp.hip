@@ -25,90 +25,252 @@
 // k_backtrack argmin (:219-245): one lane per candidate walks the part tree.
 #include "pbd_internal.hpp"
 
-size_t dt_lds_bytes(int stride, int lpb) { return (size_t)lpb * stride * (4 + 4 + 2); }
+// debug: per-phase timestamps (100 MHz wall clock) of block 0 of the last k_dt_pass launch
+__device__ unsigned long long pbd_dt_dbg[8];
+#define DT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pbd_dt_dbg[i] = wall_clock64(); } while (0)
+void dt_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_dt_dbg), sizeof(unsigned long long) * 8); }
 
-__device__ __forceinline__ float dt_isect(double a, double b, int x0, int x1, float y0, float y1) {
-  // Quadratic::operator()(x0,x1,y0,y1), DistanceTransform.hpp:98-100, narrowed to T at :161
-  return (float)((((double)y1 - (double)y0) - b * (double)(x1 - x0) + a * (double)(x1 * x1 - x0 * x0)) /
-                 (2 * a * (double)(x1 - x0)));
+// LDS per block: 64 line pointers + 64 stack sizes + per line {Y, Z : float[S]; V, P : u16[S]}
+// + per map touched by the block a table of exact reciprocals 1/(2a*dx), dx < len (double[S]).
+size_t dt_lds_bytes(int stride, int lpb, int nmb) {
+  return (size_t)lpb * stride * (4 + 4 + 2 + 2) + 64 * (8 + 8 + 4 + 4) + (size_t)nmb * stride * 8 + 8;
 }
 
+// Intersection of the parabolas rooted at x0 < x1 (Quadratic::operator()(x0,x1,y0,y1),
+// DistanceTransform.hpp:98-100), narrowed to T like `T s = f(...)` at :161.
+//   num = ((y1 - y0) - b*(x1-x0)) + a*(x1^2 - x0^2)      (same fp64 operations, same order)
+//   s   = (float)(num / den),  den = (2a)*(x1-x0)
+// The fp64 division (14 dependent instructions, four of them quarter rate) is replaced by a
+// multiplication with the exact reciprocal r = RN(1/den) from the per-map table plus one fma
+// residual correction: q1 is within 1 ulp of RN(num/den).  (float)q1 can differ from
+// (float)RN(num/den) only if a float rounding boundary lies within 1 ulp of q1, i.e. the low 29
+// mantissa bits of q1 are 0x0FFFFFFF..0x10000001, or the value leaves the normal float range; in
+// exactly those cases (~1e-8 of all evaluations) the true IEEE division is evaluated instead, so
+// the narrowed result is always bit-identical to the reference's.
+__device__ __forceinline__ float dt_isect_fast(double a, double b, double twoa, const double* __restrict__ R, int x0,
+                                               int x1, double y0, double y1) {
+  const int dx = x1 - x0;
+  const double dxd = (double)dx;
+  const double num = ((y1 - y0) - b * dxd) + a * (double)(dx * (x1 + x0));
+  const double den = twoa * dxd;
+  const double r = R[dx];
+  const double q0 = num * r;
+  const double rem = __builtin_fma(-q0, den, num);
+  double q1 = __builtin_fma(rem, r, q0);
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
+  const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
+  const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
+  if ((lo29 - 0x0FFFFFFFu) <= 2u || (ex - 897u) > 252u) q1 = num / den;
+  return (float)q1;
+}
+
+// One block = one wavefront = up to g.lpb lines of one group (lpb chosen per group so that every
+// block of the launch fits the same LDS budget: long lines -> fewer lines per block -> many more
+// blocks, so a whole pass is resident at once and all 4 SIMDs of every CU carry chains).
 __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks, const DtGroup* __restrict__ groups,
-                                                const DtMap* __restrict__ maps, int S, int lpb) {
+                                                const DtMap* __restrict__ maps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Y = (float*)smem;                 // [lpb][S] line values, then y of stack entries (in place)
-  float* Z = Y + lpb * S;                  // [lpb][S] z[k], k = 0..len
-  unsigned short* V = (unsigned short*)(Z + lpb * S);  // [lpb][S] v[k]
+  DT_STAMP(0);
   const DtTask t = tasks[blockIdx.x];
   const DtGroup g = groups[t.group];
   const int lane = threadIdx.x;
-  const int len = g.len;
+  const int len = g.len, S = g.stride, lpb = g.lpb;
+  const float** lptr = (const float**)smem;   // [64] source pointer of each line of this block
+  int16_t** pptr = (int16_t**)(smem + 64 * 8);  // [64] pointer-output base of each line
+  int* pstr = (int*)(smem + 64 * 16);         // [64] pointer-output element stride of each line
+  int* Ksz = (int*)(smem + 64 * 20);          // [64] final stack size of each line
+  double* R = (double*)(smem + 64 * 24);      // [nmb][S] 1/(2a*dx) per map of this block
   const int total = g.nmaps * g.nlines;
   const int nl = min(lpb, total - t.g0);
-  // cooperative, coalesced load of the nl lines
-  for (int i = 0; i < nl; ++i) {
-    const int gi = t.g0 + i;
+  const int m_first = t.g0 / g.nlines, m_last = (t.g0 + nl - 1) / g.nlines;
+  const int nmb = m_last - m_first + 1;
+  float* Y = (float*)(R + g.nmb * S);         // [lpb][S] line values, then y of stack entries (in place)
+  float* Z = Y + lpb * S;                     // [lpb][S] z[k], k = 0..len
+  unsigned short* V = (unsigned short*)(Z + lpb * S);  // [lpb][S] v[k]
+  unsigned short* P = V + lpb * S;            // [lpb][S] arg-max pointer per output (natural-layout staging)
+  if (lane < nl) {
+    const int gi = t.g0 + lane;
     const int mi = gi / g.nlines, li = gi - mi * g.nlines;
-    const float* s = maps[g.map0 + mi].src + (size_t)li * len;
-    for (int q = lane; q < len; q += 64) Y[i * S + q] = s[q];
+    const DtMap& mp0 = maps[g.map0 + mi];
+    lptr[lane] = mp0.src + (size_t)li * len;
+    // pointers: transposed like dst (y pass -> natural layout) or natural (x pass)
+    const bool nat = mp0.ptr_natural != 0;
+    pptr[lane] = mp0.ptr + (nat ? (size_t)li * len : (size_t)li);
+    pstr[lane] = nat ? 1 : g.nlines;
+  }
+  // reciprocal tables: one IEEE division per (map, dx), spread over the 64 lanes
+  for (int e = lane; e < nmb * len; e += 64) {
+    const int ms = e / len, dx = e - ms * len;
+    const double a = maps[g.map0 + m_first + ms].a;
+    R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
   }
   __syncthreads();
-  if (lane >= nl) return;
-  const int gi = t.g0 + lane;
-  const int mi = gi / g.nlines, li = gi - mi * g.nlines;
-  const DtMap mp = maps[g.map0 + mi];
-  const double a = mp.a, b = mp.b;
-  float* Yl = Y + lane * S;
-  float* Zl = Z + lane * S;
-  unsigned short* Vl = V + lane * S;
-
-  // ---- build the upper envelope (:156-170) ----
-  int k = 0, vk = 0;
-  float yk = Yl[0], zk = -INFINITY;
-  Vl[0] = 0;
-  Zl[0] = -INFINITY;
-  for (int q = 1; q < len; ++q) {
-    const float yq = Yl[q];
-    float s = dt_isect(a, b, vk, q, yk, yq);
-    while (s <= zk && k > 0) {
-      k--;
-      vk = Vl[k]; yk = Yl[k]; zk = Zl[k];
-      s = dt_isect(a, b, vk, q, yk, yq);
+  DT_STAMP(1);
+  // coalesced load of the nl lines.  Batches of 8 independent loads are issued before the first
+  // wait (addresses are clamped instead of predicated: a predicated load makes hipcc branch and
+  // wait per element, which serialises one full memory round trip per 256 B).
+  {
+    const int CH = (len + 63) >> 6;          // 64-element chunks per line
+    const int nch = nl * CH;
+    for (int c0 = 0; c0 < nch; c0 += 8) {
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = min(c0 + j, nch - 1);
+        const int i = c / CH;
+        const int q = min((c - i * CH) * 64 + lane, len - 1);
+        r[j] = lptr[i][q];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        const int i = min(c, nch - 1) / CH;
+        const int q = (min(c, nch - 1) - i * CH) * 64 + lane;
+        if (c < nch && q < len) Y[i * S + q] = r[j];
+      }
     }
-    k++;
-    Vl[k] = (unsigned short)q; Yl[k] = yq; Zl[k] = s;
-    vk = q; yk = yq; zk = s;
   }
-  Zl[k + 1] = INFINITY;
+  __syncthreads();
+  DT_STAMP(2);
 
-  // ---- read out (:172-178), transposed + coalesced across lanes ----
-  float* dst = mp.dst + li;
-  int16_t* ptr = mp.ptr + li;
-  const int nlines = g.nlines;
-  int os = mp.os;
-  k = 0;
-  vk = Vl[0]; yk = Yl[0];
-  float zn = Zl[1];
-  for (int q = 0; q < len; ++q) {
-    const float fos = (float)os;
-    while (zn < fos) { k++; zn = Zl[k + 1]; vk = Vl[k]; yk = Yl[k]; }
-    const int d = os - vk;
-    dst[(size_t)q * nlines] = (float)(a * (double)(d * d) + b * (double)d + (double)yk);
-    ptr[(size_t)q * nlines] = (int16_t)vk;
-    os++;
+  // ---- build the upper envelope (DistanceTransform.hpp:156-170), one lane per line ----
+  // The reference's nested loops (for q { while (pop) }) are flattened into a per-lane state
+  // machine that performs exactly one intersection per iteration, so lanes never wait for the
+  // slowest lane's pop count, and every line sees the reference's sequence of intersections and
+  // `s <= z[k]` comparisons in order.  A single in-order wave exposes every latency, so the body
+  // is branch-free and keeps all LDS operands one iteration ahead:
+  //   * stack top (v,y,z) and the entry below it live in registers;
+  //   * the entry two below, the reciprocal needed if this step pushes (R[dx+1]) and the line
+  //     element two ahead are loaded at the top of the iteration and consumed at its end;
+  //   * the stack stores of a push are issued unconditionally to slot k+1 (dead when popping).
+  if (lane < nl) {
+    const int gi = t.g0 + lane;
+    const int mi = gi / g.nlines;
+    const DtMap mp = maps[g.map0 + mi];
+    const double a = mp.a, b = mp.b, twoa = 2 * a;
+    const double* Rl = R + (mi - m_first) * S;
+    float* Yl = Y + lane * S;
+    float* Zl = Z + lane * S;
+    unsigned short* Vl = V + lane * S;
+    const double r1 = Rl[1 < len ? 1 : 0];
+    int k = 0, q = 1, vk = 0, nv = 0;
+    float zk = -INFINITY, nz = -INFINITY;
+    double yk = (double)Yl[0], ny = 0.0;
+    double r_top = r1, r_nxt = r1;
+    Vl[0] = 0;
+    Zl[0] = -INFINITY;
+    float yq_f = Yl[min(1, len - 1)], yq1_f = Yl[min(2, len - 1)];
+    while (q < len) {
+      // prefetches (addresses known now, values used after the arithmetic below)
+      const int k2 = max(k - 2, 0);
+      const int pv = Vl[k2];
+      const float py_f = Yl[k2], pz = Zl[k2];
+      const int dx = q - vk;
+      const double rn_push = Rl[min(dx + 1, len - 1)];
+      const float yq2_f = Yl[min(q + 2, len - 1)];
+      // intersection with the stack top (same fp64 operations as dt_isect_fast)
+      const double yq = (double)yq_f;
+      const double dxd = (double)dx;
+      const double num = ((yq - yk) - b * dxd) + a * (double)(dx * (q + vk));
+      const double den = twoa * dxd;
+      const double q0 = num * r_top;
+      const double rem = __builtin_fma(-q0, den, num);
+      double q1 = __builtin_fma(rem, r_top, q0);
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
+      const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
+      const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
+      if ((lo29 - 0x0FFFFFFFu) <= 2u || (ex - 897u) > 252u) q1 = num / den;  // exactness guard (rare)
+      const float s = (float)q1;
+      const bool pop = (s <= zk) && (k > 0);  // :162
+      // push stores (:166-169); slot k+1 is dead if this step pops
+      Vl[k + 1] = (unsigned short)q; Yl[k + 1] = yq_f; Zl[k + 1] = s;
+      // reciprocal for the entry two below, needed only after a second consecutive pop
+      const double rn_pop = Rl[max(q - pv, 0)];
+      // state update, selects only
+      const int vk_o = vk; const double yk_o = yk; const float zk_o = zk;
+      k = pop ? k - 1 : k + 1;
+      vk = pop ? nv : q;
+      yk = pop ? ny : yq;
+      zk = pop ? nz : s;
+      r_top = pop ? r_nxt : r1;
+      nv = pop ? pv : vk_o;
+      ny = pop ? (double)py_f : yk_o;
+      nz = pop ? pz : zk_o;
+      r_nxt = pop ? rn_pop : rn_push;
+      yq_f = pop ? yq_f : yq1_f;
+      yq1_f = pop ? yq1_f : yq2_f;
+      q = pop ? q : q + 1;
+    }
+    Zl[k + 1] = INFINITY;
+    Ksz[lane] = k;
   }
+  __syncthreads();
+  DT_STAMP(3);
+
+  // ---- read out (:172-178) ----
+  // Output q of a line depends only on the finished stack, so the 64/lpb idle lane groups share a
+  // line: sub-range r of the outputs starts from a binary search for its first stack entry.
+  {
+    const int nsub = 64 / lpb;              // lpb is a power of two <= 64
+    const int line = lane % lpb, sub = lane / lpb;
+    if (line < nl) {
+      const int gi = t.g0 + line;
+      const int mi = gi / g.nlines, li = gi - mi * g.nlines;
+      const DtMap mp = maps[g.map0 + mi];
+      const double a = mp.a, b = mp.b;
+      const float* Yl = Y + line * S;
+      const float* Zl = Z + line * S;
+      const unsigned short* Vl = V + line * S;
+      unsigned short* Pl = P + line * S;
+      const int K = Ksz[line];
+      const int chunk = (len + nsub - 1) / nsub;
+      const int q0 = sub * chunk, q1 = min(len, q0 + chunk);
+      if (q0 < q1) {
+        int os = mp.os + q0;
+        // first k with !(z[k+1] < os): z is strictly increasing, z[K+1] = +inf
+        int lo = 0, hi = K;
+        const float f0 = (float)os;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (Zl[mid + 1] < f0) lo = mid + 1; else hi = mid;
+        }
+        int k = lo;
+        int vk = Vl[k];
+        float yk = Yl[k], zn = Zl[k + 1];
+        float* dst = mp.dst + li;
+        const int nlines = g.nlines;
+        for (int q = q0; q < q1; ++q) {
+          const float fos = (float)os;
+          while (zn < fos) { k++; zn = Zl[k + 1]; vk = Vl[k]; yk = Yl[k]; }
+          const int d = os - vk;
+          dst[(size_t)q * nlines] = (float)(a * (double)(d * d) + b * (double)d + (double)yk);
+          Pl[q] = (unsigned short)vk;
+          os++;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  DT_STAMP(4);
+  // ---- pointer planes: all addressing comes from LDS (no dependent global loads in the loop) ----
+  for (int i = 0; i < nl; ++i) {
+    int16_t* ptr = pptr[i];
+    const int st = pstr[i];
+    const unsigned short* Pl = P + i * S;
+    for (int q = lane; q < len; q += 64) ptr[(size_t)q * st] = (int16_t)Pl[q];
+  }
+  DT_STAMP(5);
 }
 
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, int stride, int lpb,
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,
                     hipStream_t s) {
   if (ntasks <= 0) return;
-  const size_t lds = dt_lds_bytes(stride, lpb);
   static size_t configured = 0;
   if (lds > configured) {
     hipFuncSetAttribute((const void*)k_dt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = lds;
   }
-  hipLaunchKernelGGL(k_dt_pass, dim3(ntasks), dim3(64), lds, s, tasks, groups, maps, stride, lpb);
+  hipLaunchKernelGGL(k_dt_pass, dim3(ntasks), dim3(64), lds, s, tasks, groups, maps);
 }
 
 // ---------------------------------------------------------------------------
@@ -141,13 +303,13 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
         if (wv > v) { bi = mm; v = wv; }                      // strict >: first max wins
       }
     }
-    int ix = J.ixT[(size_t)bi * HW + (size_t)n_ * H + m_];
+    int ix = J.ixT[(size_t)bi * HW + cell];              // x pass stores its pointers row-major
     int iy;
     if (!correct_ptr) {
       iy = J.iy[(size_t)bi * HW + (size_t)m_ * W + ix];       // Iy'(m,n) = Iy(m, Ix(m,n))
     } else {
       iy = J.iy[(size_t)bi * HW + cell];
-      ix = J.ixT[(size_t)bi * HW + (size_t)n_ * H + iy];      // true arg-max composition
+      ix = J.ixT[(size_t)bi * HW + (size_t)iy * W + n_];      // true arg-max composition
     }
     J.ox[m][cell] = (int16_t)ix;
     J.oy[m][cell] = (int16_t)iy;

@@ -22,13 +22,17 @@
 struct HogLds {
   int PT;        // pixel window side
   int NB;        // blocks per side (TC+2)
-  size_t mag_off, bin_off, hist_off, norm_off, ninv_off, tab_off, total;
+  int MG;        // raw-tile margin before the window (source clamping can reach back sbin/2 pixels)
+  int RT;        // raw tile side
+  size_t mag_off, bin_off, hist_off, norm_off, ninv_off, tab_off, raw_off, total;
 };
 
-__host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc) {
+__host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int cn) {
   HogLds L;
   L.NB = tc + 2;
   L.PT = L.NB * sbin + sbin + 2;
+  L.MG = sbin / 2 + 2;
+  L.RT = L.PT + L.MG + 1;
   size_t o = 0;
   L.mag_off = o; o += sizeof(float) * L.PT * L.PT;
   L.hist_off = o; o += sizeof(float) * L.NB * L.NB * PBD_NORIENT;
@@ -36,10 +40,12 @@ __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc) {
   L.ninv_off = o; o += sizeof(float) * (tc + 1) * (tc + 1);
   L.tab_off = o; o += (sizeof(float) * 2 + sizeof(int)) * 2 * L.PT;  // w0,w1,ip for y and x
   L.bin_off = o; o += L.PT * L.PT;
+  o = (o + 3) & ~(size_t)3;
+  L.raw_off = o; o += (size_t)L.RT * L.RT * cn;
   L.total = (o + 15) & ~(size_t)15;
   return L;
 }
-size_t hog_lds_bytes(int sbin, int tc) { return hog_lds_layout(sbin, tc).total; }
+size_t hog_lds_bytes(int sbin, int tc) { return hog_lds_layout(sbin, tc, 3).total; }
 
 __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
                                              const uint8_t* __restrict__ pyr, float* __restrict__ feat, int cn,
@@ -47,9 +53,10 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const HogTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
-  const HogLds L = hog_lds_layout(sbin, tc);
+  const HogLds L = hog_lds_layout(sbin, tc, 3);
   float* mag = (float*)(smem + L.mag_off);
   uint8_t* bin = (uint8_t*)(smem + L.bin_off);
+  uint8_t* raw = (uint8_t*)(smem + L.raw_off);
   float* hist = (float*)(smem + L.hist_off);
   float* norm = (float*)(smem + L.norm_off);
   float* ninv = (float*)(smem + L.ninv_off);
@@ -59,14 +66,34 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
   float* wx1 = wx0 + L.PT;
   int* ipy = (int*)(wx1 + L.PT);
   int* ipx = ipy + L.PT;
-  const int PT = L.PT, NB = L.NB, tid = threadIdx.x;
+  const int PT = L.PT, NB = L.NB, RT = L.RT, tid = threadIdx.x;
   const int w = lv.iw, h = lv.ih, bw = lv.bw, bh = lv.bh;
   const int vw = bw * sbin, vh = bh * sbin;  // :176 visible
   const uint8_t* im = pyr + lv.img_off;
   const int stride = w * cn;
   // pixel window origin: first pixel that can touch block (cy0, cx0), minus one for safety
   const int py0 = t.cy0 * sbin - sbin / 2 - 1, px0 = t.cx0 * sbin - sbin / 2 - 1;
+  const int ry0 = py0 - L.MG, rx0 = px0 - L.MG;  // raw tile origin (source coordinates, clamped on load)
 
+  // ---- stage the source pixels of the window (+margins) in LDS, coalesced byte rows ----
+  const int rowb = RT * cn;
+  {
+    const int nbytes = RT * rowb;
+    for (int i0 = tid; i0 < nbytes; i0 += 256 * 16) {  // 16 independent byte loads in flight per lane
+      uint8_t r[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int i = min(i0 + j * 256, nbytes - 1);
+        const int rr = i / rowb, cb = i - rr * rowb;
+        const int xc = cb / cn, ch = cb - xc * cn;
+        const int sy = min(max(ry0 + rr, 0), h - 1), sx = min(max(rx0 + xc, 0), w - 1);
+        r[j] = im[(size_t)sy * stride + sx * cn + ch];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (i0 + j * 256 < nbytes) raw[i0 + j * 256] = r[j];
+    }
+  }
   // ---- interpolation tables per window row / column (:252-260) ----
   for (int i = tid; i < 2 * PT; i += 256) {
     const bool isx = i >= PT;
@@ -79,6 +106,7 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
     if (isx) { wx0[j] = v0; wx1[j] = v1; ipx[j] = ip; }
     else { wy0[j] = v0; wy1[j] = v1; ipy[j] = ip; }
   }
+  __syncthreads();
 
   // ---- per-pixel gradient magnitude + orientation bin (:202-249) ----
   const float uu[9] = {1.000, 0.9397, 0.7660, 0.5000, 0.1736, -0.1736, -0.5000, -0.7660, -0.9397};
@@ -89,22 +117,21 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
     float m = 0.f;
     int b = 255;
     if (y >= 1 && y < vh - 1 && x >= 1 && x < vw - 1) {
-      const int sx = min(x, w - 2), sy = min(y, h - 2);
+      const int sx = min(x, w - 2), sy = min(y, h - 2);  // :208,218 source clamp
+      const uint8_t* s = raw + ((sy - ry0) * RT + (sx - rx0)) * cn;
       float dx, dy, v;
       if (cn == 1) {
-        const uint8_t* s = im + sx + (size_t)sy * stride;
-        dy = (float)((int)s[stride] - (int)s[-stride]);
+        dy = (float)((int)s[rowb] - (int)s[-rowb]);
         dx = (float)((int)s[1] - (int)s[-1]);
         v = dx * dx + dy * dy;
       } else {
-        const uint8_t* s = im + 3 * sx + (size_t)sy * stride;
-        float dyb = (float)((int)s[stride] - (int)s[-stride]);
+        float dyb = (float)((int)s[rowb] - (int)s[-rowb]);
         float dxb = (float)((int)s[3] - (int)s[-3]);
         float vb = dxb * dxb + dyb * dyb;
-        float dyg = (float)((int)s[stride + 1] - (int)s[-stride + 1]);
+        float dyg = (float)((int)s[rowb + 1] - (int)s[-rowb + 1]);
         float dxg = (float)((int)s[4] - (int)s[-2]);
         float vg = dxg * dxg + dyg * dyg;
-        dy = (float)((int)s[stride + 2] - (int)s[-stride + 2]);
+        dy = (float)((int)s[rowb + 2] - (int)s[-rowb + 2]);
         dx = (float)((int)s[5] - (int)s[-1]);
         v = dx * dx + dy * dy;
         if (vg > v) { v = vg; dx = dxg; dy = dyg; }
@@ -124,37 +151,34 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
     mag[i] = m;
     bin[i] = (uint8_t)b;
   }
+  for (int i = tid; i < NB * NB * PBD_NORIENT; i += 256) hist[i] = 0.f;
   __syncthreads();
 
-  // ---- histogram gather: one thread per (block, orientation) bin (:262-265) ----
-  for (int i = tid; i < NB * NB * PBD_NORIENT; i += 256) {
-    const int o = i % PBD_NORIENT;
-    const int bl = i / PBD_NORIENT;
+  // ---- histogram: one thread owns one block's 18 bins and walks the block's pixels in the
+  //      reference's raster order (:262-265), so every bin sees the same sequence of float adds ----
+  for (int bl = tid; bl < NB * NB; bl += 256) {
     const int lby = bl / NB, lbx = bl - lby * NB;
     const int by = t.cy0 + lby, bx = t.cx0 + lbx;
-    float acc = 0.f;
-    if (by < bh && bx < bw) {
-      // candidate window rows/cols: every pixel with ip in {b-1, b}
-      const int wy_lo = lby * sbin, wx_lo = lbx * sbin;  // (py0 offset makes this a superset start)
-      const int span = 2 * sbin + 2;
-      for (int dy = 0; dy < span; ++dy) {
-        const int wy = wy_lo + dy;
-        if (wy >= PT) break;
-        const int iy = ipy[wy];
-        float fy;
-        if (iy == by) fy = wy1[wy]; else if (iy == by - 1) fy = wy0[wy]; else continue;
-        for (int dx = 0; dx < span; ++dx) {
-          const int wx = wx_lo + dx;
-          if (wx >= PT) break;
-          if (bin[wy * PT + wx] != o) continue;
-          const int ix = ipx[wx];
-          float fx;
-          if (ix == bx) fx = wx1[wx]; else if (ix == bx - 1) fx = wx0[wx]; else continue;
-          acc += (fy * fx) * mag[wy * PT + wx];
-        }
+    if (by >= bh || bx >= bw) continue;
+    float* hb = hist + bl * PBD_NORIENT;
+    const int wy_lo = lby * sbin, wx_lo = lbx * sbin, span = 2 * sbin + 2;
+    for (int dy = 0; dy < span; ++dy) {
+      const int wy = wy_lo + dy;
+      if (wy >= PT) break;
+      const int iy = ipy[wy];
+      float fy;
+      if (iy == by) fy = wy1[wy]; else if (iy == by - 1) fy = wy0[wy]; else continue;
+      for (int dx = 0; dx < span; ++dx) {
+        const int wx = wx_lo + dx;
+        if (wx >= PT) break;
+        const int ix = ipx[wx];
+        float fx;
+        if (ix == bx) fx = wx1[wx]; else if (ix == bx - 1) fx = wx0[wx]; else continue;
+        const int o = bin[wy * PT + wx];
+        if (o == 255) continue;
+        hb[o] += (fy * fx) * mag[wy * PT + wx];
       }
     }
-    hist[i] = acc;
   }
   __syncthreads();
 

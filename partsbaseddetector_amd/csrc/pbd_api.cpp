@@ -259,7 +259,24 @@ static void free_frame(pbd_handle* h) {
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
 }
 
-static int dt_class_of(int len) { return len >= 256 ? 0 : (len >= 80 ? 1 : (len >= 32 ? 2 : 3)); }
+// DT block geometry under an LDS budget.  stride = len+1 rounded up to even (keeps the double
+// table and the float arrays 8-byte aligned); lpb = lines per block (power of two, 8..64);
+// nmb = maps a block of lpb consecutive lines can touch.
+static int dt_stride_for(int len) { return (len + 2) & ~1; }
+static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (lpb + nlines - 2) / nlines + 1); }
+static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget) {
+  int lpb = 64;
+  while (lpb > 8 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps)) > budget) lpb /= 2;
+  return lpb;
+}
+static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget) {
+  DtGroup g{};
+  g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len;
+  g.stride = dt_stride_for(len);
+  g.lpb = dt_lpb_for(g.stride, nlines, nmaps, budget);
+  g.nmb = dt_nmb_for(g.lpb, nlines, nmaps);
+  return g;
+}
 
 static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   if (h->fw == w && h->fh == hgt && h->fcn == cn) return PBD_OK;
@@ -335,21 +352,12 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   if ((rc = dev_alloc(h, &h->d_dt_ixT, h->dt_cap_elems))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_iy, h->dt_cap_elems))) return rc;
 
-  // DT size classes: one launch per class so short lines do not inherit the LDS footprint of long ones
-  for (int p = 0; p < 2; ++p) for (int c = 0; c < 4; ++c) { h->dt_stride[p][c] = 0; h->dt_lpb[p][c] = 64; }
-  for (int l = 0; l < n; ++l) {
-    const Level& L = h->lv[l];
-    if (!L.active || L.cw == 0 || L.ch == 0) continue;
-    int& sx = h->dt_stride[0][dt_class_of(L.cw)]; sx = std::max(sx, (L.cw + 1) | 1);
-    int& sy = h->dt_stride[1][dt_class_of(L.ch)]; sy = std::max(sy, (L.ch + 1) | 1);
-  }
-  for (int p = 0; p < 2; ++p)
-    for (int c = 0; c < 4; ++c) {
-      int& lpb = h->dt_lpb[p][c];
-      while (lpb > 8 && dt_lds_bytes(h->dt_stride[p][c], lpb) > 160 * 1024) lpb /= 2;
-      if (dt_lds_bytes(h->dt_stride[p][c], lpb) > 160 * 1024)
-        return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
-    }
+  // DT LDS budget: ~36 KB per block (4 blocks per CU) unless the longest line needs more at 8 lines/block
+  int maxlen = 1;
+  for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
+  size_t dt_budget = std::max<size_t>(36 * 1024, dt_lds_bytes(dt_stride_for(maxlen), 8, 2));
+  if (dt_budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
+  h->dt_lds = dt_budget;
   std::vector<DtMap> maps;
   std::vector<DtGroup> groups;
   std::vector<DtTask> tasks;
@@ -359,7 +367,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   for (auto& rnd : h->rounds) {
     pbd_handle::RoundLaunch R{};
     // tasks of this round, bucketed by size class for both passes
-    std::vector<DtTask> xt[4], yt[4];
+    std::vector<DtTask> xt, yt;
     R.red0 = (int)red.size();
     unsigned red_cells = 0;
     size_t scratch = 0;
@@ -368,7 +376,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       const Level& L = h->lv[l];
       if (!L.active || L.cw == 0 || L.ch == 0) continue;
       const size_t HW = (size_t)L.cw * L.ch;
-      DtGroup gx{(int)maps.size(), 0, L.ch, L.cw};
+      const int gx_map0 = (int)maps.size();
+      int gx_nmaps = 0;
       std::vector<DtMap> ymaps;
       for (int fp : rnd) {
         const PartInfo& P = h->parts[fp];
@@ -385,12 +394,12 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
                                                    : h->d_resp + L.cell_off * m.nfilters + (size_t)fid * HW;
           const float* wv = &h->defw[(size_t)did * 4];
           DtMap mx{src, h->d_dt_tmpT + scratch, h->d_dt_ixT + scratch, -(double)wv[0], -(double)wv[1],
-                   h->anchors[did * 2], 0};
+                   h->anchors[did * 2], 1};
           DtMap my{h->d_dt_tmpT + scratch, h->d_dt_sdt + scratch, h->d_dt_iy + scratch, -(double)wv[2],
                    -(double)wv[3], h->anchors[did * 2 + 1], 0};
           maps.push_back(mx);
           ymaps.push_back(my);
-          gx.nmaps++;
+          gx_nmaps++;
           J.bias_off[mm] = P.biasid[mm];
           scratch += HW;
         }
@@ -405,15 +414,15 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
         red.push_back(J);
         red_cells += (unsigned)HW;
       }
-      DtGroup gy{(int)maps.size(), gx.nmaps, L.cw, L.ch};
+      const DtGroup gx = dt_group(gx_map0, gx_nmaps, L.ch, L.cw, dt_budget);
+      const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, dt_budget);
       for (auto& my : ymaps) maps.push_back(my);
       const int gxi = (int)groups.size();
       groups.push_back(gx);
       const int gyi = (int)groups.size();
       groups.push_back(gy);
-      const int cx = dt_class_of(gx.len), cy = dt_class_of(gy.len);
-      for (int g0 = 0; g0 < gx.nmaps * gx.nlines; g0 += h->dt_lpb[0][cx]) xt[cx].push_back(DtTask{gxi, g0});
-      for (int g0 = 0; g0 < gy.nmaps * gy.nlines; g0 += h->dt_lpb[1][cy]) yt[cy].push_back(DtTask{gyi, g0});
+      for (int g0 = 0; g0 < gx.nmaps * gx.nlines; g0 += gx.lpb) xt.push_back(DtTask{gxi, g0});
+      for (int g0 = 0; g0 < gy.nmaps * gy.nlines; g0 += gy.lpb) yt.push_back(DtTask{gyi, g0});
     }
     // after this round the parents' slots hold accumulated scores
     for (int fp : rnd) {
@@ -422,14 +431,10 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       for (int pm = 0; pm < Par.K; ++pm) slot_init[Par.slot[pm]] = 1;
     }
     (void)slot_after;
-    for (int c = 0; c < 4; ++c) {
-      R.xtask0[c] = (int)tasks.size(); R.nxtasks[c] = (int)xt[c].size();
-      tasks.insert(tasks.end(), xt[c].begin(), xt[c].end());
-    }
-    for (int c = 0; c < 4; ++c) {
-      R.ytask0[c] = (int)tasks.size(); R.nytasks[c] = (int)yt[c].size();
-      tasks.insert(tasks.end(), yt[c].begin(), yt[c].end());
-    }
+    R.xtask0 = (int)tasks.size(); R.nxtasks = (int)xt.size();
+    tasks.insert(tasks.end(), xt.begin(), xt.end());
+    R.ytask0 = (int)tasks.size(); R.nytasks = (int)yt.size();
+    tasks.insert(tasks.end(), yt.begin(), yt.end());
     R.nred = (int)red.size() - R.red0;
     R.red_cells = red_cells;
     h->rl.push_back(R);
@@ -517,10 +522,8 @@ static int run_pdf(pbd_handle* h) {
 static int run_dp_min(pbd_handle* h) {
   if (h->dp_timer_on) hipEventRecord(h->ev_dp0, h->stream);
   for (auto& R : h->rl) {
-    for (int c = 0; c < 4; ++c)
-      launch_dt_pass(h->d_dttasks + R.xtask0[c], R.nxtasks[c], h->d_dtgroups, h->d_dtmaps, h->dt_stride[0][c], h->dt_lpb[0][c], h->stream);
-    for (int c = 0; c < 4; ++c)
-      launch_dt_pass(h->d_dttasks + R.ytask0[c], R.nytasks[c], h->d_dtgroups, h->d_dtmaps, h->dt_stride[1][c], h->dt_lpb[1][c], h->stream);
+    launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
+    launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
     launch_reduce(h->d_redjobs + R.red0, R.nred, R.red_cells, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
   }
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
@@ -872,15 +875,14 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   HIPCHK(h, hipMalloc(&d_ox, HW * 2)); HIPCHK(h, hipMalloc(&d_oy, HW * 2)); HIPCHK(h, hipMalloc(&d_ok, HW));
   HIPCHK(h, hipMemcpyAsync(d_in, in, HW * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(d_zero, 0, HW * 4, h->stream));
-  DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 0}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
-  DtGroup groups[2] = {{0, 1, rows, cols}, {1, 1, cols, rows}};
+  DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
+  const size_t budget = std::max<size_t>(36 * 1024, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 8, 1));
+  if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
+  DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget), dt_group(1, 1, cols, rows, budget)};
   std::vector<DtTask> tasks;
-  int lpbx = 64, lpby = 64;
-  while (lpbx > 8 && dt_lds_bytes((cols + 1) | 1, lpbx) > 160 * 1024) lpbx /= 2;
-  while (lpby > 8 && dt_lds_bytes((rows + 1) | 1, lpby) > 160 * 1024) lpby /= 2;
-  for (int g0 = 0; g0 < rows; g0 += lpbx) tasks.push_back(DtTask{0, g0});
+  for (int g0 = 0; g0 < rows; g0 += groups[0].lpb) tasks.push_back(DtTask{0, g0});
   const int nx = (int)tasks.size();
-  for (int g0 = 0; g0 < cols; g0 += lpby) tasks.push_back(DtTask{1, g0});
+  for (int g0 = 0; g0 < cols; g0 += groups[1].lpb) tasks.push_back(DtTask{1, g0});
   DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks; ReduceJob* d_job;
   HIPCHK(h, hipMalloc(&d_maps, sizeof(maps))); HIPCHK(h, hipMalloc(&d_groups, sizeof(groups)));
   HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size())); HIPCHK(h, hipMalloc(&d_job, sizeof(ReduceJob)));
@@ -893,12 +895,8 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_job, &J, sizeof(J), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
-  if (dt_lds_bytes((cols + 1) | 1, lpbx) > 160 * 1024 || dt_lds_bytes((rows + 1) | 1, lpby) > 160 * 1024) {
-    h->err = "map too large for the LDS-resident distance transform";
-    return PBD_ERR_UNSUPPORTED;
-  }
-  launch_dt_pass(d_tasks, nx, d_groups, d_maps, (cols + 1) | 1, lpbx, h->stream);
-  launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, (rows + 1) | 1, lpby, h->stream);
+  launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, h->stream);
+  launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, h->stream);
   launch_reduce(d_job, 1, (unsigned)HW, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_out, HW * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1078,6 +1076,8 @@ int pbd_get_work(const pbd_handle* h, double work[6]) {
   work[5] = C * dtmaps;
   return PBD_OK;
 }
+int pbd_debug_dt_stamps(unsigned long long* out) { dt_debug_read(out); return PBD_OK; }
+
 int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes) {
   if (!h) return PBD_ERR_ARG;
   if (avg_ms) *avg_ms = h->dp_frames ? h->dp_ms_sum / h->dp_frames : 0.0;

@@ -57,14 +57,14 @@ struct DtMap {       // one 1-D pass over one score map
   float* dst;        // transposed out: element q of line i at dst + q*nlines + i
   int16_t* ptr;      // same layout as dst
   double a, b;       // Quadratic(a, b)
-  int os, pad;
+  int os, ptr_natural;  // ptr_natural: write ptr row-major [line][q] instead of transposed
 };
-struct DtGroup { int map0, nmaps, nlines, len; };
+struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, nmb, pad; };  // stride: LDS elements per line (even); lpb: lines per block; nmb: max maps a block touches
 struct DtTask { int group, g0; };
 
 struct ReduceJob {   // one (level, child part): max over child mixtures for each parent mixture
   const float* sdt;      // [K][H][W] distance-transformed child scores
-  const int16_t* ixT;    // [K][W][H] x pointers (transposed)
+  const int16_t* ixT;    // [K][H][W] x pointers (row-major)
   const int16_t* iy;     // [K][H][W] y pointers
   int H, W, K, L;
   int bias_off[PBD_MAX_MIX];       // biasw index of bias(mm)[0] for each child mixture mm (K<=8)
@@ -139,11 +139,8 @@ struct pbd_handle {
   // DP tables (all rounds back to back)
   DtMap* d_dtmaps = nullptr; DtGroup* d_dtgroups = nullptr; DtTask* d_dttasks = nullptr;
   ReduceJob* d_redjobs = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
-  struct RoundLaunch {
-    int xtask0[4], nxtasks[4], ytask0[4], nytasks[4];  // per DT size class
-    int red0, nred; unsigned red_cells;
-  };
-  int dt_stride[2][4] = {}, dt_lpb[2][4] = {};      // [pass][class] LDS line stride / lines per block
+  struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks, red0, nred; unsigned red_cells; };
+  size_t dt_lds = 0;                                 // dynamic LDS of every k_dt_pass launch
   std::vector<RoundLaunch> rl;
   int n_rootjobs = 0; unsigned root_cells = 0;
   // candidates
@@ -172,9 +169,9 @@ void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels
                        const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, int stride, int lpb,
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,
                     hipStream_t s);
-size_t dt_lds_bytes(int stride, int lpb);
+size_t dt_lds_bytes(int stride, int lpb, int nmb);
 void launch_reduce(const ReduceJob* jobs, int njobs, unsigned total_cells, const float* biasw, int correct_ptr,
                    hipStream_t s);
 void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
@@ -182,4 +179,5 @@ void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double th
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
                       char* out, size_t out_stride, hipStream_t s);
+void dt_debug_read(unsigned long long* out);
 void launch_nms_map(const float* src, int rows, int cols, int sz, uint8_t* dst, hipStream_t s);
