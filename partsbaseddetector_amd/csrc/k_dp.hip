@@ -287,34 +287,41 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
   }
   const ReduceJob& J = jobs[lo];
   const unsigned cell = gid - J.cell0;
-  const int H = J.H, W = J.W, K = J.K, L = J.L;
+  const int H = J.H, W = J.W, L = J.L;
   const unsigned HW = (unsigned)H * W;
   if (cell >= HW) return;
   const int m_ = cell / W, n_ = cell - m_ * W;
   for (int m = 0; m < L; ++m) {
-    float v;
-    int bi = 0;
-    if (K == 1) {  // Math::reduceMax K==1 shortcut: copy (Math.hpp:154-158)
-      v = J.sdt[cell] + biasw[J.bias_off[0] + m];
-    } else {
-      v = -INFINITY;
-      for (int mm = 0; mm < K; ++mm) {
-        const float wv = J.sdt[(size_t)mm * HW + cell] + biasw[J.bias_off[mm] + m];  // DynamicProgram.cpp:139
-        if (wv > v) { bi = mm; v = wv; }                      // strict >: first max wins
+    float acc = J.par_in[m][cell];
+    for (int c = 0; c < J.nch; ++c) {
+      const ReduceChild& C = J.ch[c];
+      const int K = C.K;
+      float v;
+      int bi = 0;
+      if (K == 1) {  // Math::reduceMax K==1 shortcut: copy (Math.hpp:154-158)
+        v = C.sdt[cell] + biasw[C.bias_off[0] + m];
+      } else {
+        v = -INFINITY;
+        for (int mm = 0; mm < K; ++mm) {
+          const float wv = C.sdt[(size_t)mm * HW + cell] + biasw[C.bias_off[mm] + m];  // DynamicProgram.cpp:139
+          if (wv > v) { bi = mm; v = wv; }                                            // strict >: first max wins
+        }
       }
+      int ix = C.ix[(size_t)bi * HW + cell];
+      int iy;
+      if (!correct_ptr) {
+        iy = C.iy[(size_t)bi * HW + (size_t)m_ * W + ix];       // Iy'(m,n) = Iy(m, Ix(m,n))
+      } else {
+        iy = C.iy[(size_t)bi * HW + cell];
+        ix = C.ix[(size_t)bi * HW + (size_t)iy * W + n_];       // true arg-max composition
+      }
+      const size_t o = (size_t)m * HW + cell;
+      C.ox[o] = (int16_t)ix;
+      C.oy[o] = (int16_t)iy;
+      C.ok[o] = (uint8_t)bi;
+      acc = acc + v;                                            // parent.score += maxv (:156), child order kept
     }
-    int ix = J.ixT[(size_t)bi * HW + cell];              // x pass stores its pointers row-major
-    int iy;
-    if (!correct_ptr) {
-      iy = J.iy[(size_t)bi * HW + (size_t)m_ * W + ix];       // Iy'(m,n) = Iy(m, Ix(m,n))
-    } else {
-      iy = J.iy[(size_t)bi * HW + cell];
-      ix = J.ixT[(size_t)bi * HW + (size_t)iy * W + n_];      // true arg-max composition
-    }
-    J.ox[m][cell] = (int16_t)ix;
-    J.oy[m][cell] = (int16_t)iy;
-    J.ok[m][cell] = (uint8_t)bi;
-    J.par_out[m][cell] = J.par_in[m][cell] + v;               // parent.score += maxv (:156)
+    J.par_out[m][cell] = acc;
   }
 }
 

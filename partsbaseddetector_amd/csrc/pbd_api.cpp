@@ -150,37 +150,63 @@ static int ingest_model(pbd_handle* h, const pbd_model_desc* m) {
   h->nplanes = plane_next;
 
   // ---- round schedule -------------------------------------------------------
-  // A part is transformed once all its children have sent their message
-  // (DynamicProgram.cpp:95 walks p = P-1..1 and parent < child).  Messages into
-  // one parent are float adds in descending child order (:156), so siblings are
-  // serialised in that order; everything else in a round is independent.
+  // DT of a part runs once all its children have sent their message (DynamicProgram.cpp:95 walks
+  // p = P-1..1 with parent < child): round = height of the part.  Messages into one parent are
+  // float adds in DESCENDING child order (:156); to keep those bits, a child's message is folded
+  // no earlier than every higher-indexed sibling's (reduce round = max over them), and siblings
+  // folded in the same round go through ONE reduce job that adds them in that order.
   h->rounds.clear();
-  std::vector<int> done(np, 0);
-  if (aliasing) {  // shared filter ids inside a component: keep the reference's sequential order
+  h->red_rounds.clear();
+  if (aliasing) {  // shared filter ids inside a component: keep the reference's strictly sequential order
     for (int c = 0; c < nc; ++c)
-      for (int p = h->part_offset[c + 1] - h->part_offset[c] - 1; p > 0; --p)
+      for (int p = h->part_offset[c + 1] - h->part_offset[c] - 1; p > 0; --p) {
         h->rounds.push_back(std::vector<int>(1, h->part_offset[c] + p));
-  } else {
-    int remaining = 0;
-    for (int fp = 0; fp < np; ++fp) if (h->parts[fp].p > 0) remaining++;
-    while (remaining > 0) {
-      std::vector<int> rnd;
-      for (int fp = 0; fp < np; ++fp) {
-        const PartInfo& P = h->parts[fp];
-        if (P.p == 0 || done[fp]) continue;
-        const int p0 = h->part_offset[P.comp], cnp = h->part_offset[P.comp + 1] - p0;
-        bool ready = true;
-        for (int q = P.p + 1; q < cnp && ready; ++q) {
-          if (done[p0 + q]) continue;
-          if (h->parts[p0 + q].parent == P.p) ready = false;          // a child not yet processed
-          if (h->parts[p0 + q].parent == P.parent) ready = false;     // a later sibling not yet processed
-        }
-        if (ready) rnd.push_back(fp);
+        h->red_rounds.push_back({std::vector<int>(1, h->part_offset[c] + p)});
       }
-      if (rnd.empty()) return fail(h, PBD_ERR_ARG, "model: part tree cannot be scheduled");
-      for (int fp : rnd) done[fp] = 1;
-      remaining -= (int)rnd.size();
-      h->rounds.push_back(rnd);
+  } else {
+    std::vector<int> height(np, 0), rround(np, 0);
+    int nrounds = 0;
+    for (int c = 0; c < nc; ++c) {
+      const int p0 = h->part_offset[c], cnp = h->part_offset[c + 1] - p0;
+      for (int p = cnp - 1; p > 0; --p) {  // children before parents (parent < child)
+        const int par = h->parts[p0 + p].parent;
+        height[p0 + par] = std::max(height[p0 + par], height[p0 + p] + 1);
+      }
+      for (int p = cnp - 1; p > 0; --p) {  // descending index: higher siblings first
+        int rr = height[p0 + p];
+        for (int q = p + 1; q < cnp; ++q)
+          if (h->parts[p0 + q].parent == h->parts[p0 + p].parent) rr = std::max(rr, rround[p0 + q]);
+        rround[p0 + p] = rr;
+        nrounds = std::max(nrounds, rr + 1);
+      }
+    }
+    h->rounds.assign(nrounds, {});
+    std::vector<std::vector<int>> red(nrounds);
+    for (int fp = 0; fp < np; ++fp) {
+      if (h->parts[fp].p == 0) continue;
+      h->rounds[height[fp]].push_back(fp);
+      red[rround[fp]].push_back(fp);
+    }
+    // waves: at most PBD_MAX_CH children of one parent per reduce job; overflow goes to a later wave
+    h->red_rounds.assign(nrounds, {});
+    for (int r = 0; r < nrounds; ++r) {
+      std::vector<int> rest(red[r].rbegin(), red[r].rend());  // descending flat index
+      while (!rest.empty()) {
+        std::vector<int> wave, next;
+        std::map<int, int> cnt;
+        for (int fp : rest) {
+          const int parent_fp = h->part_offset[h->parts[fp].comp] + h->parts[fp].parent;
+          if (cnt[parent_fp] < PBD_MAX_CH && !std::count_if(next.begin(), next.end(), [&](int g) {
+                return h->part_offset[h->parts[g].comp] + h->parts[g].parent == parent_fp; })) {
+            cnt[parent_fp]++;
+            wave.push_back(fp);
+          } else {
+            next.push_back(fp);
+          }
+        }
+        h->red_rounds[r].push_back(wave);
+        rest.swap(next);
+      }
     }
   }
   return PBD_OK;
@@ -341,12 +367,14 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   if ((rc = dev_upload(h, &h->d_conv_tiles, ct))) return rc;
 
   // ---- DP tables ---------------------------------------------------------------
-  // scratch capacity: max over rounds of sum_{parts in round} K * cells(active)
+  // DT scratch: every (part, mixture) keeps its own x-pass / y-pass outputs until its message has
+  // been folded (a message may wait for a higher-indexed sibling), so nothing is recycled:
+  // 4 planes x 150 maps x 140 K cells = 250 MB for the person model, trivial next to 288 GB.
   size_t act_cells = 0;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) act_cells += (size_t)h->lv[l].cw * h->lv[l].ch;
-  size_t maxmaps = 1;
-  for (auto& rnd : h->rounds) { size_t k = 0; for (int fp : rnd) k += h->parts[fp].K; maxmaps = std::max(maxmaps, k); }
-  h->dt_cap_elems = maxmaps * act_cells;
+  size_t allmaps = 0;
+  for (const PartInfo& P : h->parts) if (P.p > 0) allmaps += P.K;
+  h->dt_cap_elems = std::max<size_t>(1, allmaps * act_cells);
   if ((rc = dev_alloc(h, &h->d_dt_tmpT, h->dt_cap_elems))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_sdt, h->dt_cap_elems))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_ixT, h->dt_cap_elems))) return rc;
@@ -364,15 +392,19 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   std::vector<ReduceJob> red;
   h->rl.clear();
   std::vector<char> slot_init((size_t)h->nslots, 0);  // ncscores[fid].empty() emulation (same for every level)
-  for (auto& rnd : h->rounds) {
+  // scratch offset of (part, level): parts in flat order, levels inside
+  std::vector<size_t> part_scr(h->parts.size(), 0);
+  { size_t o = 0; for (size_t fp = 0; fp < h->parts.size(); ++fp) if (h->parts[fp].p > 0) { part_scr[fp] = o; o += (size_t)h->parts[fp].K * act_cells; } }
+  std::vector<size_t> lvl_scr(n, 0);  // prefix of active cells
+  { size_t o = 0; for (int l = 0; l < n; ++l) { lvl_scr[l] = o; if (h->lv[l].active) o += (size_t)h->lv[l].cw * h->lv[l].ch; } }
+  auto scr_of = [&](int fp, int l, int mm) {
+    return part_scr[fp] + (size_t)h->parts[fp].K * lvl_scr[l] + (size_t)mm * h->lv[l].cw * h->lv[l].ch;
+  };
+  for (size_t r = 0; r < h->rounds.size(); ++r) {
+    const std::vector<int>& rnd = h->rounds[r];
     pbd_handle::RoundLaunch R{};
-    // tasks of this round, bucketed by size class for both passes
     std::vector<DtTask> xt, yt;
-    R.red0 = (int)red.size();
-    unsigned red_cells = 0;
-    size_t scratch = 0;
-    std::vector<char> slot_after = slot_init;
-    for (int l = 0; l < n; ++l) {
+    for (int l = 0; l < n && !rnd.empty(); ++l) {
       const Level& L = h->lv[l];
       if (!L.active || L.cw == 0 || L.ch == 0) continue;
       const size_t HW = (size_t)L.cw * L.ch;
@@ -381,38 +413,19 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       std::vector<DtMap> ymaps;
       for (int fp : rnd) {
         const PartInfo& P = h->parts[fp];
-        const PartInfo& Par = h->parts[h->part_offset[P.comp] + P.parent];
-        ReduceJob J{};
-        J.sdt = h->d_dt_sdt + scratch;
-        J.ixT = h->d_dt_ixT + scratch;
-        J.iy = h->d_dt_iy + scratch;
-        J.H = L.ch; J.W = L.cw; J.K = P.K; J.L = Par.K;
-        J.cell0 = red_cells;
         for (int mm = 0; mm < P.K; ++mm) {
           const int fid = P.filterid[mm], did = P.defid[mm];
+          const size_t so = scr_of(fp, l, mm);
           const float* src = slot_init[P.slot[mm]] ? h->d_acc + L.cell_off * h->nslots + (size_t)P.slot[mm] * HW
                                                    : h->d_resp + L.cell_off * m.nfilters + (size_t)fid * HW;
           const float* wv = &h->defw[(size_t)did * 4];
-          DtMap mx{src, h->d_dt_tmpT + scratch, h->d_dt_ixT + scratch, -(double)wv[0], -(double)wv[1],
-                   h->anchors[did * 2], 1};
-          DtMap my{h->d_dt_tmpT + scratch, h->d_dt_sdt + scratch, h->d_dt_iy + scratch, -(double)wv[2],
-                   -(double)wv[3], h->anchors[did * 2 + 1], 0};
+          DtMap mx{src, h->d_dt_tmpT + so, h->d_dt_ixT + so, -(double)wv[0], -(double)wv[1], h->anchors[did * 2], 1};
+          DtMap my{h->d_dt_tmpT + so, h->d_dt_sdt + so, h->d_dt_iy + so, -(double)wv[2], -(double)wv[3],
+                   h->anchors[did * 2 + 1], 0};
           maps.push_back(mx);
           ymaps.push_back(my);
           gx_nmaps++;
-          J.bias_off[mm] = P.biasid[mm];
-          scratch += HW;
         }
-        for (int pm = 0; pm < Par.K; ++pm) {
-          const int pslot = Par.slot[pm], pfid = Par.filterid[pm];
-          float* accp = h->d_acc + L.cell_off * h->nslots + (size_t)pslot * HW;
-          J.par_in[pm] = slot_after[pslot] ? accp : h->d_resp + L.cell_off * m.nfilters + (size_t)pfid * HW;
-          J.par_out[pm] = accp;
-          const size_t po = L.cell_off * h->nplanes + (size_t)(P.plane0 + pm) * HW;
-          J.ox[pm] = h->d_px + po; J.oy[pm] = h->d_py + po; J.ok[pm] = h->d_pk + po;
-        }
-        red.push_back(J);
-        red_cells += (unsigned)HW;
       }
       const DtGroup gx = dt_group(gx_map0, gx_nmaps, L.ch, L.cw, dt_budget);
       const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, dt_budget);
@@ -424,19 +437,51 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       for (int g0 = 0; g0 < gx.nmaps * gx.nlines; g0 += gx.lpb) xt.push_back(DtTask{gxi, g0});
       for (int g0 = 0; g0 < gy.nmaps * gy.nlines; g0 += gy.lpb) yt.push_back(DtTask{gyi, g0});
     }
-    // after this round the parents' slots hold accumulated scores
-    for (int fp : rnd) {
-      const PartInfo& P = h->parts[fp];
-      const PartInfo& Par = h->parts[h->part_offset[P.comp] + P.parent];
-      for (int pm = 0; pm < Par.K; ++pm) slot_init[Par.slot[pm]] = 1;
-    }
-    (void)slot_after;
     R.xtask0 = (int)tasks.size(); R.nxtasks = (int)xt.size();
     tasks.insert(tasks.end(), xt.begin(), xt.end());
     R.ytask0 = (int)tasks.size(); R.nytasks = (int)yt.size();
     tasks.insert(tasks.end(), yt.begin(), yt.end());
-    R.nred = (int)red.size() - R.red0;
-    R.red_cells = red_cells;
+    // reduce waves of this round
+    for (const std::vector<int>& wave : h->red_rounds[r]) {
+      pbd_handle::ReduceWave Wv{(int)red.size(), 0, 0};
+      std::vector<int> parents;  // distinct parents, in first-appearance order
+      for (int fp : wave) {
+        const int pf = h->part_offset[h->parts[fp].comp] + h->parts[fp].parent;
+        if (std::find(parents.begin(), parents.end(), pf) == parents.end()) parents.push_back(pf);
+      }
+      for (int l = 0; l < n; ++l) {
+        const Level& L = h->lv[l];
+        if (!L.active || L.cw == 0 || L.ch == 0) continue;
+        const size_t HW = (size_t)L.cw * L.ch;
+        for (int pf : parents) {
+          const PartInfo& Par = h->parts[pf];
+          ReduceJob J{};
+          J.H = L.ch; J.W = L.cw; J.L = Par.K; J.cell0 = Wv.cells;
+          for (int pm = 0; pm < Par.K; ++pm) {
+            float* accp = h->d_acc + L.cell_off * h->nslots + (size_t)Par.slot[pm] * HW;
+            J.par_in[pm] = slot_init[Par.slot[pm]] ? accp : h->d_resp + L.cell_off * m.nfilters + (size_t)Par.filterid[pm] * HW;
+            J.par_out[pm] = accp;
+          }
+          for (int fp : wave) {  // `wave` is in descending child order
+            const PartInfo& P = h->parts[fp];
+            if (h->part_offset[P.comp] + P.parent != pf) continue;
+            ReduceChild& C = J.ch[J.nch++];
+            const size_t so = scr_of(fp, l, 0);
+            C.sdt = h->d_dt_sdt + so; C.ix = h->d_dt_ixT + so; C.iy = h->d_dt_iy + so;
+            const size_t po = L.cell_off * h->nplanes + (size_t)P.plane0 * HW;
+            C.ox = h->d_px + po; C.oy = h->d_py + po; C.ok = h->d_pk + po;
+            C.K = P.K;
+            for (int mm = 0; mm < P.K; ++mm) C.bias_off[mm] = P.biasid[mm];
+          }
+          red.push_back(J);
+          Wv.cells += (unsigned)HW;
+        }
+      }
+      for (int pf : parents)
+        for (int pm = 0; pm < h->parts[pf].K; ++pm) slot_init[h->parts[pf].slot[pm]] = 1;
+      Wv.njobs = (int)red.size() - Wv.job0;
+      R.waves.push_back(Wv);
+    }
     h->rl.push_back(R);
   }
   if ((rc = dev_upload(h, &h->d_dtmaps, maps))) return rc;
@@ -524,7 +569,8 @@ static int run_dp_min(pbd_handle* h) {
   for (auto& R : h->rl) {
     launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
     launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
-    launch_reduce(h->d_redjobs + R.red0, R.nred, R.red_cells, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
+    for (auto& Wv : R.waves)
+      launch_reduce(h->d_redjobs + Wv.job0, Wv.njobs, Wv.cells, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
   }
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
   launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
@@ -887,9 +933,11 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   HIPCHK(h, hipMalloc(&d_maps, sizeof(maps))); HIPCHK(h, hipMalloc(&d_groups, sizeof(groups)));
   HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size())); HIPCHK(h, hipMalloc(&d_job, sizeof(ReduceJob)));
   ReduceJob J{};
-  J.sdt = d_sdt; J.ixT = d_ixT; J.iy = d_iy; J.H = rows; J.W = cols; J.K = 1; J.L = 1;
-  J.bias_off[0] = (int)h->biasw.size();  // the trailing 0.0f
-  J.par_in[0] = d_zero; J.par_out[0] = d_out; J.ox[0] = d_ox; J.oy[0] = d_oy; J.ok[0] = d_ok; J.cell0 = 0;
+  J.H = rows; J.W = cols; J.L = 1; J.nch = 1; J.cell0 = 0;
+  J.par_in[0] = d_zero; J.par_out[0] = d_out;
+  J.ch[0].sdt = d_sdt; J.ch[0].ix = d_ixT; J.ch[0].iy = d_iy; J.ch[0].ox = d_ox; J.ch[0].oy = d_oy; J.ch[0].ok = d_ok;
+  J.ch[0].K = 1;
+  J.ch[0].bias_off[0] = (int)h->biasw.size();  // the trailing 0.0f
   HIPCHK(h, hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_groups, groups, sizeof(groups), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));

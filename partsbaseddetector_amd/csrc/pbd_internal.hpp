@@ -62,16 +62,21 @@ struct DtMap {       // one 1-D pass over one score map
 struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, nmb, pad; };  // stride: LDS elements per line (even); lpb: lines per block; nmb: max maps a block touches
 struct DtTask { int group, g0; };
 
-struct ReduceJob {   // one (level, child part): max over child mixtures for each parent mixture
+#define PBD_MAX_CH 8   // children of one parent folded into one reduce job
+struct ReduceChild {     // one child part's distance-transformed mixtures
   const float* sdt;      // [K][H][W] distance-transformed child scores
-  const int16_t* ixT;    // [K][H][W] x pointers (row-major)
+  const int16_t* ix;     // [K][H][W] x pointers (row-major)
   const int16_t* iy;     // [K][H][W] y pointers
-  int H, W, K, L;
-  int bias_off[PBD_MAX_MIX];       // biasw index of bias(mm)[0] for each child mixture mm (K<=8)
+  int16_t* ox; int16_t* oy; uint8_t* ok;  // output pointer planes of this child, [L][H][W]
+  int K, pad;
+  int bias_off[PBD_MAX_MIX];  // biasw index of bias(mm)[0] for each child mixture mm
+};
+struct ReduceJob {       // one (level, parent): fold the messages of nch children, in the reference's order
+  int H, W, L, nch;
+  unsigned cell0, pad;   // prefix of cells of this job within the launch
   const float* par_in[PBD_MAX_MIX];  // parent mixture m: current score (resp plane or acc slot)
   float* par_out[PBD_MAX_MIX];       // parent mixture m: acc slot
-  int16_t* ox[PBD_MAX_MIX]; int16_t* oy[PBD_MAX_MIX]; uint8_t* ok[PBD_MAX_MIX];  // output pointer planes
-  unsigned cell0;        // prefix of cells of this job within the launch
+  ReduceChild ch[PBD_MAX_CH];        // descending child index (src/DynamicProgram.cpp:95)
 };
 struct RootJob {
   const float* score[PBD_MAX_MIX]; // root mixture m current score
@@ -105,8 +110,8 @@ struct pbd_handle {
   pbd_options opt;
   int max_parts = 0, nslots = 0, nplanes = 0;
   std::vector<PartInfo> parts;                 // flat parts
-  std::vector<std::vector<int>> rounds;        // flat part ids per round
-  std::vector<std::vector<char>> first_msg;    // per round/part/parent-mixture: parent slot uninitialised
+  std::vector<std::vector<int>> rounds;        // flat part ids whose DT runs in round r
+  std::vector<std::vector<std::vector<int>>> red_rounds;  // [round][wave] -> flat child part ids reduced (grouped by parent at plan time)
   std::vector<int> comp_plane0;
   std::string err;
   int conv_mode = PBD_CONV_EXACT;
@@ -139,7 +144,8 @@ struct pbd_handle {
   // DP tables (all rounds back to back)
   DtMap* d_dtmaps = nullptr; DtGroup* d_dtgroups = nullptr; DtTask* d_dttasks = nullptr;
   ReduceJob* d_redjobs = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
-  struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks, red0, nred; unsigned red_cells; };
+  struct ReduceWave { int job0, njobs; unsigned cells; };
+  struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; std::vector<ReduceWave> waves; };
   size_t dt_lds = 0;                                 // dynamic LDS of every k_dt_pass launch
   std::vector<RoundLaunch> rl;
   int n_rootjobs = 0; unsigned root_cells = 0;
