@@ -287,3 +287,107 @@ def test_nms_map_matches_oracle(small_handle, orc):
     for (M, N, sz) in [(40, 50, 3), (17, 23, 1), (64, 64, 5), (9, 9, 10)]:
         a = rng.normal(size=(M, N)).astype(np.float32)
         np.testing.assert_array_equal(small_handle.nms_map(a, sz), orc.nms_map(a, sz))
+
+
+# ---------------------------------------------------------------- boundary behaviour
+def test_level_sharding_union_equals_full(gpu_required, orc):
+    """configs[3]-style level sharding: disjoint level ranges on separate handles reproduce the
+    full frame's candidates (levels are independent, src/DynamicProgram.cpp:83-87)."""
+    from partsbaseddetector_amd import parallel
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    im = make_image(0, 320, 240)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.5)
+    full = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    ref = full.detect(im)
+    g = full.geometry(320, 240)
+    cells = (g["cell_w"].astype(np.int64) * g["cell_h"]).tolist()
+    parts = []
+    for (b, e) in parallel.shard_levels_contiguous(cells, 3):
+        if e <= b:
+            continue
+        h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, level_begin=b, level_end=e)
+        parts.append(h.detect(im))
+        h.close()
+    merged = parallel.merge_candidates(parts)
+    full.close()
+    assert_candidates_equal(merged, ref)
+
+
+def test_device_resident_and_async_entry_points(gpu_required, orc):
+    import torch
+    m = make_tree_model([-1, 0, 0], 2, seed=6)
+    im = make_image(3, 200, 150)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.0)
+    ref = orc.detect(m, im)[:3]
+    d_im = torch.from_numpy(im).cuda()
+    torch.cuda.synchronize()
+    h1 = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    h2 = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    assert_candidates_equal(h1.detect_dev(d_im.data_ptr(), 200, 150, 3), ref)
+    h1.enqueue_dev(d_im.data_ptr(), 200, 150, 3)      # two frames in flight on two handles
+    h2.enqueue_dev(d_im.data_ptr(), 200, 150, 3)
+    with pytest.raises(capi.PbdError) as e:            # a handle holds one pending frame
+        h1.enqueue_dev(d_im.data_ptr(), 200, 150, 3)
+    assert e.value.code == capi.PBD_ERR_STATE
+    assert_candidates_equal(h1.collect(), ref)
+    assert_candidates_equal(h2.collect(), ref)
+    # geometry change re-plans the frame
+    im2 = make_image(4, 160, 120)
+    assert_candidates_equal(h1.detect(im2), orc.detect(m, im2)[:3])
+    h1.close(); h2.close()
+
+
+def test_stage_order_and_argument_errors(gpu_required):
+    m = make_tree_model([-1, 0], 1, seed=2)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    with pytest.raises(capi.PbdError) as e:
+        h.pdf()                                        # pdf() before pyramid()
+    assert e.value.code == capi.PBD_ERR_STATE
+    with pytest.raises(capi.PbdError) as e:
+        h.detect(np.zeros((30, 40, 3), np.uint8))      # fewer than `interval` pyramid levels
+    assert e.value.code == capi.PBD_ERR_ARG
+    with pytest.raises(capi.PbdError) as e:
+        h.detect(np.zeros((200, 200, 4), np.uint8))    # 4 channels: CV_StsUnsupportedFormat
+    assert e.value.code == capi.PBD_ERR_UNSUPPORTED
+    h.begin_frame(200, 150, 3)
+    with pytest.raises(capi.PbdError) as e:
+        h.dp_min()                                     # min() before pdf()
+    assert e.value.code == capi.PBD_ERR_STATE
+    h.close()
+
+
+def test_detector_class_stagewise_equals_fused(gpu_required, orc):
+    """The reference's call sequence (pyramid -> pdf -> min -> argmin, src/PartsBasedDetector.cpp:73-89)
+    through the mirror classes gives the fused detect() result."""
+    from partsbaseddetector_amd import PartsBasedDetector
+    m = make_tree_model([-1, 0, 1], 2, seed=7)
+    im = make_image(5, 180, 140)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.0)
+    det = PartsBasedDetector(conv_mode=capi.PBD_CONV_EXACT)
+    det.distributeModel(m)
+    fused = det.detect(im)
+    pyr = det.features_.pyramid(im)
+    assert len(pyr) == det.features_.nscales() == len(det.features_.scales())
+    resp = det.convolution_engine_.pdf()
+    assert len(resp) == len(pyr) and len(resp[0]) == len(m.filtersw)
+    Ix, Iy, Ik, rootv, rooti = det.dp_.min()
+    assert rootv[0][0].shape == resp[0][0].shape
+    staged = det.dp_.argmin()
+    assert len(staged) == len(fused) > 0
+    for a, b in zip(staged, fused):
+        assert a.score() == b.score() and np.array_equal(a.parts, b.parts) and a.component == b.component
+
+
+def test_person_1080p_plan_and_run(gpu_required):
+    """configs[3] geometry: 1920x1080, 58 levels, level 0 is 478 cells wide (DT lines of 478)."""
+    m = make_person_model()
+    m.thresh = 3.0e38
+    h = capi.Handle(m)
+    im = make_image(0, 1920, 1080)
+    heads, _, _ = h.detect(im)
+    g = h.geometry(1920, 1080)
+    assert g["nlevels"] == 58 and g["cell_w"][0] == 478 and len(heads) == 0
+    h._geo = g
+    rv, _ = h.root(0, 0)
+    assert np.isfinite(rv).all()
+    h.close()
