@@ -204,6 +204,9 @@ int pbd_get_work(const pbd_handle* h, double work[6]);
 /* average GPU ms of the DP-min kernels alone over frames since the last reset
  * (HIP events on the handle's stream around the DP stage)                    */
 int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes);
+/* debug: 100 MHz wall-clock stamps of block 0 of the last distance-transform launch at its six
+ * phase boundaries (setup, line load, envelope scan, read-out, pointer store, end)            */
+int pbd_debug_dt_stamps(unsigned long long out[8]);
 
 #ifdef __cplusplus
 }

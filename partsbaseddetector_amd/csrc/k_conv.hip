@@ -169,101 +169,73 @@ void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels
 }
 
 // ---------------------------------------------------------------------------
-// fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32).
-// Workgroup = 256 threads = 4 waves, tile = 16x16 cells (M = 256) x NB_N
-// filters.  Wave w owns cell rows 4w..4w+3 (M = 64 = two 32-row MFMA tiles:
-// 2 cell rows x 16 cols each) and all NT n-tiles of 32 filters:
-// acc[2][NT] f32x16.  K loop: tap-major, channel-minor; per k-step (2
-// channels of one tap): 2 A reads (ds_read_b32, cell stride 33 -> conflict
-// free), NT B reads ([k][n] row, n contiguous), 2*NT MFMAs.
-// B (weights) for the current tap (32 x nfpad floats) is staged in LDS.
+// fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32), M = cells, N = filters, K = kh*kw*32.
+// Workgroup = 256 threads = 4 waves: tile = 16x16 cells (M = 256) x ONE 32-filter n-tile; the
+// grid is (tiles, nfpad/32), so work units are small (3 resident per CU, ~12 per CU for the person
+// model) and the tail of the launch is short.  Wave w owns cell rows 4w..4w+3 = two 32-row MFMA
+// M-tiles (2 cell rows x 16 cols each): 2 accumulators of 16 VGPRs.
+//  * A (features): the 20x20-cell tile with halo is staged once in LDS, cell stride 33 floats, so
+//    the 32 lanes of an M-tile read conflict-free; lane l holds A[i = l&31][k = l>>5].
+//  * B (weights, [tap][channel][nfpad]): 512 KB for the whole bank, L2-resident.  A lane's B
+//    operand is ONE float per MFMA (B[k = l>>5][j = l&31]); the 16 values of a tap are loaded
+//    straight from L2 into registers a whole tap (2048 MFMA cycles) ahead of use — no weight LDS,
+//    no barrier anywhere in the K loop.
+//  * K order: tap-major, channel-minor; the accumulation is a k-ordered fp32 fma chain.
 // ---------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KH, int KW, int NT>
+template <int KH, int KW>
 __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ tiles,
                                                    const LevelDev* __restrict__ levels,
                                                    const float* __restrict__ feat, const float* __restrict__ wT,
                                                    float* __restrict__ resp, int nf, int nfpad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TW = CT + KW - 1, TH = CT + KH - 1;
-  constexpr int NW = NT * 32;               // filters handled by this workgroup
+  constexpr int TW = CT + KW - 1;
   float* ft = (float*)smem;                 // [TH][TW][CSTR]
-  float* wb = ft + TH * TW * CSTR;          // [2][32][NW] double-buffered weights of one tap
   const ConvTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const int H = lv.ch, W = lv.cw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nbase = blockIdx.y * NW;
+  const int nbase = blockIdx.y * 32;
   const float* F = feat + lv.cell_off * PBD_FLEN;
+  // A operand: lane l holds A[i = l&31][k = l>>5]; M-tile m of this wave: cell rows 4*wave + 2*m + (ai>>4), col ai&15
+  const int ai = lane & 31, ak = lane >> 5;
+  // B operand: B[k = l>>5][j = l&31] -> wT[(tap*32 + c + ak)*nfpad + nbase + (l&31)]
+  const float* bsrc = wT + (size_t)ak * nfpad + nbase + (lane & 31);
+  float bcur[16], bnxt[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) bcur[u] = bsrc[(size_t)(2 * u) * nfpad];  // tap 0, issued before the tile staging
   stage_feature_tile<KH, KW>(ft, F, t.y0, t.x0, H, W, tid);
-  // weights of tap 0 -> wb[0]
-  // weights of one tap: [32 channels][NW filters]; loads are issued a whole tap ahead of their use
-  constexpr int NV = 32 * NW / 4, NBW = (NV + 255) / 256;
-  float4 wr[NBW];
-  auto load_w = [&](int tap) {
-    const float* src = wT + (size_t)tap * PBD_FLEN * nfpad + nbase;
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-      const int i = min(tid + j * 256, NV - 1);
-      const int c = i / (NW / 4), n4 = i - c * (NW / 4);
-      wr[j] = *(const float4*)(src + (size_t)c * nfpad + n4 * 4);
-    }
-  };
-  auto store_w = [&](int buf) {
-    float* dst = wb + buf * 32 * NW;
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-      const int i = tid + j * 256;
-      if (i < NV) {
-        const int c = i / (NW / 4), n4 = i - c * (NW / 4);
-        *(float4*)(dst + c * NW + n4 * 4) = wr[j];
-      }
-    }
-  };
-  load_w(0);
-  store_w(0);
   __syncthreads();
 
-  f32x16 acc[2][NT];
+  f32x16 acc0, acc1;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-  // A operand of v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5]
-  const int ai = lane & 31, ak = lane >> 5;
-  // M-tile m of this wave: cell rows 4*wave + 2*m + (ai>>4), col ai&15
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
   const int arow0 = 4 * wave + (ai >> 4), acol = ai & 15;
-  const float* abase0 = ft + ((arow0)*TW + acol) * CSTR + ak;
+  const float* abase0 = ft + (arow0 * TW + acol) * CSTR + ak;
   const float* abase1 = ft + ((arow0 + 2) * TW + acol) * CSTR + ak;
-  const int bj = lane & 31;  // B[k = l>>5][j = l&31]
 
   for (int tap = 0; tap < KH * KW; ++tap) {
-    const int buf = tap & 1;
-    if (tap + 1 < KH * KW) load_w(tap + 1);
+    const int tn = min(tap + 1, KH * KW - 1);
+    const float* bs = bsrc + (size_t)tn * PBD_FLEN * nfpad;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bnxt[u] = bs[(size_t)(2 * u) * nfpad];   // next tap's weights, in flight during this tap
     const int ti = tap / KW, tj = tap - ti * KW;
     const float* a0 = abase0 + (ti * TW + tj) * CSTR;
     const float* a1 = abase1 + (ti * TW + tj) * CSTR;
-    const float* b = wb + buf * 32 * NW + ak * NW + bj;
-#pragma unroll 4
-    for (int c = 0; c < 32; c += 2) {
-      const float av0 = a0[c], av1 = a1[c];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float bv = b[c * NW + n * 32];
-        acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc[0][n], 0, 0, 0);
-        acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv, acc[1][n], 0, 0, 0);
-      }
+    for (int u = 0; u < 16; ++u) {
+      const float av0 = a0[2 * u], av1 = a1[2 * u];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bcur[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bcur[u], acc1, 0, 0, 0);
     }
-    if (tap + 1 < KH * KW) store_w(buf ^ 1);
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bcur[u] = bnxt[u];
   }
+  __syncthreads();  // all waves are done reading the feature tile: reuse it for the epilogue
   // Epilogue.  C/D layout 32x32: col(j) = lane&31, row(i) = (reg&3) + 8*(reg>>2) + 4*(lane>>5),
   // i.e. a lane holds ONE filter and 16 scattered cells: storing that directly would be 4-byte
-  // scatters across 32 response planes.  Transpose each 64-cell x 32-filter slab through the
+  // scatters across 32 response planes.  Transpose the wave's 64-cell x 32-filter slab through the
   // (now free) feature-tile LDS so lanes run along cells: every store instruction then writes
   // four 64-B row segments of one plane.
   float* R = resp + lv.cell_off * nf;
@@ -271,20 +243,15 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ 
   const int py = t.y0 + 4 * wave + (lane >> 4), pxx = t.x0 + (lane & 15);
   const bool pvalid = (py < H && pxx < W);
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        tr[(lane & 31) * 65 + m * 32 + i] = acc[m][n][r];
-      }
-    __syncthreads();
-    for (int j = 0; j < 32; ++j) {
-      const int fn = nbase + n * 32 + j;
-      if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[j * 65 + lane];
-    }
-    __syncthreads();
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    tr[(lane & 31) * 65 + i] = acc0[r];
+    tr[(lane & 31) * 65 + 32 + i] = acc1[r];
+  }
+  __syncthreads();
+  for (int j = 0; j < 32; ++j) {
+    const int fn = nbase + j;
+    if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[j * 65 + lane];
   }
 }
 
@@ -292,10 +259,9 @@ void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels,
                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
   if (ntiles <= 0) return;
   if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, kh, kw, s); return; }
-  constexpr int NT = 5;  // 160 filters per workgroup (person model: 156 -> one N pass)
-  const size_t lds = sizeof(float) * ((CT + 4) * (CT + 4) * CSTR + 2 * 32 * NT * 32);
+  const size_t lds = sizeof(float) * (CT + 4) * (CT + 4) * CSTR;
   static bool cfg = false;
-  if (!cfg) { hipFuncSetAttribute((const void*)k_conv_mfma<5, 5, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
-  dim3 grid(ntiles, (nfpad + NT * 32 - 1) / (NT * 32));
-  hipLaunchKernelGGL((k_conv_mfma<5, 5, NT>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
+  if (!cfg) { hipFuncSetAttribute((const void*)k_conv_mfma<5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+  dim3 grid(ntiles, (nf + 31) / 32);
+  hipLaunchKernelGGL((k_conv_mfma<5, 5>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
 }

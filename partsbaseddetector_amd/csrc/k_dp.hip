@@ -140,8 +140,8 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
   // `s <= z[k]` comparisons in order.  A single in-order wave exposes every latency, so the body
   // is branch-free and keeps all LDS operands one iteration ahead:
   //   * stack top (v,y,z) and the entry below it live in registers;
-  //   * the entry two below, the reciprocal needed if this step pushes (R[dx+1]) and the line
-  //     element two ahead are loaded at the top of the iteration and consumed at its end;
+  //   * the entry two below, the reciprocal needed if this step pops (R[q - v_below]) and the
+  //     line element two ahead are loaded at the top of the iteration and consumed at its end;
   //   * the stack stores of a push are issued unconditionally to slot k+1 (dead when popping).
   if (lane < nl) {
     const int gi = t.g0 + lane;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
     int k = 0, q = 1, vk = 0, nv = 0;
     float zk = -INFINITY, nz = -INFINITY;
     double yk = (double)Yl[0], ny = 0.0;
-    double r_top = r1, r_nxt = r1;
+    double r_top = r1;
     Vl[0] = 0;
     Zl[0] = -INFINITY;
     float yq_f = Yl[min(1, len - 1)], yq1_f = Yl[min(2, len - 1)];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
       const int pv = Vl[k2];
       const float py_f = Yl[k2], pz = Zl[k2];
       const int dx = q - vk;
-      const double rn_push = Rl[min(dx + 1, len - 1)];
+      const double r_nxt = Rl[max(q - nv, 0)];  // reciprocal for the entry below the top (used if this step pops)
       const float yq2_f = Yl[min(q + 2, len - 1)];
       // intersection with the stack top (same fp64 operations as dt_isect_fast)
       const double yq = (double)yq_f;
@@ -184,8 +184,6 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
       const bool pop = (s <= zk) && (k > 0);  // :162
       // push stores (:166-169); slot k+1 is dead if this step pops
       Vl[k + 1] = (unsigned short)q; Yl[k + 1] = yq_f; Zl[k + 1] = s;
-      // reciprocal for the entry two below, needed only after a second consecutive pop
-      const double rn_pop = Rl[max(q - pv, 0)];
       // state update, selects only
       const int vk_o = vk; const double yk_o = yk; const float zk_o = zk;
       k = pop ? k - 1 : k + 1;
@@ -196,7 +194,6 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
       nv = pop ? pv : vk_o;
       ny = pop ? (double)py_f : yk_o;
       nz = pop ? pz : zk_o;
-      r_nxt = pop ? rn_pop : rn_push;
       yq_f = pop ? yq_f : yq1_f;
       yq1_f = pop ? yq1_f : yq2_f;
       q = pop ? q : q + 1;
@@ -276,17 +273,19 @@ void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, cons
 // ---------------------------------------------------------------------------
 // reduce over child mixtures, one thread per cell of one (level, child part)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jobs, int njobs,
+__global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jobs, const ReduceBlock* __restrict__ blocks,
                                                 const float* __restrict__ biasw, int correct_ptr) {
-  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
-  // find the job containing this cell (jobs sorted by cell0; njobs is small): binary search
-  int lo = 0, hi = njobs - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].cell0 <= gid) lo = mid; else hi = mid - 1;
+  // block -> (job, first cell) comes from a host-built table; the job descriptor (pointers, bias
+  // offsets) is staged in LDS once per block instead of being chased through global memory.
+  __shared__ ReduceJob J;
+  const ReduceBlock rb = blocks[blockIdx.x];
+  {
+    const int* src = (const int*)(jobs + rb.job);
+    int* dst = (int*)&J;
+    for (int i = threadIdx.x; i < (int)(sizeof(ReduceJob) / 4); i += 256) dst[i] = src[i];
   }
-  const ReduceJob& J = jobs[lo];
-  const unsigned cell = gid - J.cell0;
+  __syncthreads();
+  const unsigned cell = rb.cell0 + threadIdx.x;
   const int H = J.H, W = J.W, L = J.L;
   const unsigned HW = (unsigned)H * W;
   if (cell >= HW) return;
@@ -325,10 +324,10 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
   }
 }
 
-void launch_reduce(const ReduceJob* jobs, int njobs, unsigned total_cells, const float* biasw, int correct_ptr,
+void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
                    hipStream_t s) {
-  if (njobs <= 0 || total_cells == 0) return;
-  hipLaunchKernelGGL(k_reduce, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, biasw, correct_ptr);
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(k_reduce, dim3(nblocks), dim3(256), 0, s, jobs, blocks, biasw, correct_ptr);
 }
 
 // ---------------------------------------------------------------------------

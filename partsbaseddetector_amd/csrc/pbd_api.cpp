@@ -390,6 +390,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   std::vector<DtGroup> groups;
   std::vector<DtTask> tasks;
   std::vector<ReduceJob> red;
+  std::vector<ReduceBlock> redblk;
   h->rl.clear();
   std::vector<char> slot_init((size_t)h->nslots, 0);  // ncscores[fid].empty() emulation (same for every level)
   // scratch offset of (part, level): parts in flat order, levels inside
@@ -443,7 +444,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     tasks.insert(tasks.end(), yt.begin(), yt.end());
     // reduce waves of this round
     for (const std::vector<int>& wave : h->red_rounds[r]) {
-      pbd_handle::ReduceWave Wv{(int)red.size(), 0, 0};
+      pbd_handle::ReduceWave Wv{(int)redblk.size(), 0};
       std::vector<int> parents;  // distinct parents, in first-appearance order
       for (int fp : wave) {
         const int pf = h->part_offset[h->parts[fp].comp] + h->parts[fp].parent;
@@ -456,7 +457,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
         for (int pf : parents) {
           const PartInfo& Par = h->parts[pf];
           ReduceJob J{};
-          J.H = L.ch; J.W = L.cw; J.L = Par.K; J.cell0 = Wv.cells;
+          J.H = L.ch; J.W = L.cw; J.L = Par.K;
           for (int pm = 0; pm < Par.K; ++pm) {
             float* accp = h->d_acc + L.cell_off * h->nslots + (size_t)Par.slot[pm] * HW;
             J.par_in[pm] = slot_init[Par.slot[pm]] ? accp : h->d_resp + L.cell_off * m.nfilters + (size_t)Par.filterid[pm] * HW;
@@ -473,13 +474,13 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
             C.K = P.K;
             for (int mm = 0; mm < P.K; ++mm) C.bias_off[mm] = P.biasid[mm];
           }
+          for (unsigned c0 = 0; c0 < (unsigned)HW; c0 += 256) redblk.push_back(ReduceBlock{(int)red.size(), c0});
           red.push_back(J);
-          Wv.cells += (unsigned)HW;
         }
       }
       for (int pf : parents)
         for (int pm = 0; pm < h->parts[pf].K; ++pm) slot_init[h->parts[pf].slot[pm]] = 1;
-      Wv.njobs = (int)red.size() - Wv.job0;
+      Wv.nblks = (int)redblk.size() - Wv.blk0;
       R.waves.push_back(Wv);
     }
     h->rl.push_back(R);
@@ -488,6 +489,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   if ((rc = dev_upload(h, &h->d_dtgroups, groups))) return rc;
   if ((rc = dev_upload(h, &h->d_dttasks, tasks))) return rc;
   if ((rc = dev_upload(h, &h->d_redjobs, red))) return rc;
+  if ((rc = dev_upload(h, &h->d_redblocks, redblk))) return rc;
 
   // root jobs + backtracking info
   std::vector<RootJob> rj;
@@ -570,7 +572,7 @@ static int run_dp_min(pbd_handle* h) {
     launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
     launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
     for (auto& Wv : R.waves)
-      launch_reduce(h->d_redjobs + Wv.job0, Wv.njobs, Wv.cells, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
+      launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
   }
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
   launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
@@ -929,11 +931,15 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   for (int g0 = 0; g0 < rows; g0 += groups[0].lpb) tasks.push_back(DtTask{0, g0});
   const int nx = (int)tasks.size();
   for (int g0 = 0; g0 < cols; g0 += groups[1].lpb) tasks.push_back(DtTask{1, g0});
-  DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks; ReduceJob* d_job;
+  DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks; ReduceJob* d_job; ReduceBlock* d_rblk;
+  std::vector<ReduceBlock> rblk;
+  for (unsigned c0 = 0; c0 < (unsigned)HW; c0 += 256) rblk.push_back(ReduceBlock{0, c0});
+  HIPCHK(h, hipMalloc(&d_rblk, sizeof(ReduceBlock) * rblk.size()));
+  HIPCHK(h, hipMemcpyAsync(d_rblk, rblk.data(), sizeof(ReduceBlock) * rblk.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMalloc(&d_maps, sizeof(maps))); HIPCHK(h, hipMalloc(&d_groups, sizeof(groups)));
   HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size())); HIPCHK(h, hipMalloc(&d_job, sizeof(ReduceJob)));
   ReduceJob J{};
-  J.H = rows; J.W = cols; J.L = 1; J.nch = 1; J.cell0 = 0;
+  J.H = rows; J.W = cols; J.L = 1; J.nch = 1;
   J.par_in[0] = d_zero; J.par_out[0] = d_out;
   J.ch[0].sdt = d_sdt; J.ch[0].ix = d_ixT; J.ch[0].iy = d_iy; J.ch[0].ox = d_ox; J.ch[0].oy = d_oy; J.ch[0].ok = d_ok;
   J.ch[0].K = 1;
@@ -945,7 +951,7 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
   launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, h->stream);
   launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, h->stream);
-  launch_reduce(d_job, 1, (unsigned)HW, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
+  launch_reduce(d_job, d_rblk, (int)rblk.size(), h->d_biasw, h->opt.dt_correct_ptr, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_out, HW * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(hx.data(), d_ox, HW * 2, hipMemcpyDeviceToHost, h->stream));
@@ -953,7 +959,7 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (size_t i = 0; i < HW; ++i) { if (ix) ix[i] = hx[i]; if (iy) iy[i] = hy[i]; }
   hipFree(d_in); hipFree(d_tmp); hipFree(d_sdt); hipFree(d_zero); hipFree(d_out); hipFree(d_ixT); hipFree(d_iy);
-  hipFree(d_ox); hipFree(d_oy); hipFree(d_ok); hipFree(d_maps); hipFree(d_groups); hipFree(d_tasks); hipFree(d_job);
+  hipFree(d_ox); hipFree(d_oy); hipFree(d_ok); hipFree(d_rblk); hipFree(d_maps); hipFree(d_groups); hipFree(d_tasks); hipFree(d_job);
   return PBD_OK;
 }
 

@@ -73,11 +73,11 @@ struct ReduceChild {     // one child part's distance-transformed mixtures
 };
 struct ReduceJob {       // one (level, parent): fold the messages of nch children, in the reference's order
   int H, W, L, nch;
-  unsigned cell0, pad;   // prefix of cells of this job within the launch
   const float* par_in[PBD_MAX_MIX];  // parent mixture m: current score (resp plane or acc slot)
   float* par_out[PBD_MAX_MIX];       // parent mixture m: acc slot
   ReduceChild ch[PBD_MAX_CH];        // descending child index (src/DynamicProgram.cpp:95)
 };
+struct ReduceBlock { int job; unsigned cell0; };  // one 256-thread block of k_reduce
 struct RootJob {
   const float* score[PBD_MAX_MIX]; // root mixture m current score
   float* rootv; int* rooti;
@@ -143,8 +143,8 @@ struct pbd_handle {
   ConvTile* d_conv_tiles = nullptr; int n_conv_tiles = 0;
   // DP tables (all rounds back to back)
   DtMap* d_dtmaps = nullptr; DtGroup* d_dtgroups = nullptr; DtTask* d_dttasks = nullptr;
-  ReduceJob* d_redjobs = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
-  struct ReduceWave { int job0, njobs; unsigned cells; };
+  ReduceJob* d_redjobs = nullptr; ReduceBlock* d_redblocks = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
+  struct ReduceWave { int blk0, nblks; };
   struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; std::vector<ReduceWave> waves; };
   size_t dt_lds = 0;                                 // dynamic LDS of every k_dt_pass launch
   std::vector<RoundLaunch> rl;
@@ -178,7 +178,7 @@ void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels,
 void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,
                     hipStream_t s);
 size_t dt_lds_bytes(int stride, int lpb, int nmb);
-void launch_reduce(const ReduceJob* jobs, int njobs, unsigned total_cells, const float* biasw, int correct_ptr,
+void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
                    hipStream_t s);
 void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
                  int capacity, hipStream_t s);

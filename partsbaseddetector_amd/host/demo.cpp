@@ -1,0 +1,54 @@
+// demo.cpp — the reference's canonical caller (src/demo.cpp:55-118) against the MI355X path:
+//   pbd_demo model.bin image.raw width height channels [stagewise]
+// deserialize -> distributeModel -> detect -> Candidate::sort, then prints the candidates (the
+// reference shows them in a window; here they go to stdout so tests can compare them).
+// `stagewise` walks pyramid -> pdf -> min -> argmin through the interface classes instead of the
+// fused detect() (src/PartsBasedDetector.cpp:73-89).
+#include <cstdio>
+#include <cstdlib>
+#include "pbd_host.hpp"
+using namespace pbd;
+
+int main(int argc, char** argv) {
+  if (argc != 6 && argc != 7) {
+    printf("Usage: pbd_demo model_file image.raw width height channels [stagewise]\n");
+    exit(-1);
+  }
+  BinaryModel model;
+  if (!model.deserialize(argv[1])) { printf("Error deserializing file\n"); exit(-3); }
+  const int w = atoi(argv[3]), h = atoi(argv[4]), cn = atoi(argv[5]);
+  Mat im(h, w, PBD_8U, cn);
+  FILE* f = fopen(argv[2], "rb");
+  if (!f || fread(im.ptr<uint8_t>(), 1, (size_t)w * h * cn, f) != (size_t)w * h * cn) {
+    printf("Image not found or invalid image format\n");
+    exit(-4);
+  }
+  fclose(f);
+  try {
+    PartsBasedDetector<float> pbd(0, PBD_CONV_EXACT);
+    pbd.distributeModel(model);
+    vectorCandidate candidates;
+    if (argc == 7) {
+      vectorMat pyramid;
+      pbd.features().pyramid(im, pyramid);
+      vector2DMat pdf, rootv, rooti;
+      pbd.convolutionEngine().pdf(pyramid, pdf);
+      pbd.dp().min(rootv, rooti, pbd.ncomponents(), pdf);
+      pbd.dp().argmin(candidates);
+    } else {
+      Mat depth;
+      pbd.detect(im, depth, candidates);
+    }
+    printf("Number of candidates: %ld\n", (long)candidates.size());
+    Candidate::sort(candidates);
+    for (const Candidate& c : candidates) {
+      printf("%.9g %d %d", c.score(), c.component(), c.level);
+      for (const Rect& r : c.parts()) printf(" %d,%d,%d,%d", r.x, r.y, r.width, r.height);
+      printf("\n");
+    }
+  } catch (const Exception& e) {
+    printf("error %d: %s\n", e.code, e.what());
+    return 1;
+  }
+  return 0;
+}

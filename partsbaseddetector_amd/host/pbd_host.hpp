@@ -1,0 +1,377 @@
+// pbd_host.hpp — C++ host side above the C ABI (include/pbd_c.h), mirroring the reference's
+// interfaces so code written against wg-perception/PartsBasedDetector reads the same:
+//
+//   reference                                              here (namespace pbd)
+//   IFeatures            include/IFeatures.hpp:49-73       pbd::IFeatures, pbd::HipHOGFeatures
+//   IConvolutionEngine   include/IConvolutionEngine.hpp:44-68  pbd::IConvolutionEngine, pbd::HipConvolutionEngine
+//   DynamicProgram<T>    include/DynamicProgram.hpp:61-77  pbd::DynamicProgram<T>
+//   PartsBasedDetector<T> include/PartsBasedDetector.hpp:152-175  pbd::PartsBasedDetector<T>
+//   Candidate            include/Candidate.hpp:56-111,277-304  pbd::Candidate
+//   Model                include/Model.hpp:49-122          pbd::Model (+ pbd::BinaryModel reader)
+//
+// The reference passes cv::Mat; OpenCV is not a dependency of this library, so a minimal dense
+// matrix (pbd::Mat: rows, cols, channels, 8U/32S/32F) carries the same data.  The OpenCV-typed
+// adaptors for dropping the engines into the reference tree itself are in INTEGRATION.md.
+// All numerics run in libpbd_hip.so; this header only marshals.  T = float.
+#ifndef PBD_HOST_HPP_
+#define PBD_HOST_HPP_
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/pbd_c.h"
+
+namespace pbd {
+
+enum { PBD_8U = 0, PBD_32S = 4, PBD_32F = 5 };  // depth codes (numerically OpenCV's CV_8U/32S/32F)
+
+class Exception : public std::runtime_error {   // plays the role of cv::Exception
+ public:
+  int code;
+  Exception(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+class Mat {
+ public:
+  int rows = 0, cols = 0;
+  Mat() {}
+  Mat(int r, int c, int depth, int cn = 1) { create(r, c, depth, cn); }
+  void create(int r, int c, int depth, int cn = 1) {
+    rows = r; cols = c; depth_ = depth; cn_ = cn;
+    buf_.assign((size_t)r * c * cn * elem1(), 0);
+  }
+  bool empty() const { return buf_.empty(); }
+  int depth() const { return depth_; }
+  int channels() const { return cn_; }
+  size_t elem1() const { return depth_ == PBD_8U ? 1 : 4; }
+  size_t step() const { return (size_t)cols * cn_ * elem1(); }
+  template <typename T> T* ptr(int r = 0) { return (T*)(buf_.data() + (size_t)r * step()); }
+  template <typename T> const T* ptr(int r = 0) const { return (const T*)(buf_.data() + (size_t)r * step()); }
+  template <typename T> T& at(int r, int c) { return ptr<T>(r)[c]; }
+  template <typename T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
+ private:
+  int depth_ = PBD_8U, cn_ = 1;
+  std::vector<uint8_t> buf_;
+};
+
+struct Rect { int x, y, width, height; };
+struct Point { int x, y; };
+typedef std::vector<int> vectori;
+typedef std::vector<float> vectorf;
+typedef std::vector<Mat> vectorMat;
+typedef std::vector<vectorMat> vector2DMat;
+typedef std::vector<vector2DMat> vector3DMat;
+typedef std::vector<vector3DMat> vector4DMat;
+typedef std::vector<vectori> vector2Di;
+typedef std::vector<vector2Di> vector3Di;
+typedef std::vector<vectorf> vector2Df;
+
+// ---- include/Candidate.hpp:56-111 ---------------------------------------------------------
+class Candidate {
+  std::vector<Rect> parts_;
+  vectorf confidence_;
+  int component_ = 0;
+ public:
+  int level = -1;                        // extra: pyramid level of the root
+  std::vector<int> locs;                 // extra: (x, y, mixture) per part, in cells
+  const std::vector<Rect>& parts() const { return parts_; }
+  const vectorf& confidence() const { return confidence_; }
+  void addPart(Rect r, float c) { parts_.push_back(r); confidence_.push_back(c); }
+  float score() const { return confidence_.empty() ? -std::numeric_limits<float>::infinity() : confidence_[0]; }
+  void setComponent(int c) { component_ = c; }
+  int component() const { return component_; }
+  Rect boundingBox() const {             // union of the part rects (:103-109)
+    Rect h = parts_[0];
+    for (const Rect& q : parts_) {
+      const int x1 = std::min(h.x, q.x), y1 = std::min(h.y, q.y);
+      h.width = std::max(h.x + h.width, q.x + q.width) - x1;
+      h.height = std::max(h.y + h.height, q.y + q.height) - y1;
+      h.x = x1; h.y = y1;
+    }
+    return h;
+  }
+  static void sort(std::vector<Candidate>& c);                                         // :97-99
+  static void nonMaximaSuppression(int im_w, int im_h, std::vector<Candidate>& c, float overlap = 0.0f);  // :277-304
+};
+typedef std::vector<Candidate> vectorCandidate;
+
+// ---- include/Model.hpp:49-122 ---------------------------------------------------------------
+class Model {
+ protected:
+  vectorMat filtersw_; vector2Df defw_; vectorf biasw_; std::vector<Point> anchors_;
+  vector3Di biasid_, filterid_, defid_; vector2Di parentid_;
+  std::string name_; int nscales_ = 0; float thresh_ = 0; int binsize_ = 0, flen_ = 0, norient_ = 0;
+ public:
+  virtual ~Model() {}
+  vectorMat& filters() { return filtersw_; }
+  vector2Df& def() { return defw_; }
+  vectorf& bias() { return biasw_; }
+  std::vector<Point>& anchors() { return anchors_; }
+  vector3Di& filterid() { return filterid_; }
+  vector3Di& biasid() { return biasid_; }
+  vector3Di& defid() { return defid_; }
+  vector2Di& parentid() { return parentid_; }
+  std::string name() { return name_; }
+  float thresh() const { return thresh_; }
+  void setThresh(float t) { thresh_ = t; }
+  int binsize() const { return binsize_; }
+  int nscales() const { return nscales_; }
+  int flen() const { return flen_; }
+  int norient() const { return norient_; }
+  int ncomponents() const { return (int)filterid_.size(); }
+  virtual bool deserialize(const std::string& filename) = 0;
+};
+
+// Flat little-endian dump of the fields above (written by partsbaseddetector_amd.model.Model.save);
+// the reference's own formats (cv::FileStorage XML/YAML, .mat) are SURVEY §8(f) "next".
+class BinaryModel : public Model {
+  static bool rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
+ public:
+  bool deserialize(const std::string& filename) override {
+    FILE* f = fopen(filename.c_str(), "rb");
+    if (!f) return false;
+    int32_t hd[12];
+    char magic[8];
+    bool ok = rd(f, magic, 8) && !memcmp(magic, "PBDMODL1", 8) && rd(f, hd, sizeof(hd));
+    if (!ok) { fclose(f); return false; }
+    const int nf = hd[0], kh = hd[1], kw = hd[2];
+    flen_ = hd[3]; norient_ = hd[4]; binsize_ = hd[5]; nscales_ = hd[6];
+    const int ndefs = hd[7], nbias = hd[8], ncomp = hd[9];
+    ok = rd(f, &thresh_, 4);
+    filtersw_.resize(nf);
+    for (int n = 0; n < nf && ok; ++n) { filtersw_[n].create(kh, kw * flen_, PBD_32F); ok = rd(f, filtersw_[n].ptr<float>(), (size_t)kh * kw * flen_ * 4); }
+    defw_.assign(ndefs, vectorf(4)); anchors_.resize(ndefs);
+    for (int d = 0; d < ndefs && ok; ++d) ok = rd(f, defw_[d].data(), 16);
+    for (int d = 0; d < ndefs && ok; ++d) { int32_t a[2]; ok = rd(f, a, 8); anchors_[d] = Point{a[0], a[1]}; }
+    biasw_.resize(nbias);
+    ok = ok && rd(f, biasw_.data(), (size_t)nbias * 4);
+    filterid_.resize(ncomp); biasid_.resize(ncomp); defid_.resize(ncomp); parentid_.resize(ncomp);
+    for (int c = 0; c < ncomp && ok; ++c) {
+      int32_t np; ok = rd(f, &np, 4);
+      filterid_[c].resize(np); biasid_[c].resize(np); defid_[c].resize(np); parentid_[c].resize(np);
+      for (int p = 0; p < np && ok; ++p) {
+        int32_t pk[2]; ok = rd(f, pk, 8);
+        parentid_[c][p] = pk[0];
+        filterid_[c][p].resize(pk[1]); biasid_[c][p].resize(pk[1]); defid_[c][p].resize(pk[1]);
+        ok = ok && rd(f, filterid_[c][p].data(), 4 * pk[1]) && rd(f, defid_[c][p].data(), 4 * pk[1]) && rd(f, biasid_[c][p].data(), 4 * pk[1]);
+      }
+    }
+    name_ = filename;
+    fclose(f);
+    return ok;
+  }
+};
+
+// ---- shared device handle -------------------------------------------------------------------
+class Device {
+ public:
+  pbd_handle* h = nullptr;
+  std::vector<float> filters, defw, biasw;
+  std::vector<int32_t> anchors, part_offset, parentid, mix_offset, filterid, defid, biasid;
+  Device(Model& m, int device, int conv_mode) {
+    pbd_model_desc d{};
+    const int kh = m.filters()[0].rows, kw = m.filters()[0].cols / m.flen();
+    for (Mat& f : m.filters()) filters.insert(filters.end(), f.ptr<float>(), f.ptr<float>() + (size_t)kh * kw * m.flen());
+    for (vectorf& w : m.def()) defw.insert(defw.end(), w.begin(), w.begin() + 4);
+    for (Point& a : m.anchors()) { anchors.push_back(a.x); anchors.push_back(a.y); }
+    biasw = m.bias();
+    part_offset.push_back(0); mix_offset.push_back(0);
+    for (size_t c = 0; c < m.filterid().size(); ++c) {
+      for (size_t p = 0; p < m.filterid()[c].size(); ++p) {
+        parentid.push_back(p ? m.parentid()[c][p] : -1);
+        for (size_t k = 0; k < m.filterid()[c][p].size(); ++k) {
+          filterid.push_back(m.filterid()[c][p][k]);
+          defid.push_back(p ? m.defid()[c][p][k] : 0);
+          biasid.push_back(m.biasid()[c][p][k]);
+        }
+        mix_offset.push_back((int32_t)filterid.size());
+      }
+      part_offset.push_back((int32_t)parentid.size());
+    }
+    d.nfilters = (int)m.filters().size(); d.kh = kh; d.kw = kw; d.flen = m.flen(); d.norient = m.norient();
+    d.sbin = m.binsize(); d.interval = m.nscales(); d.thresh = m.thresh();
+    d.filters = filters.data(); d.ndefs = (int)m.def().size(); d.defw = defw.data(); d.anchors = anchors.data();
+    d.nbias = (int)biasw.size(); d.biasw = biasw.data(); d.ncomponents = (int)m.filterid().size();
+    d.part_offset = part_offset.data(); d.parentid = parentid.data(); d.mix_offset = mix_offset.data();
+    d.filterid = filterid.data(); d.defid = defid.data(); d.biasid = biasid.data();
+    pbd_options opt{};
+    opt.device = device; opt.conv_mode = conv_mode;
+    const int rc = pbd_create(&d, &opt, &h);
+    if (rc != PBD_OK) { std::string msg = h ? pbd_last_error(h) : "pbd_create failed"; if (h) pbd_destroy(h); h = nullptr; throw Exception(rc, msg); }
+  }
+  ~Device() { if (h) pbd_destroy(h); }
+  void check(int rc) const { if (rc != PBD_OK) throw Exception(rc, pbd_last_error(h)); }
+};
+
+// ---- include/IFeatures.hpp:49-73 --------------------------------------------------------------
+class IFeatures {
+ public:
+  virtual ~IFeatures() {}
+  virtual size_t binsize() const = 0;
+  virtual size_t nscales() const = 0;
+  virtual vectorf scales() const = 0;
+  virtual void pyramid(const Mat& im, vectorMat& pyrafeatures) = 0;
+};
+
+class HipHOGFeatures : public IFeatures {          // include/HOGFeatures.hpp:52-88
+  std::shared_ptr<Device> dev_; size_t binsize_, nscales_; vectorf scales_;
+ public:
+  HipHOGFeatures(std::shared_ptr<Device> d, size_t binsize, size_t nscales) : dev_(d), binsize_(binsize), nscales_(nscales) {}
+  size_t binsize() const override { return binsize_; }
+  size_t nscales() const override { return nscales_; }
+  vectorf scales() const override { return scales_; }
+  void pyramid(const Mat& im, vectorMat& pyrafeatures) override {   // src/HOGFeatures.cpp:95-151
+    if (im.depth() != PBD_8U) throw Exception(PBD_ERR_UNSUPPORTED, "Unsupported image type");  // :141-145
+    dev_->check(pbd_pyramid_u8(dev_->h, im.ptr<uint8_t>(), im.cols, im.rows, im.channels(), (int)im.step()));
+    int n = 0;
+    dev_->check(pbd_pyramid_geometry(dev_->h, im.cols, im.rows, &n, 0, 0, 0, 0, 0));
+    std::vector<int32_t> cw(n), ch(n);
+    scales_.resize(n); nscales_ = n;
+    dev_->check(pbd_pyramid_geometry(dev_->h, im.cols, im.rows, &n, 0, 0, cw.data(), ch.data(), scales_.data()));
+    pyrafeatures.clear(); pyrafeatures.resize(n);
+    for (int l = 0; l < n; ++l) {
+      pyrafeatures[l].create(ch[l], cw[l] * 32, PBD_32F);
+      if (ch[l] > 0 && cw[l] > 0) dev_->check(pbd_get_level_features(dev_->h, l, pyrafeatures[l].ptr<float>()));
+    }
+  }
+};
+
+// ---- include/IConvolutionEngine.hpp:44-68 -------------------------------------------------------
+class IConvolutionEngine {
+ public:
+  virtual ~IConvolutionEngine() {}
+  virtual void pdf(const vectorMat& features, vector2DMat& responses) = 0;
+  virtual void setFilters(const vectorMat& filters) = 0;
+};
+
+class HipConvolutionEngine : public IConvolutionEngine {   // include/SpatialConvolutionEngine.hpp:44-58
+  std::shared_ptr<Device> dev_; size_t nfilters_ = 0;
+ public:
+  explicit HipConvolutionEngine(std::shared_ptr<Device> d) : dev_(d) {}
+  void setFilters(const vectorMat& filters) override { nfilters_ = filters.size(); }  // uploaded by pbd_create
+  void pdf(const vectorMat& features, vector2DMat& responses) override {  // src/SpatialConvolutionEngine.cpp:106-124
+    dev_->check(pbd_pdf(dev_->h));                 // consumes the pyramid resident on the device
+    responses.assign(features.size(), vectorMat(nfilters_));
+    for (size_t l = 0; l < features.size(); ++l)
+      for (size_t n = 0; n < nfilters_; ++n) {
+        responses[l][n].create(features[l].rows, features[l].cols / 32, PBD_32F);
+        if (!responses[l][n].empty()) dev_->check(pbd_get_level_response(dev_->h, (int)l, (int)n, responses[l][n].ptr<float>()));
+      }
+  }
+};
+
+// ---- include/DynamicProgram.hpp:61-77 ----------------------------------------------------------
+static inline void append_candidates(std::vector<Candidate>& out, const std::vector<pbd_candidate_head>& heads,
+                                     const std::vector<int32_t>& boxes, const std::vector<int32_t>& locs, int n, int mp) {
+  for (int i = 0; i < n; ++i) {                    // src/DynamicProgram.cpp:216-251 (appends)
+    Candidate c;
+    c.setComponent(heads[i].component);
+    c.level = heads[i].level;
+    for (int p = 0; p < heads[i].nparts; ++p) {
+      const int32_t* b = &boxes[((size_t)i * mp + p) * 4];
+      c.addPart(Rect{b[0], b[1], b[2], b[3]}, p == 0 ? heads[i].score : 0.0f);
+      for (int k = 0; k < 3; ++k) c.locs.push_back(locs[((size_t)i * mp + p) * 3 + k]);
+    }
+    out.push_back(c);
+  }
+}
+
+template <typename T>
+class DynamicProgram {
+  std::shared_ptr<Device> dev_;
+ public:
+  DynamicProgram() {}
+  explicit DynamicProgram(std::shared_ptr<Device> d) : dev_(d) {}
+  // min(parts, scores, Ix, Iy, Ik, rootv, rooti): the tables stay on the device; rootv/rooti are
+  // returned ([level][component]); pointer planes can be fetched with pbd_get_dp_pointers.
+  void min(vector2DMat& rootv, vector2DMat& rooti, int ncomponents, const vector2DMat& scores) {
+    dev_->check(pbd_dp_min(dev_->h));
+    rootv.assign(scores.size(), vectorMat(ncomponents));
+    rooti.assign(scores.size(), vectorMat(ncomponents));
+    for (size_t l = 0; l < scores.size(); ++l)
+      for (int c = 0; c < ncomponents; ++c) {
+        rootv[l][c].create(scores[l][0].rows, scores[l][0].cols, PBD_32F);
+        rooti[l][c].create(scores[l][0].rows, scores[l][0].cols, PBD_32S);
+        if (!rootv[l][c].empty()) dev_->check(pbd_get_root(dev_->h, (int)l, c, rootv[l][c].ptr<float>(), rooti[l][c].ptr<int32_t>()));
+      }
+  }
+  void argmin(vectorCandidate& candidates, int capacity = 4096) {
+    const int mp = pbd_max_parts(dev_->h);
+    std::vector<pbd_candidate_head> heads(capacity);
+    std::vector<int32_t> boxes((size_t)capacity * mp * 4), locs((size_t)capacity * mp * 3);
+    int n = 0;
+    dev_->check(pbd_dp_argmin(dev_->h, heads.data(), boxes.data(), locs.data(), capacity, &n));
+    append_candidates(candidates, heads, boxes, locs, n, mp);
+  }
+};
+
+// ---- include/PartsBasedDetector.hpp:152-175 ----------------------------------------------------
+template <typename T>
+class PartsBasedDetector {
+  std::string name_;
+  std::shared_ptr<Device> dev_;
+  std::unique_ptr<IFeatures> features_;
+  std::unique_ptr<IConvolutionEngine> convolution_engine_;
+  DynamicProgram<T> dp_;
+  int device_, conv_mode_, ncomponents_ = 0;
+ public:
+  explicit PartsBasedDetector(int device = 0, int conv_mode = PBD_CONV_AUTO) : device_(device), conv_mode_(conv_mode) {}
+  const std::string& name() const { return name_; }
+  IFeatures& features() { return *features_; }
+  IConvolutionEngine& convolutionEngine() { return *convolution_engine_; }
+  DynamicProgram<T>& dp() { return dp_; }
+  int ncomponents() const { return ncomponents_; }
+  void distributeModel(Model& model) {             // src/PartsBasedDetector.cpp:102-127
+    static_assert(sizeof(T) == sizeof(float), "T = float (double: SURVEY 8f)");
+    name_ = model.name();
+    ncomponents_ = model.ncomponents();
+    dev_ = std::make_shared<Device>(model, device_, conv_mode_);
+    features_.reset(new HipHOGFeatures(dev_, model.binsize(), model.nscales()));
+    convolution_engine_.reset(new HipConvolutionEngine(dev_));
+    convolution_engine_->setFilters(model.filters());
+    dp_ = DynamicProgram<T>(dev_);
+  }
+  void detect(const Mat& im, vectorCandidate& candidates) { detect(im, Mat(), candidates); }
+  // src/PartsBasedDetector.cpp:69-95: fused path, everything stays in HBM; `depth` ignored (:91-93)
+  void detect(const Mat& im, const Mat& /*depth*/, vectorCandidate& candidates) {
+    if (!dev_) throw Exception(PBD_ERR_STATE, "detect() before distributeModel()");
+    if (im.depth() != PBD_8U) throw Exception(PBD_ERR_UNSUPPORTED, "Unsupported image type");
+    const int cap = 4096, mp = pbd_max_parts(dev_->h);
+    std::vector<pbd_candidate_head> heads(cap);
+    std::vector<int32_t> boxes((size_t)cap * mp * 4), locs((size_t)cap * mp * 3);
+    int n = 0;
+    dev_->check(pbd_detect_u8(dev_->h, im.ptr<uint8_t>(), im.cols, im.rows, im.channels(), (int)im.step(),
+                              heads.data(), boxes.data(), locs.data(), cap, &n));
+    append_candidates(candidates, heads, boxes, locs, n, mp);
+  }
+};
+
+inline void Candidate::sort(std::vector<Candidate>& c) {
+  std::stable_sort(c.begin(), c.end(), [](const Candidate& a, const Candidate& b) { return a.score() > b.score(); });
+}
+inline void Candidate::nonMaximaSuppression(int im_w, int im_h, std::vector<Candidate>& c, float overlap) {
+  std::vector<uint8_t> scratch((size_t)im_w * im_h, 0);
+  size_t keep = 0;
+  for (size_t n = 0; n < c.size(); ++n) {
+    Rect b = c[n].boundingBox();
+    int x1 = std::max(b.x, 0), y1 = std::max(b.y, 0);
+    int w = std::min(b.x + b.width, im_w) - x1, h = std::min(b.y + b.height, im_h) - y1;
+    if (w <= 0 || h <= 0) x1 = y1 = w = h = 0;
+    double sum = 0;
+    for (int y = y1; y < y1 + h; ++y) for (int x = x1; x < x1 + w; ++x) sum += scratch[(size_t)y * im_w + x];
+    if (sum / (double)(w * h) > (double)overlap) continue;
+    for (int y = y1; y < y1 + h; ++y) memset(&scratch[(size_t)y * im_w + x1], 1, w);
+    if (keep != n) c[keep] = c[n];
+    keep++;
+  }
+  c.resize(keep);
+}
+
+}  // namespace pbd
+#endif  // PBD_HOST_HPP_

@@ -62,6 +62,33 @@ class Model:
     def max_parts(self) -> int:
         return max(self.nparts(c) for c in range(self.ncomponents))
 
+    def save(self, path: str) -> None:
+        """Flat little-endian dump read by pbd::BinaryModel (partsbaseddetector_amd/host/pbd_host.hpp)."""
+        import struct
+        kh = self.filtersw[0].shape[0]
+        kw = self.filtersw[0].shape[1] // self.flen
+        with open(path, "wb") as f:
+            f.write(b"PBDMODL1")
+            f.write(struct.pack("<12i", len(self.filtersw), kh, kw, self.flen, self.norient, self.sbin, self.interval,
+                                len(self.defw), len(self.biasw), self.ncomponents, 0, 0))
+            f.write(struct.pack("<f", float(np.float32(self.thresh))))
+            for w in self.filtersw:
+                f.write(np.ascontiguousarray(w, np.float32).tobytes())
+            f.write(np.ascontiguousarray(self.defw, np.float32).tobytes())
+            f.write(np.ascontiguousarray(self.anchors, np.int32).tobytes())
+            f.write(np.ascontiguousarray(self.biasw, np.float32).tobytes())
+            for c in range(self.ncomponents):
+                f.write(struct.pack("<i", self.nparts(c)))
+                for p in range(self.nparts(c)):
+                    k = len(self.filterid[c][p])
+                    d = (list(self.defid[c][p]) + [0] * k)[:k] if p > 0 else [0] * k
+                    b = list(self.biasid[c][p])
+                    b = (b + [b[0] if b else 0] * k)[:k]
+                    f.write(struct.pack("<2i", self.parentid[c][p] if p > 0 else -1, k))
+                    f.write(np.asarray(self.filterid[c][p], np.int32).tobytes())
+                    f.write(np.asarray(d, np.int32).tobytes())
+                    f.write(np.asarray(b, np.int32).tobytes())
+
     def to_desc(self) -> pbd_model_desc:
         """Flatten into the C ABI descriptor (arrays kept alive on self)."""
         kh = self.filtersw[0].shape[0]

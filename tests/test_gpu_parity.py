@@ -391,3 +391,30 @@ def test_person_1080p_plan_and_run(gpu_required):
     rv, _ = h.root(0, 0)
     assert np.isfinite(rv).all()
     h.close()
+
+
+def test_cpp_host_demo_matches_oracle(gpu_required, orc, tmp_path):
+    """The C++ host layer (partsbaseddetector_amd/host: pbd::PartsBasedDetector<float> etc.) driven by
+    the reference's demo call sequence (src/demo.cpp:64-111), fused and stage by stage."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(capi.LIB_PATH), "host", "pbd_demo")
+    assert os.path.exists(exe), "build() did not produce the C++ demo"
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    im = make_image(0, 200, 150)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.5)
+    m.save(str(tmp_path / "model.bin"))
+    im.tofile(str(tmp_path / "im.raw"))
+    heads, boxes, _ = orc.candidates_sort(*orc.detect(m, im)[:3])
+    for extra in ([], ["stagewise"]):
+        out = subprocess.run([exe, str(tmp_path / "model.bin"), str(tmp_path / "im.raw"), "200", "150", "3"] + extra,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = out.stdout.strip().splitlines()
+        assert lines[0] == f"Number of candidates: {len(heads)}"
+        assert len(lines) == 1 + len(heads)
+        for ln, h, b in zip(lines[1:], heads, boxes):
+            tok = ln.split()
+            assert np.float32(float(tok[0])) == h["score"] and int(tok[2]) == h["level"]
+            got = np.array([[int(v) for v in t.split(",")] for t in tok[3:]])
+            np.testing.assert_array_equal(got, b[: len(got)])
