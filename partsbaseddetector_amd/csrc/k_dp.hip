@@ -36,32 +36,87 @@ size_t dt_lds_bytes(int stride, int lpb, int nmb) {
   return (size_t)lpb * stride * (4 + 4 + 2 + 2) + 64 * (8 + 8 + 4 + 4) + (size_t)nmb * stride * 8 + 8;
 }
 
-// Intersection of the parabolas rooted at x0 < x1 (Quadratic::operator()(x0,x1,y0,y1),
-// DistanceTransform.hpp:98-100), narrowed to T like `T s = f(...)` at :161.
+// Envelope scan of one line (DistanceTransform.hpp:156-170), one lane per line.
+//
+// Intersection of the parabolas rooted at x0 < x1 (Quadratic::operator()(x0,x1,y0,y1), :98-100),
+// narrowed to T like `T s = f(...)` at :161:
 //   num = ((y1 - y0) - b*(x1-x0)) + a*(x1^2 - x0^2)      (same fp64 operations, same order)
 //   s   = (float)(num / den),  den = (2a)*(x1-x0)
-// The fp64 division (14 dependent instructions, four of them quarter rate) is replaced by a
-// multiplication with the exact reciprocal r = RN(1/den) from the per-map table plus one fma
-// residual correction: q1 is within 1 ulp of RN(num/den).  (float)q1 can differ from
-// (float)RN(num/den) only if a float rounding boundary lies within 1 ulp of q1, i.e. the low 29
-// mantissa bits of q1 are 0x0FFFFFFF..0x10000001, or the value leaves the normal float range; in
-// exactly those cases (~1e-8 of all evaluations) the true IEEE division is evaluated instead, so
-// the narrowed result is always bit-identical to the reference's.
-__device__ __forceinline__ float dt_isect_fast(double a, double b, double twoa, const double* __restrict__ R, int x0,
-                                               int x1, double y0, double y1) {
-  const int dx = x1 - x0;
-  const double dxd = (double)dx;
-  const double num = ((y1 - y0) - b * dxd) + a * (double)(dx * (x1 + x0));
-  const double den = twoa * dxd;
-  const double r = R[dx];
-  const double q0 = num * r;
-  const double rem = __builtin_fma(-q0, den, num);
-  double q1 = __builtin_fma(rem, r, q0);
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
-  const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
-  const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-  if ((lo29 - 0x0FFFFFFFu) <= 2u || (ex - 897u) > 252u) q1 = num / den;
-  return (float)q1;
+// EXACT = false: the fp64 division (14 dependent instructions, four of them quarter rate) is
+// replaced by a multiplication with the exact reciprocal r = RN(1/den) from the per-map table plus
+// one fma residual correction; q1 is within 1 ulp of RN(num/den), so (float)q1 can differ from
+// (float)RN(num/den) only if a float rounding boundary lies within 1 ulp of q1 (low 29 mantissa
+// bits in 0x0FFFFFFF..0x10000001) or the value leaves the normal float range.  Those cases
+// (~1e-8 of all evaluations) set a sticky flag and the whole line is redone with EXACT = true
+// (true IEEE division), so the result is always bit-identical to the reference's.
+//
+// The reference's nested loops (for q { while (pop) }) are flattened into a state machine doing
+// exactly one intersection per iteration: lanes never wait for the slowest lane's pop count and
+// every line sees the reference's sequence of intersections / `s <= z[k]` tests in order.  A
+// single in-order wave exposes every latency and is instruction-issue bound, so the body is
+// branch-free, keeps the stack top and the entry below it in registers, prefetches the entry two
+// below, the reciprocal for a pop and the next line element at the top of the iteration (consumed
+// at its end), stores (y,z) of an entry as one 8-byte LDS word, and issues the push stores
+// unconditionally to slot k+1 (dead when the step pops).  The y of stack entry k overwrites the
+// consumed line element k in place (k <= q).
+template <bool EXACT>
+__device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, unsigned short* __restrict__ Vl,
+                                            const double* __restrict__ Rl, int len, double a, double b, int* kout) {
+  const double twoa = 2 * a;
+  const double r1 = Rl[1 < len ? 1 : 0];
+  int k = 0, q = 1, vk = 0, nv = 0;
+  float zk = -INFINITY, nz = -INFINITY;
+  double yk = (double)YZl[0].x, ny = 0.0;
+  double r_top = r1;
+  unsigned suspect = 0;
+  Vl[0] = 0;
+  YZl[0].y = -INFINITY;
+  float yq_f = YZl[min(1, len - 1)].x;
+  while (q < len) {
+    // prefetches (addresses known now, values used after the arithmetic below)
+    const int k2 = max(k - 2, 0);
+    const int pv = Vl[k2];
+    const float2 pyz = YZl[k2];
+    const double r_nxt = Rl[max(q - nv, 0)];   // reciprocal for the entry below the top (used if this step pops)
+    const float ynext_f = YZl[min(q + 1, len - 1)].x;
+    // intersection with the stack top
+    const int dx = q - vk;
+    const double yq = (double)yq_f;
+    const double dxd = (double)dx;
+    const double num = ((yq - yk) - b * dxd) + a * (double)(dx * (q + vk));
+    const double den = twoa * dxd;
+    double q1;
+    if (EXACT) {
+      q1 = num / den;
+    } else {
+      const double q0 = num * r_top;
+      const double rem = __builtin_fma(-q0, den, num);
+      q1 = __builtin_fma(rem, r_top, q0);
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
+      const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
+      const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
+      suspect |= (unsigned)((lo29 - 0x0FFFFFFFu) <= 2u) | (unsigned)((ex - 897u) > 252u);
+    }
+    const float s = (float)q1;
+    const bool pop = (s <= zk) && (k > 0);  // :162
+    // push stores (:166-169); slot k+1 is dead if this step pops
+    Vl[k + 1] = (unsigned short)q;
+    YZl[k + 1] = make_float2(yq_f, s);
+    // state update, selects only
+    const int vk_o = vk; const double yk_o = yk; const float zk_o = zk;
+    k = pop ? k - 1 : k + 1;
+    vk = pop ? nv : q;
+    yk = pop ? ny : yq;
+    zk = pop ? nz : s;
+    r_top = pop ? r_nxt : r1;
+    nv = pop ? pv : vk_o;
+    ny = pop ? (double)pyz.x : yk_o;
+    nz = pop ? pyz.y : zk_o;
+    yq_f = pop ? yq_f : ynext_f;
+    q = pop ? q : q + 1;
+  }
+  *kout = k;
+  return suspect != 0;
 }
 
 // One block = one wavefront = up to g.lpb lines of one group (lpb chosen per group so that every
@@ -84,9 +139,8 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
   const int nl = min(lpb, total - t.g0);
   const int m_first = t.g0 / g.nlines, m_last = (t.g0 + nl - 1) / g.nlines;
   const int nmb = m_last - m_first + 1;
-  float* Y = (float*)(R + g.nmb * S);         // [lpb][S] line values, then y of stack entries (in place)
-  float* Z = Y + lpb * S;                     // [lpb][S] z[k], k = 0..len
-  unsigned short* V = (unsigned short*)(Z + lpb * S);  // [lpb][S] v[k]
+  float2* YZ = (float2*)(R + g.nmb * S);      // [lpb][S] .x: line values, then y of stack entries (in place); .y: z[k]
+  unsigned short* V = (unsigned short*)(YZ + lpb * S);  // [lpb][S] v[k]
   unsigned short* P = V + lpb * S;            // [lpb][S] arg-max pointer per output (natural-layout staging)
   if (lane < nl) {
     const int gi = t.g0 + lane;
@@ -126,7 +180,7 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
         const int c = c0 + j;
         const int i = min(c, nch - 1) / CH;
         const int q = (min(c, nch - 1) - i * CH) * 64 + lane;
-        if (c < nch && q < len) Y[i * S + q] = r[j];
+        if (c < nch && q < len) YZ[i * S + q].x = r[j];
       }
     }
   }
@@ -134,71 +188,21 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
   DT_STAMP(2);
 
   // ---- build the upper envelope (DistanceTransform.hpp:156-170), one lane per line ----
-  // The reference's nested loops (for q { while (pop) }) are flattened into a per-lane state
-  // machine that performs exactly one intersection per iteration, so lanes never wait for the
-  // slowest lane's pop count, and every line sees the reference's sequence of intersections and
-  // `s <= z[k]` comparisons in order.  A single in-order wave exposes every latency, so the body
-  // is branch-free and keeps all LDS operands one iteration ahead:
-  //   * stack top (v,y,z) and the entry below it live in registers;
-  //   * the entry two below, the reciprocal needed if this step pops (R[q - v_below]) and the
-  //     line element two ahead are loaded at the top of the iteration and consumed at its end;
-  //   * the stack stores of a push are issued unconditionally to slot k+1 (dead when popping).
   if (lane < nl) {
     const int gi = t.g0 + lane;
     const int mi = gi / g.nlines;
     const DtMap mp = maps[g.map0 + mi];
-    const double a = mp.a, b = mp.b, twoa = 2 * a;
     const double* Rl = R + (mi - m_first) * S;
-    float* Yl = Y + lane * S;
-    float* Zl = Z + lane * S;
+    float2* YZl = YZ + lane * S;
     unsigned short* Vl = V + lane * S;
-    const double r1 = Rl[1 < len ? 1 : 0];
-    int k = 0, q = 1, vk = 0, nv = 0;
-    float zk = -INFINITY, nz = -INFINITY;
-    double yk = (double)Yl[0], ny = 0.0;
-    double r_top = r1;
-    Vl[0] = 0;
-    Zl[0] = -INFINITY;
-    float yq_f = Yl[min(1, len - 1)], yq1_f = Yl[min(2, len - 1)];
-    while (q < len) {
-      // prefetches (addresses known now, values used after the arithmetic below)
-      const int k2 = max(k - 2, 0);
-      const int pv = Vl[k2];
-      const float py_f = Yl[k2], pz = Zl[k2];
-      const int dx = q - vk;
-      const double r_nxt = Rl[max(q - nv, 0)];  // reciprocal for the entry below the top (used if this step pops)
-      const float yq2_f = Yl[min(q + 2, len - 1)];
-      // intersection with the stack top (same fp64 operations as dt_isect_fast)
-      const double yq = (double)yq_f;
-      const double dxd = (double)dx;
-      const double num = ((yq - yk) - b * dxd) + a * (double)(dx * (q + vk));
-      const double den = twoa * dxd;
-      const double q0 = num * r_top;
-      const double rem = __builtin_fma(-q0, den, num);
-      double q1 = __builtin_fma(rem, r_top, q0);
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
-      const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
-      const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-      if ((lo29 - 0x0FFFFFFFu) <= 2u || (ex - 897u) > 252u) q1 = num / den;  // exactness guard (rare)
-      const float s = (float)q1;
-      const bool pop = (s <= zk) && (k > 0);  // :162
-      // push stores (:166-169); slot k+1 is dead if this step pops
-      Vl[k + 1] = (unsigned short)q; Yl[k + 1] = yq_f; Zl[k + 1] = s;
-      // state update, selects only
-      const int vk_o = vk; const double yk_o = yk; const float zk_o = zk;
-      k = pop ? k - 1 : k + 1;
-      vk = pop ? nv : q;
-      yk = pop ? ny : yq;
-      zk = pop ? nz : s;
-      r_top = pop ? r_nxt : r1;
-      nv = pop ? pv : vk_o;
-      ny = pop ? (double)py_f : yk_o;
-      nz = pop ? pz : zk_o;
-      yq_f = pop ? yq_f : yq1_f;
-      yq1_f = pop ? yq1_f : yq2_f;
-      q = pop ? q : q + 1;
+    int k;
+    if (dt_envelope<false>(YZl, Vl, Rl, len, mp.a, mp.b, &k)) {
+      // a quotient landed within 1 ulp of a float rounding boundary: redo this line with true divisions
+      const float* src = lptr[lane];
+      for (int q = 0; q < len; ++q) YZl[q].x = src[q];
+      dt_envelope<true>(YZl, Vl, Rl, len, mp.a, mp.b, &k);
     }
-    Zl[k + 1] = INFINITY;
+    YZl[k + 1].y = INFINITY;
     Ksz[lane] = k;
   }
   __syncthreads();
@@ -215,8 +219,7 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
       const int mi = gi / g.nlines, li = gi - mi * g.nlines;
       const DtMap mp = maps[g.map0 + mi];
       const double a = mp.a, b = mp.b;
-      const float* Yl = Y + line * S;
-      const float* Zl = Z + line * S;
+      const float2* YZl = YZ + line * S;
       const unsigned short* Vl = V + line * S;
       unsigned short* Pl = P + line * S;
       const int K = Ksz[line];
@@ -229,16 +232,16 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
         const float f0 = (float)os;
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
-          if (Zl[mid + 1] < f0) lo = mid + 1; else hi = mid;
+          if (YZl[mid + 1].y < f0) lo = mid + 1; else hi = mid;
         }
         int k = lo;
         int vk = Vl[k];
-        float yk = Yl[k], zn = Zl[k + 1];
+        float yk = YZl[k].x, zn = YZl[k + 1].y;
         float* dst = mp.dst + li;
         const int nlines = g.nlines;
         for (int q = q0; q < q1; ++q) {
           const float fos = (float)os;
-          while (zn < fos) { k++; zn = Zl[k + 1]; vk = Vl[k]; yk = Yl[k]; }
+          while (zn < fos) { k++; zn = YZl[k + 1].y; vk = Vl[k]; yk = YZl[k].x; }
           const int d = os - vk;
           dst[(size_t)q * nlines] = (float)(a * (double)(d * d) + b * (double)d + (double)yk);
           Pl[q] = (unsigned short)vk;
