@@ -160,23 +160,23 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
   }
   __syncthreads();
   DT_STAMP(1);
-  // coalesced load of the nl lines.  Batches of 8 independent loads are issued before the first
+  // coalesced load of the nl lines.  Batches of 16 independent loads are issued before the first
   // wait (addresses are clamped instead of predicated: a predicated load makes hipcc branch and
   // wait per element, which serialises one full memory round trip per 256 B).
   {
     const int CH = (len + 63) >> 6;          // 64-element chunks per line
     const int nch = nl * CH;
-    for (int c0 = 0; c0 < nch; c0 += 8) {
-      float r[8];
+    for (int c0 = 0; c0 < nch; c0 += 16) {
+      float r[16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 16; ++j) {
         const int c = min(c0 + j, nch - 1);
         const int i = c / CH;
         const int q = min((c - i * CH) * 64 + lane, len - 1);
         r[j] = lptr[i][q];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 16; ++j) {
         const int c = c0 + j;
         const int i = min(c, nch - 1) / CH;
         const int q = (min(c, nch - 1) - i * CH) * 64 + lane;
@@ -293,35 +293,90 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
   const unsigned HW = (unsigned)H * W;
   if (cell >= HW) return;
   const int m_ = cell / W, n_ = cell - m_ * W;
-  for (int m = 0; m < L; ++m) {
+  constexpr int ML = 8;            // parent mixtures handled with all their gathers in flight at once
+  if (L <= ML) {
+    float acc[ML];
+#pragma unroll
+    for (int m = 0; m < ML; ++m) acc[m] = (m < L) ? J.par_in[m][cell] : 0.f;
+    for (int c = 0; c < J.nch; ++c) {
+      const ReduceChild& C = J.ch[c];
+      const int K = C.K;
+      int bi[ML];
+      float v[ML];
+      if (K == 1) {  // Math::reduceMax K==1 shortcut: copy (Math.hpp:154-158)
+        const float sd = C.sdt[cell];
+#pragma unroll
+        for (int m = 0; m < ML; ++m) { bi[m] = 0; v[m] = (m < L) ? sd + biasw[C.bias_off[0] + m] : 0.f; }
+      } else {
+#pragma unroll
+        for (int m = 0; m < ML; ++m) { bi[m] = 0; v[m] = -INFINITY; }
+        for (int mm = 0; mm < K; ++mm) {
+          const float sd = C.sdt[(size_t)mm * HW + cell];
+          const int bo = C.bias_off[mm];
+#pragma unroll
+          for (int m = 0; m < ML; ++m) {
+            if (m < L) {
+              const float wv = sd + biasw[bo + m];              // DynamicProgram.cpp:139
+              if (wv > v[m]) { bi[m] = mm; v[m] = wv; }         // strict >: first max wins
+            }
+          }
+        }
+      }
+      int ix[ML], iy[ML];
+#pragma unroll
+      for (int m = 0; m < ML; ++m)                               // first-level gathers, all in flight
+        ix[m] = (m < L) ? (correct_ptr ? (int)C.iy[(size_t)bi[m] * HW + cell] : (int)C.ix[(size_t)bi[m] * HW + cell]) : 0;
+#pragma unroll
+      for (int m = 0; m < ML; ++m) {                             // second-level gathers
+        if (m < L) {
+          if (!correct_ptr) iy[m] = C.iy[(size_t)bi[m] * HW + (size_t)m_ * W + ix[m]];   // Iy'(m,n) = Iy(m, Ix(m,n))
+          else { iy[m] = ix[m]; ix[m] = C.ix[(size_t)bi[m] * HW + (size_t)iy[m] * W + n_]; }  // true arg-max
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < ML; ++m) {
+        if (m < L) {
+          const size_t o = (size_t)m * HW + cell;
+          C.ox[o] = (int16_t)ix[m];
+          C.oy[o] = (int16_t)iy[m];
+          C.ok[o] = (uint8_t)bi[m];
+          acc[m] = acc[m] + v[m];                                // parent.score += maxv (:156), child order kept
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < ML; ++m) if (m < L) J.par_out[m][cell] = acc[m];
+    return;
+  }
+  for (int m = 0; m < L; ++m) {   // generic path (more than 8 parent mixtures)
     float acc = J.par_in[m][cell];
     for (int c = 0; c < J.nch; ++c) {
       const ReduceChild& C = J.ch[c];
       const int K = C.K;
       float v;
       int bi = 0;
-      if (K == 1) {  // Math::reduceMax K==1 shortcut: copy (Math.hpp:154-158)
+      if (K == 1) {
         v = C.sdt[cell] + biasw[C.bias_off[0] + m];
       } else {
         v = -INFINITY;
         for (int mm = 0; mm < K; ++mm) {
-          const float wv = C.sdt[(size_t)mm * HW + cell] + biasw[C.bias_off[mm] + m];  // DynamicProgram.cpp:139
-          if (wv > v) { bi = mm; v = wv; }                                            // strict >: first max wins
+          const float wv = C.sdt[(size_t)mm * HW + cell] + biasw[C.bias_off[mm] + m];
+          if (wv > v) { bi = mm; v = wv; }
         }
       }
       int ix = C.ix[(size_t)bi * HW + cell];
       int iy;
       if (!correct_ptr) {
-        iy = C.iy[(size_t)bi * HW + (size_t)m_ * W + ix];       // Iy'(m,n) = Iy(m, Ix(m,n))
+        iy = C.iy[(size_t)bi * HW + (size_t)m_ * W + ix];
       } else {
         iy = C.iy[(size_t)bi * HW + cell];
-        ix = C.ix[(size_t)bi * HW + (size_t)iy * W + n_];       // true arg-max composition
+        ix = C.ix[(size_t)bi * HW + (size_t)iy * W + n_];
       }
       const size_t o = (size_t)m * HW + cell;
       C.ox[o] = (int16_t)ix;
       C.oy[o] = (int16_t)iy;
       C.ok[o] = (uint8_t)bi;
-      acc = acc + v;                                            // parent.score += maxv (:156), child order kept
+      acc = acc + v;
     }
     J.par_out[m][cell] = acc;
   }

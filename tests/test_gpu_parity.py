@@ -418,3 +418,50 @@ def test_cpp_host_demo_matches_oracle(gpu_required, orc, tmp_path):
             assert np.float32(float(tok[0])) == h["score"] and int(tok[2]) == h["level"]
             got = np.array([[int(v) for v in t.split(",")] for t in tok[3:]])
             np.testing.assert_array_equal(got, b[: len(got)])
+
+
+# ---------------------------------------------------------------- remaining BASELINE configs
+def _score_locs_agree(got, ref, thresh, tol=1e-4):
+    rk = {(int(h["level"]), int(h["component"]), int(l[0][0]), int(l[0][1])): i for i, (h, l) in enumerate(zip(ref[0], ref[2]))}
+    gk = {(int(h["level"]), int(h["component"]), int(l[0][0]), int(l[0][1])): i for i, (h, l) in enumerate(zip(got[0], got[2]))}
+    for k in set(rk) ^ set(gk):            # present on one side only: must sit on the threshold
+        s = ref[0][rk[k]]["score"] if k in rk else got[0][gk[k]]["score"]
+        assert abs(float(s) - thresh) < tol
+    common = set(rk) & set(gk)
+    flips = 0
+    for k in common:
+        i, j = rk[k], gk[k]
+        assert abs(float(ref[0][i]["score"]) - float(got[0][j]["score"])) < tol
+        flips += int(not np.array_equal(ref[2][i], got[2][j]))
+    return len(common), flips
+
+
+def test_config1_face_like_320x240(gpu_required, orc):
+    """configs[0]: face-like model (13 single-mixture components sharing a filter pool), 320x240:
+    exact filter bank bit-identical; MFMA filter bank within the north_star tolerance."""
+    m = make_face_like_model(seed=77, ncomp=13, nfilters=146, part_counts=(39, 68))
+    im = make_image(7, 320, 240)
+    got, ref = _e2e(orc, m, im, capi.PBD_CONV_EXACT, q=99.9)
+    assert len(ref[0]) > 20
+    assert_candidates_equal(got, ref)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA)
+    n, flips = _score_locs_agree(h.detect(im), ref, m.thresh)
+    h.close()
+    assert n >= 0.9 * len(ref[0]) and flips <= max(1, n // 50)
+
+
+def test_config5_large_mixture_mfma_vs_exact(gpu_required):
+    """configs[4]: 26 parts x 8 mixtures = 208 filters (7 MFMA n-tiles, padded to 320):
+    MFMA responses within 2e-5 of the bit-exact VALU path on the same resident features."""
+    m = make_person_model(K=8)
+    im = make_image(1, 320, 240)
+    he = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    hm = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA)
+    he.pyramid(im); hm.pyramid(im)
+    he.pdf(); hm.pdf()
+    worst = 0.0
+    for l in (0, 5, he._geo["nlevels"] - 1):
+        for n in (0, 31, 32, 159, 160, 207):
+            worst = max(worst, float(np.abs(he.level_response(l, n) - hm.level_response(l, n)).max()))
+    he.close(); hm.close()
+    assert worst < 2e-5, worst
