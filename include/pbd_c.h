@@ -207,6 +207,10 @@ int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes);
 /* debug: 100 MHz wall-clock stamps of block 0 of the last distance-transform launch at its six
  * phase boundaries (setup, line load, envelope scan, read-out, pointer store, end)            */
 int pbd_debug_dt_stamps(unsigned long long out[8]);
+/* same for the HOG kernel: tile staging, gradient, histogram, energy+normalisers, features */
+int pbd_debug_hog_stamps(unsigned long long out[8]);
+/* same for the MFMA filter bank: tile staging, K loop, barrier, epilogue                    */
+int pbd_debug_conv_stamps(unsigned long long out[8]);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ EXPORTS = [
     "pbd_set_level_response", "pbd_dp_min", "pbd_get_dp_pointers", "pbd_get_root", "pbd_dp_argmin",
     "pbd_dt2d", "pbd_hog_u8", "pbd_resize_u8", "pbd_pyrdown_u8", "pbd_nms_map",
     "pbd_candidates_sort", "pbd_candidates_nms", "pbd_get_stage_ms", "pbd_set_profiling",
-    "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps",
+    "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps",
 ]
 
 

@@ -19,6 +19,11 @@
 // workgroup (border values materialised there) and write plane-major outputs.
 #include "pbd_internal.hpp"
 
+// debug: per-phase wall-clock stamps (100 MHz) of one workgroup of the last k_conv_mfma launch
+__device__ unsigned long long pbd_conv_dbg[8];
+#define CONV_STAMP(i) do { if (blockIdx.x == 300 && blockIdx.y == 2 && threadIdx.x == 0) pbd_conv_dbg[i] = wall_clock64(); } while (0)
+void conv_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_conv_dbg), sizeof(unsigned long long) * 8); }
+
 #define CT 16        // spatial tile side (cells)
 #define CSTR 33      // LDS floats per cell (32 + 1 pad: conflict-free across x)
 #define NFG 8        // filters held in registers per pass (exact kernel)
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TW = CT + KW - 1;
   float* ft = (float*)smem;                 // [TH][TW][CSTR]
+  CONV_STAMP(0);
   const ConvTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const int H = lv.ch, W = lv.cw;
@@ -202,11 +208,16 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ 
   const int ai = lane & 31, ak = lane >> 5;
   // B operand: B[k = l>>5][j = l&31] -> wT[(tap*32 + c + ak)*nfpad + nbase + (l&31)]
   const float* bsrc = wT + (size_t)ak * nfpad + nbase + (lane & 31);
-  float bcur[16], bnxt[16];
+  // two register sets in explicit ping-pong (the tap loop is unrolled by two): while one set feeds
+  // the 32 MFMAs of a tap, the other receives the next tap's 16 values.  With a single pair of
+  // arrays and a copy hipcc merges them and ends up loading the next tap AFTER the last MFMA that
+  // reads the registers, then waits vmcnt(0) at the loop tail: a full L2 round trip per tap.
+  float b0[16], b1[16];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) bcur[u] = bsrc[(size_t)(2 * u) * nfpad];  // tap 0, issued before the tile staging
+  for (int u = 0; u < 16; ++u) b0[u] = bsrc[(size_t)(2 * u) * nfpad];  // tap 0, issued before the tile staging
   stage_feature_tile<KH, KW>(ft, F, t.y0, t.x0, H, W, tid);
   __syncthreads();
+  CONV_STAMP(1);
 
   f32x16 acc0, acc1;
 #pragma unroll
@@ -214,25 +225,35 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ 
   const int arow0 = 4 * wave + (ai >> 4), acol = ai & 15;
   const float* abase0 = ft + (arow0 * TW + acol) * CSTR + ak;
   const float* abase1 = ft + ((arow0 + 2) * TW + acol) * CSTR + ak;
+  constexpr int NTAP = KH * KW;
 
-  for (int tap = 0; tap < KH * KW; ++tap) {
-    const int tn = min(tap + 1, KH * KW - 1);
-    const float* bs = bsrc + (size_t)tn * PBD_FLEN * nfpad;
+  auto load_tap = [&](float (&dst)[16], int tap) {
+    const float* bs = bsrc + (size_t)min(tap, NTAP - 1) * PBD_FLEN * nfpad;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) bnxt[u] = bs[(size_t)(2 * u) * nfpad];   // next tap's weights, in flight during this tap
+    for (int u = 0; u < 16; ++u) dst[u] = bs[(size_t)(2 * u) * nfpad];
+  };
+  auto mma_tap = [&](const float (&bw)[16], int tap) {
     const int ti = tap / KW, tj = tap - ti * KW;
     const float* a0 = abase0 + (ti * TW + tj) * CSTR;
     const float* a1 = abase1 + (ti * TW + tj) * CSTR;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const float av0 = a0[2 * u], av1 = a1[2 * u];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bcur[u], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bcur[u], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bw[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bw[u], acc1, 0, 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) bcur[u] = bnxt[u];
+  };
+  for (int tap = 0; tap < NTAP; tap += 2) {
+    load_tap(b1, tap + 1);
+    mma_tap(b0, tap);
+    if (tap + 1 < NTAP) {
+      load_tap(b0, tap + 2);
+      mma_tap(b1, tap + 1);
+    }
   }
+  CONV_STAMP(2);
   __syncthreads();  // all waves are done reading the feature tile: reuse it for the epilogue
+  CONV_STAMP(3);
   // Epilogue.  C/D layout 32x32: col(j) = lane&31, row(i) = (reg&3) + 8*(reg>>2) + 4*(lane>>5),
   // i.e. a lane holds ONE filter and 16 scattered cells: storing that directly would be 4-byte
   // scatters across 32 response planes.  Transpose the wave's 64-cell x 32-filter slab through the
@@ -253,6 +274,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ 
     const int fn = nbase + j;
     if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[j * 65 + lane];
   }
+  CONV_STAMP(4);
 }
 
 void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,

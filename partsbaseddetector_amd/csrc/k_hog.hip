@@ -19,6 +19,11 @@
 // consecutive lanes covering one cell's 128 B.
 #include "pbd_internal.hpp"
 
+// debug: per-phase wall-clock stamps (100 MHz) of block 0 of the last k_hog launch
+__device__ unsigned long long pbd_hog_dbg[8];
+#define HOG_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pbd_hog_dbg[i] = wall_clock64(); } while (0)
+void hog_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_hog_dbg), sizeof(unsigned long long) * 8); }
+
 struct HogLds {
   int PT;        // pixel window side
   int NB;        // blocks per side (TC+2)
@@ -47,10 +52,18 @@ __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int cn) {
 }
 size_t hog_lds_bytes(int sbin, int tc) { return hog_lds_layout(sbin, tc, 3).total; }
 
-__global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
-                                             const uint8_t* __restrict__ pyr, float* __restrict__ feat, int cn,
-                                             int sbin, int tc) {
+#define HOG_NT 384   // threads per workgroup: (TC+2)^2 = 324 block histograms finish in one pass
+
+// SBIN_T / TC_T > 0: compile-time cell size / tile side (index divisions become shifts, loops unroll);
+// 0: taken from the runtime arguments (generic fallback).
+template <int SBIN_T, int TC_T>
+__global__ __launch_bounds__(HOG_NT) void k_hog(const HogTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
+                                                const uint8_t* __restrict__ pyr, float* __restrict__ feat, int cn,
+                                                int sbin_rt, int tc_rt) {
+  const int sbin = SBIN_T > 0 ? SBIN_T : sbin_rt;
+  const int tc = TC_T > 0 ? TC_T : tc_rt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  HOG_STAMP(0);
   const HogTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const HogLds L = hog_lds_layout(sbin, tc, 3);
@@ -77,25 +90,24 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
 
   // ---- stage the source pixels of the window (+margins) in LDS, coalesced byte rows ----
   const int rowb = RT * cn;
-  {
-    const int nbytes = RT * rowb;
-    for (int i0 = tid; i0 < nbytes; i0 += 256 * 16) {  // 16 independent byte loads in flight per lane
-      uint8_t r[16];
+  for (int cb = tid; cb < rowb; cb += HOG_NT) {  // one byte column per thread, 32 independent row loads in flight
+    const int xc = cb / cn, chn = cb - xc * cn;
+    const int sx = min(max(rx0 + xc, 0), w - 1);
+    const uint8_t* col = im + sx * cn + chn;
+    for (int r0 = 0; r0 < RT; r0 += 32) {
+      uint8_t rr[32];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int i = min(i0 + j * 256, nbytes - 1);
-        const int rr = i / rowb, cb = i - rr * rowb;
-        const int xc = cb / cn, ch = cb - xc * cn;
-        const int sy = min(max(ry0 + rr, 0), h - 1), sx = min(max(rx0 + xc, 0), w - 1);
-        r[j] = im[(size_t)sy * stride + sx * cn + ch];
+      for (int j = 0; j < 32; ++j) {
+        const int sy = min(max(ry0 + min(r0 + j, RT - 1), 0), h - 1);
+        rr[j] = col[(size_t)sy * stride];
       }
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (i0 + j * 256 < nbytes) raw[i0 + j * 256] = r[j];
+      for (int j = 0; j < 32; ++j)
+        if (r0 + j < RT) raw[(r0 + j) * rowb + cb] = rr[j];
     }
   }
   // ---- interpolation tables per window row / column (:252-260) ----
-  for (int i = tid; i < 2 * PT; i += 256) {
+  for (int i = tid; i < 2 * PT; i += HOG_NT) {
     const bool isx = i >= PT;
     const int j = isx ? i - PT : i;
     const int p = (isx ? px0 : py0) + j;
@@ -107,11 +119,12 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
     else { wy0[j] = v0; wy1[j] = v1; ipy[j] = ip; }
   }
   __syncthreads();
+  HOG_STAMP(1);
 
   // ---- per-pixel gradient magnitude + orientation bin (:202-249) ----
   const float uu[9] = {1.000, 0.9397, 0.7660, 0.5000, 0.1736, -0.1736, -0.5000, -0.7660, -0.9397};
   const float vv[9] = {0.000, 0.3420, 0.6428, 0.8660, 0.9848, 0.9848, 0.8660, 0.6428, 0.3420};
-  for (int i = tid; i < PT * PT; i += 256) {
+  for (int i = tid; i < PT * PT; i += HOG_NT) {
     const int wy = i / PT, wx = i - wy * PT;
     const int y = py0 + wy, x = px0 + wx;
     float m = 0.f;
@@ -151,17 +164,19 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
     mag[i] = m;
     bin[i] = (uint8_t)b;
   }
-  for (int i = tid; i < NB * NB * PBD_NORIENT; i += 256) hist[i] = 0.f;
+  for (int i = tid; i < NB * NB * PBD_NORIENT; i += HOG_NT) hist[i] = 0.f;
   __syncthreads();
+  HOG_STAMP(2);
 
   // ---- histogram: one thread owns one block's 18 bins and walks the block's pixels in the
   //      reference's raster order (:262-265), so every bin sees the same sequence of float adds ----
-  for (int bl = tid; bl < NB * NB; bl += 256) {
+  for (int bl = tid; bl < NB * NB; bl += HOG_NT) {
     const int lby = bl / NB, lbx = bl - lby * NB;
     const int by = t.cy0 + lby, bx = t.cx0 + lbx;
     if (by >= bh || bx >= bw) continue;
     float* hb = hist + bl * PBD_NORIENT;
     const int wy_lo = lby * sbin, wx_lo = lbx * sbin, span = 2 * sbin + 2;
+#pragma unroll 2
     for (int dy = 0; dy < span; ++dy) {
       const int wy = wy_lo + dy;
       if (wy >= PT) break;
@@ -181,9 +196,10 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
     }
   }
   __syncthreads();
+  HOG_STAMP(3);
 
   // ---- block energy (:270-283) ----
-  for (int i = tid; i < NB * NB; i += 256) {
+  for (int i = tid; i < NB * NB; i += HOG_NT) {
     const float* hsrc = hist + i * PBD_NORIENT;
     float acc = 0.f;
 #pragma unroll
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
 
   // ---- normalisers on the (TC+1)^2 block corners (:292-299) ----
   const int NC = tc + 1;
-  for (int i = tid; i < NC * NC; i += 256) {
+  for (int i = tid; i < NC * NC; i += HOG_NT) {
     const int y = i / NC, x = i - y * NC;
     const float* p = norm + y * NB + x;
     float s = p[0] + p[1] + p[NB] + p[NB + 1];
@@ -205,9 +221,10 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
   }
   __syncthreads();
 
+  HOG_STAMP(4);
   // ---- 32 features per cell, one lane per feature (:301-338) ----
   float* out = feat + lv.cell_off * PBD_FLEN;
-  for (int i = tid; i < tc * tc * PBD_FLEN; i += 256) {
+  for (int i = tid; i < tc * tc * PBD_FLEN; i += HOG_NT) {
     const int k = i & 31;
     const int cell = i >> 5;
     const int ly = cell / tc, lx = cell - ly * tc;
@@ -233,16 +250,22 @@ __global__ __launch_bounds__(256) void k_hog(const HogTile* __restrict__ tiles, 
     }
     out[((size_t)cy * lv.cw + cx) * PBD_FLEN + k] = r;
   }
+  HOG_STAMP(5);
 }
 
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, float* feat,
                 int cn, int sbin, int tc, hipStream_t s) {
   if (ntiles <= 0) return;
-  size_t lds = hog_lds_bytes(sbin, tc);
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipFuncSetAttribute((const void*)k_hog, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = lds;
-  }
-  hipLaunchKernelGGL(k_hog, dim3(ntiles), dim3(256), lds, s, tiles, levels, pyr, feat, cn, sbin, tc);
+  const size_t lds = hog_lds_bytes(sbin, tc);
+  auto go = [&](auto kern) {
+    static size_t configured = 0;  // one per instantiation
+    if (lds > configured) {
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      configured = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(HOG_NT), lds, s, tiles, levels, pyr, feat, cn, sbin, tc);
+  };
+  if (sbin == 4 && tc == 16) go(k_hog<4, 16>);
+  else if (sbin == 8 && tc == 8) go(k_hog<8, 8>);
+  else go(k_hog<0, 0>);
 }

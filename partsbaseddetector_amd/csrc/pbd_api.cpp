@@ -1131,6 +1131,8 @@ int pbd_get_work(const pbd_handle* h, double work[6]) {
   return PBD_OK;
 }
 int pbd_debug_dt_stamps(unsigned long long* out) { dt_debug_read(out); return PBD_OK; }
+int pbd_debug_hog_stamps(unsigned long long* out) { hog_debug_read(out); return PBD_OK; }
+int pbd_debug_conv_stamps(unsigned long long* out) { conv_debug_read(out); return PBD_OK; }
 
 int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes) {
   if (!h) return PBD_ERR_ARG;

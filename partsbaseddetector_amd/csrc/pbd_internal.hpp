@@ -186,4 +186,6 @@ void launch_backtrack(const int* count, const CandRec* rec, int capacity, const 
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
                       char* out, size_t out_stride, hipStream_t s);
 void dt_debug_read(unsigned long long* out);
+void hog_debug_read(unsigned long long* out);
+void conv_debug_read(unsigned long long* out);
 void launch_nms_map(const float* src, int rows, int cols, int sz, uint8_t* dst, hipStream_t s);

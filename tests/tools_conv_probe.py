@@ -1,0 +1,16 @@
+"""Ad-hoc probe (not a test): per-phase timestamps of one workgroup of k_conv_mfma on the person model."""
+import ctypes as C
+import sys
+sys.path.insert(0, "/root/repo")
+from partsbaseddetector_amd import capi
+from partsbaseddetector_amd.model import make_image, make_person_model
+m = make_person_model(); m.thresh = 3e38
+h = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA)
+im = make_image(0, 640, 480)
+for _ in range(3):
+    h.detect(im)
+    st = (C.c_ulonglong * 8)()
+    capi.lib().pbd_debug_conv_stamps(st)
+    d = [(st[i + 1] - st[i]) / 100.0 for i in range(4)]
+    print(f"conv WG(300,2) phases us: stage {d[0]:.1f} kloop {d[1]:.1f} barrier {d[2]:.1f} epilogue {d[3]:.1f}", flush=True)
+h.close()
