@@ -89,7 +89,7 @@ typedef struct pbd_options {
                             arg-max composition                                */
   int32_t level_begin;   /* process pyramid levels [level_begin, level_end)    */
   int32_t level_end;     /* <=0: all levels (multi-GPU level sharding)         */
-  int32_t reserved[2];
+  int32_t reserved[2];   /* [0]: DP level groups on separate streams (0/1 = one chain, max 3) */
 } pbd_options;
 
 /* ---- output record: include/Candidate.hpp:56-111 --------------------------

@@ -401,13 +401,33 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   auto scr_of = [&](int fp, int l, int mm) {
     return part_scr[fp] + (size_t)h->parts[fp].K * lvl_scr[l] + (size_t)mm * h->lv[l].cw * h->lv[l].ch;
   };
+  // level groups: walk levels fine -> coarse, start a new group whenever the x-pass of the busiest
+  // round would exceed ~800 blocks (one wave of 4 blocks per CU on 256 CUs)
+  {
+    size_t maxK = 1;
+    for (auto& rnd : h->rounds) { size_t k = 0; for (int fp : rnd) k += h->parts[fp].K; maxK = std::max(maxK, k); }
+    int gcur = 0; size_t blocks = 0;
+    for (int l = 0; l < n; ++l) {
+      const Level& L = h->lv[l];
+      if (L.active && L.cw > 0 && L.ch > 0) {
+        const DtGroup gx = dt_group(0, (int)maxK, L.ch, L.cw, dt_budget);
+        const size_t b = ((size_t)maxK * L.ch + gx.lpb - 1) / gx.lpb;
+        if (blocks + b > 800 && blocks > 0 && gcur < h->ngroups - 1) { gcur++; blocks = 0; }
+        blocks += b;
+      }
+      h->level_group[l] = gcur;
+    }
+  }
+  std::vector<std::vector<char>> slot_hist;  // slot_init before each round (identical for all groups)
+  for (int gi_ = 0; gi_ < PBD_NGROUPS; ++gi_) h->grl[gi_].clear();
   for (size_t r = 0; r < h->rounds.size(); ++r) {
     const std::vector<int>& rnd = h->rounds[r];
+    for (int grp = 0; grp < h->ngroups; ++grp) {
     pbd_handle::RoundLaunch R{};
     std::vector<DtTask> xt, yt;
     for (int l = 0; l < n && !rnd.empty(); ++l) {
       const Level& L = h->lv[l];
-      if (!L.active || L.cw == 0 || L.ch == 0) continue;
+      if (!L.active || L.cw == 0 || L.ch == 0 || h->level_group[l] != grp) continue;
       const size_t HW = (size_t)L.cw * L.ch;
       const int gx_map0 = (int)maps.size();
       int gx_nmaps = 0;
@@ -442,7 +462,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     tasks.insert(tasks.end(), xt.begin(), xt.end());
     R.ytask0 = (int)tasks.size(); R.nytasks = (int)yt.size();
     tasks.insert(tasks.end(), yt.begin(), yt.end());
-    // reduce waves of this round
+    // reduce waves of this round (slot state is advanced once per wave, after the last group)
+    std::vector<char> slot_w = slot_init;
     for (const std::vector<int>& wave : h->red_rounds[r]) {
       pbd_handle::ReduceWave Wv{(int)redblk.size(), 0};
       std::vector<int> parents;  // distinct parents, in first-appearance order
@@ -452,7 +473,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       }
       for (int l = 0; l < n; ++l) {
         const Level& L = h->lv[l];
-        if (!L.active || L.cw == 0 || L.ch == 0) continue;
+        if (!L.active || L.cw == 0 || L.ch == 0 || h->level_group[l] != grp) continue;
         const size_t HW = (size_t)L.cw * L.ch;
         for (int pf : parents) {
           const PartInfo& Par = h->parts[pf];
@@ -460,7 +481,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
           J.H = L.ch; J.W = L.cw; J.L = Par.K;
           for (int pm = 0; pm < Par.K; ++pm) {
             float* accp = h->d_acc + L.cell_off * h->nslots + (size_t)Par.slot[pm] * HW;
-            J.par_in[pm] = slot_init[Par.slot[pm]] ? accp : h->d_resp + L.cell_off * m.nfilters + (size_t)Par.filterid[pm] * HW;
+            J.par_in[pm] = slot_w[Par.slot[pm]] ? accp : h->d_resp + L.cell_off * m.nfilters + (size_t)Par.filterid[pm] * HW;
             J.par_out[pm] = accp;
           }
           for (int fp : wave) {  // `wave` is in descending child order
@@ -479,11 +500,13 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
         }
       }
       for (int pf : parents)
-        for (int pm = 0; pm < h->parts[pf].K; ++pm) slot_init[h->parts[pf].slot[pm]] = 1;
+        for (int pm = 0; pm < h->parts[pf].K; ++pm) slot_w[h->parts[pf].slot[pm]] = 1;
       Wv.nblks = (int)redblk.size() - Wv.blk0;
       R.waves.push_back(Wv);
     }
-    h->rl.push_back(R);
+    h->grl[grp].push_back(R);
+    if (grp == h->ngroups - 1) slot_init = slot_w;
+    }  // groups
   }
   if ((rc = dev_upload(h, &h->d_dtmaps, maps))) return rc;
   if ((rc = dev_upload(h, &h->d_dtgroups, groups))) return rc;
@@ -568,11 +591,27 @@ static int run_pdf(pbd_handle* h) {
 
 static int run_dp_min(pbd_handle* h) {
   if (h->dp_timer_on) hipEventRecord(h->ev_dp0, h->stream);
-  for (auto& R : h->rl) {
-    launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
-    launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
-    for (auto& Wv : R.waves)
-      launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
+  // optional fork: every level group runs its chain of rounds on its own stream
+  if (h->ngroups > 1) hipEventRecord(h->ev_fork, h->stream);
+  if (h->ngroups == 1) {  // default: one chain of rounds on the handle's stream
+    for (auto& R : h->grl[0]) {
+      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
+      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
+      for (auto& Wv : R.waves)
+        launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
+    }
+  }
+  for (int g = 0; g < h->ngroups && h->ngroups > 1; ++g) {
+    hipStream_t s = h->gstream[g];
+    hipStreamWaitEvent(s, h->ev_fork, 0);
+    for (auto& R : h->grl[g]) {
+      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, s);
+      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, s);
+      for (auto& Wv : R.waves)
+        launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, s);
+    }
+    hipEventRecord(h->ev_join[g], s);
+    hipStreamWaitEvent(h->stream, h->ev_join[g], 0);  // join
   }
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
   launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
@@ -678,6 +717,7 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   h->opt = o;
   int rc = ingest_model(h, model);
   if (rc) return rc;
+  h->ngroups = std::min(std::max(o.reserved[0], 1), PBD_NGROUPS);
   h->conv_mode = o.conv_mode;
   if (h->conv_mode == PBD_CONV_AUTO)  // a dense contraction when N x K is GEMM-sized
     h->conv_mode = ((size_t)model->nfilters * model->kh * model->kw * model->flen >= 32 * 800 && model->kh == 5 && model->kw == 5)
@@ -691,6 +731,11 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   for (int i = 0; i < 8; ++i) HIPCHK(h, hipEventCreate(&h->ev[i]));
   HIPCHK(h, hipEventCreate(&h->ev_dp0));
   HIPCHK(h, hipEventCreate(&h->ev_dp1));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  for (int g = 0; g < PBD_NGROUPS && h->ngroups > 1; ++g) {  // extra streams only when asked for: streams share a few HW queues
+    HIPCHK(h, hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
+  }
   return upload_model(h);
 }
 
@@ -705,6 +750,11 @@ int pbd_destroy(pbd_handle* h) {
   for (int i = 0; i < 8; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
   if (h->ev_dp0) hipEventDestroy(h->ev_dp0);
   if (h->ev_dp1) hipEventDestroy(h->ev_dp1);
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  for (int g = 0; g < PBD_NGROUPS; ++g) {
+    if (h->gstream[g]) { hipStreamSynchronize(h->gstream[g]); hipStreamDestroy(h->gstream[g]); }
+    if (h->ev_join[g]) hipEventDestroy(h->ev_join[g]);
+  }
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return PBD_OK;

@@ -146,6 +146,15 @@ struct pbd_handle {
   ReduceJob* d_redjobs = nullptr; ReduceBlock* d_redblocks = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
   struct ReduceWave { int blk0, nblks; };
   struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; std::vector<ReduceWave> waves; };
+  // Pyramid levels never interact in the DP (src/DynamicProgram.cpp:83-87), so levels are split into
+  // PBD_NGROUPS size classes, each running its own chain of rounds on its own stream: a launch then
+  // only waits for the longest line of ITS levels, and the big-level group fits one wave of blocks.
+  #define PBD_NGROUPS 3
+  std::vector<RoundLaunch> grl[PBD_NGROUPS];          // [group][round]
+  hipStream_t gstream[PBD_NGROUPS] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[PBD_NGROUPS] = {};
+  int level_group[PBD_MAX_LEVELS] = {};
+  int ngroups = 1;   // pbd_options.reserved[0]: 1 (default) .. PBD_NGROUPS; measured slower than one chain on MI355X
   size_t dt_lds = 0;                                 // dynamic LDS of every k_dt_pass launch
   std::vector<RoundLaunch> rl;
   int n_rootjobs = 0; unsigned root_cells = 0;
