@@ -6,7 +6,8 @@
 // fused detect() (src/PartsBasedDetector.cpp:73-89).
 #include <cstdio>
 #include <cstdlib>
-#include "pbd_host.hpp"
+#include <memory>
+#include "pbd_filestorage.hpp"
 using namespace pbd;
 
 int main(int argc, char** argv) {
@@ -14,8 +15,15 @@ int main(int argc, char** argv) {
     printf("Usage: pbd_demo model_file image.raw width height channels [stagewise]\n");
     exit(-1);
   }
-  BinaryModel model;
-  if (!model.deserialize(argv[1])) { printf("Error deserializing file\n"); exit(-3); }
+  // determine the type of model to read (src/demo.cpp:63-82)
+  std::unique_ptr<Model> modelp;
+  const std::string mf = argv[1];
+  const std::string ext = mf.find('.') == std::string::npos ? "" : mf.substr(mf.rfind('.'));
+  if (ext == ".xml" || ext == ".yaml" || ext == ".yml") modelp.reset(new FileStorageModel);
+  else if (ext == ".bin") modelp.reset(new BinaryModel);
+  else { printf("Unsupported model format: %s\n", ext.c_str()); exit(-2); }
+  if (!modelp->deserialize(argv[1])) { printf("Error deserializing file\n"); exit(-3); }
+  Model& model = *modelp;
   const int w = atoi(argv[3]), h = atoi(argv[4]), cn = atoi(argv[5]);
   Mat im(h, w, PBD_8U, cn);
   FILE* f = fopen(argv[2], "rb");

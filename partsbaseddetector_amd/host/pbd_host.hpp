@@ -166,6 +166,36 @@ class BinaryModel : public Model {
     fclose(f);
     return ok;
   }
+  bool serialize(const std::string& filename) const {
+    FILE* f = fopen(filename.c_str(), "wb");
+    if (!f) return false;
+    const int kh = filtersw_[0].rows, kw = filtersw_[0].cols / flen_;
+    int32_t hd[12] = {(int32_t)filtersw_.size(), kh, kw, flen_, norient_, binsize_, nscales_, (int32_t)defw_.size(),
+                      (int32_t)biasw_.size(), (int32_t)filterid_.size(), 0, 0};
+    fwrite("PBDMODL1", 1, 8, f); fwrite(hd, 4, 12, f); fwrite(&thresh_, 4, 1, f);
+    for (const Mat& m : filtersw_) fwrite(m.ptr<float>(), 4, (size_t)kh * kw * flen_, f);
+    for (const vectorf& d : defw_) fwrite(d.data(), 4, 4, f);
+    for (const Point& a : anchors_) { int32_t v[2] = {a.x, a.y}; fwrite(v, 4, 2, f); }
+    fwrite(biasw_.data(), 4, biasw_.size(), f);
+    for (size_t c = 0; c < filterid_.size(); ++c) {
+      int32_t np = (int32_t)filterid_[c].size(); fwrite(&np, 4, 1, f);
+      for (int p = 0; p < np; ++p) {
+        const int32_t k = (int32_t)filterid_[c][p].size();
+        int32_t pk[2] = {p ? parentid_[c][p] : -1, k}; fwrite(pk, 4, 2, f);
+        std::vector<int32_t> d(k, 0), b(k, biasid_[c][p].empty() ? 0 : biasid_[c][p][0]);
+        for (int q = 0; q < k && p > 0 && q < (int)defid_[c][p].size(); ++q) d[q] = defid_[c][p][q];
+        for (int q = 0; q < k && q < (int)biasid_[c][p].size(); ++q) b[q] = biasid_[c][p][q];
+        fwrite(filterid_[c][p].data(), 4, k, f); fwrite(d.data(), 4, k, f); fwrite(b.data(), 4, k, f);
+      }
+    }
+    fclose(f);
+    return true;
+  }
+  void assign(Model& o) {
+    filtersw_ = o.filters(); defw_ = o.def(); biasw_ = o.bias(); anchors_ = o.anchors(); biasid_ = o.biasid();
+    filterid_ = o.filterid(); defid_ = o.defid(); parentid_ = o.parentid(); name_ = o.name(); nscales_ = o.nscales();
+    thresh_ = o.thresh(); binsize_ = o.binsize(); flen_ = o.flen(); norient_ = o.norient();
+  }
 };
 
 // ---- shared device handle -------------------------------------------------------------------
@@ -187,8 +217,9 @@ class Device {
         parentid.push_back(p ? m.parentid()[c][p] : -1);
         for (size_t k = 0; k < m.filterid()[c][p].size(); ++k) {
           filterid.push_back(m.filterid()[c][p][k]);
-          defid.push_back(p ? m.defid()[c][p][k] : 0);
-          biasid.push_back(m.biasid()[c][p][k]);
+          const vectori& dv = m.defid()[c][p]; const vectori& bv = m.biasid()[c][p];
+          defid.push_back(p && k < dv.size() ? dv[k] : 0);
+          biasid.push_back(bv.empty() ? 0 : bv[std::min(k, bv.size() - 1)]);
         }
         mix_offset.push_back((int32_t)filterid.size());
       }

@@ -9,6 +9,7 @@ produces (matlab/learning/buildmodel.m:19-80): see SURVEY.md §8(d).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List
 
@@ -88,6 +89,91 @@ class Model:
                     f.write(np.asarray(self.filterid[c][p], np.int32).tobytes())
                     f.write(np.asarray(d, np.int32).tobytes())
                     f.write(np.asarray(b, np.int32).tobytes())
+
+    @staticmethod
+    def load(path: str) -> "Model":
+        """Read the flat dump written by `save` / pbd::BinaryModel::serialize / pbd_modelconv."""
+        import struct
+        with open(path, "rb") as f:
+            if f.read(8) != b"PBDMODL1":
+                raise ValueError("not a PBDMODL1 file")
+            nf, kh, kw, flen, norient, sbin, interval, ndefs, nbias, ncomp, _, _ = struct.unpack("<12i", f.read(48))
+            thresh = struct.unpack("<f", f.read(4))[0]
+            filt = [np.frombuffer(f.read(kh * kw * flen * 4), np.float32).reshape(kh, kw * flen).copy() for _ in range(nf)]
+            defw = np.frombuffer(f.read(ndefs * 16), np.float32).reshape(ndefs, 4).copy()
+            anchors = np.frombuffer(f.read(ndefs * 8), np.int32).reshape(ndefs, 2).copy()
+            biasw = np.frombuffer(f.read(nbias * 4), np.float32).copy()
+            filterid, defid, biasid, parentid = [], [], [], []
+            for _c in range(ncomp):
+                npart = struct.unpack("<i", f.read(4))[0]
+                fi, di, bi, pa = [], [], [], []
+                for p in range(npart):
+                    par, k = struct.unpack("<2i", f.read(8))
+                    fi.append(np.frombuffer(f.read(4 * k), np.int32).tolist())
+                    d = np.frombuffer(f.read(4 * k), np.int32).tolist()
+                    bi.append(np.frombuffer(f.read(4 * k), np.int32).tolist())
+                    di.append(d if p > 0 else [])
+                    pa.append(par)
+                filterid.append(fi); defid.append(di); biasid.append(bi); parentid.append(pa)
+        return Model(filt, biasw, anchors, defw, filterid, biasid, defid, parentid, interval, thresh, sbin, norient,
+                     flen, os.path.basename(path))
+
+    def save_filestorage(self, path: str) -> None:
+        """Write the reference's on-disk format (cv::FileStorage layout of
+        FileStorageModel::serialize, src/FileStorageModel.cpp:42-94) as OpenCV 2.4 emits it:
+        XML for .xml, YAML for .yaml/.yml.  Used to exercise pbd::FileStorageModel::deserialize."""
+        num = lambda v: (repr(float(np.float32(v))).replace("e-0", "e-0") if float(v) != int(v) else f"{int(v)}.")
+        xml = path.endswith(".xml")
+        o = []
+        if xml:
+            o += ['<?xml version="1.0"?>', "<opencv_storage>", f"<name>{self.name}</name>", f"<interval>{self.interval}</interval>",
+                  f"<thresh>{num(self.thresh)}</thresh>", f"<sbin>{self.sbin}</sbin>", f"<norient>{self.norient}</norient>",
+                  f"<flen>{self.flen}</flen>", "<filtersw>"]
+            for w in self.filtersw:
+                data = " ".join(num(v) for v in w.ravel())
+                o += ['  <_ type_id="opencv-matrix">', f"    <rows>{w.shape[0]}</rows>", f"    <cols>{w.shape[1]}</cols>",
+                      "    <dt>d</dt>", "    <data>", "      " + data + "</data></_>"]
+            o += ["</filtersw>", "<biasw>", "  " + " ".join(num(v) for v in self.biasw) + "</biasw>", "<anchors>"]
+            for a in np.asarray(self.anchors).reshape(-1, 2):
+                o += ["  <_>", f"    {int(a[0])} {int(a[1])}</_>"]
+            o += ["</anchors>", "<defs>"]
+            for d in np.asarray(self.defw).reshape(-1, 4):
+                o += ["  <_>", "    " + " ".join(num(v) for v in d) + "</_>"]
+            o += ["</defs>", "<indexers>"]
+            for c in range(self.ncomponents):
+                o.append(f"  <component-{c}>")
+                for p in range(self.nparts(c)):
+                    di = self.defid[c][p] if p > 0 else []
+                    o += [f"    <part-{p}>", f"      <parentid>{self.parentid[c][p] if p > 0 else 0}</parentid>",
+                          "      <filterid>" + " ".join(map(str, self.filterid[c][p])) + "</filterid>",
+                          "      <biasid>" + " ".join(map(str, self.biasid[c][p])) + "</biasid>",
+                          "      <defid>" + " ".join(map(str, di)) + f"</defid></part-{p}>"]
+                o.append(f"  </component-{c}>")
+            o += ["</indexers>", "</opencv_storage>"]
+        else:
+            def flow(vals, per=8, ind="       "):
+                vals = list(vals)
+                rows = [", ".join(vals[i:i + per]) for i in range(0, len(vals), per)]
+                return "[ " + (",\n" + ind).join(rows) + " ]"
+            o += ["%YAML:1.0", f"name: {self.name}", f"interval: {self.interval}", f"thresh: {num(self.thresh)}",
+                  f"sbin: {self.sbin}", f"norient: {self.norient}", f"flen: {self.flen}", "filtersw:"]
+            for w in self.filtersw:
+                o += ["   - !!opencv-matrix", f"      rows: {w.shape[0]}", f"      cols: {w.shape[1]}", "      dt: d",
+                      "      data: " + flow([num(v) for v in w.ravel()], 6, "          ")]
+            o += ["biasw: " + flow([num(v) for v in self.biasw]), "anchors:"]
+            o += [f"   - [ {int(a[0])}, {int(a[1])} ]" for a in np.asarray(self.anchors).reshape(-1, 2)]
+            o += ["defs:"] + ["   - " + flow([num(v) for v in d]) for d in np.asarray(self.defw).reshape(-1, 4)]
+            o += ["indexers:"]
+            for c in range(self.ncomponents):
+                o.append(f"   component-{c}:")
+                for p in range(self.nparts(c)):
+                    di = self.defid[c][p] if p > 0 else []
+                    o += [f"      part-{p}:", f"         parentid: {self.parentid[c][p] if p > 0 else 0}",
+                          "         filterid: [ " + ", ".join(map(str, self.filterid[c][p])) + " ]",
+                          "         biasid: [ " + ", ".join(map(str, self.biasid[c][p])) + " ]",
+                          "         defid: [ " + ", ".join(map(str, di)) + " ]"]
+        with open(path, "w") as f:
+            f.write("\n".join(o) + "\n")
 
     def to_desc(self) -> pbd_model_desc:
         """Flatten into the C ABI descriptor (arrays kept alive on self)."""

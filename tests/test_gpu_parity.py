@@ -405,9 +405,10 @@ def test_cpp_host_demo_matches_oracle(gpu_required, orc, tmp_path):
     m.thresh = thresh_from_oracle(orc, m, im, 99.5)
     m.save(str(tmp_path / "model.bin"))
     im.tofile(str(tmp_path / "im.raw"))
+    m.save_filestorage(str(tmp_path / "model.xml"))   # the reference's own format, read by pbd::FileStorageModel
     heads, boxes, _ = orc.candidates_sort(*orc.detect(m, im)[:3])
-    for extra in ([], ["stagewise"]):
-        out = subprocess.run([exe, str(tmp_path / "model.bin"), str(tmp_path / "im.raw"), "200", "150", "3"] + extra,
+    for mf, extra in (("model.bin", []), ("model.bin", ["stagewise"]), ("model.xml", [])):
+        out = subprocess.run([exe, str(tmp_path / mf), str(tmp_path / "im.raw"), "200", "150", "3"] + extra,
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         lines = out.stdout.strip().splitlines()
