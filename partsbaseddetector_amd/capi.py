@@ -27,7 +27,7 @@ EXPORTS = [
     "pbd_set_level_response", "pbd_dp_min", "pbd_get_dp_pointers", "pbd_get_root", "pbd_dp_argmin",
     "pbd_dt2d", "pbd_hog_u8", "pbd_resize_u8", "pbd_pyrdown_u8", "pbd_nms_map",
     "pbd_candidates_sort", "pbd_candidates_nms", "pbd_get_stage_ms", "pbd_set_profiling",
-    "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps",
+    "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps", "pbd_debug_dtw_stats",
 ]
 
 
@@ -76,11 +76,12 @@ class Handle:
     """Owns one pbd_handle (one GPU, one stream)."""
 
     def __init__(self, model, device=0, conv_mode=PBD_CONV_AUTO, max_candidates=4096, dt_correct_ptr=0,
-                 level_begin=0, level_end=0):
+                 level_begin=0, level_end=0, dp_groups=0, dt_mode=0):
         self.L = lib()
         self.model = model
         self.desc = model.to_desc()
-        opt = pbd_options(device, conv_mode, max_candidates, dt_correct_ptr, level_begin, level_end)
+        opt = pbd_options(device, conv_mode, max_candidates, dt_correct_ptr, level_begin, level_end,
+                          (C.c_int32 * 2)(dp_groups, dt_mode))
         self.h = C.c_void_p()
         rc = self.L.pbd_create(C.byref(self.desc), C.byref(opt), C.byref(self.h))
         if rc != PBD_OK:

@@ -418,13 +418,13 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       h->level_group[l] = gcur;
     }
   }
-  std::vector<std::vector<char>> slot_hist;  // slot_init before each round (identical for all groups)
+  int wave_maxlen = 0;
   for (int gi_ = 0; gi_ < PBD_NGROUPS; ++gi_) h->grl[gi_].clear();
   for (size_t r = 0; r < h->rounds.size(); ++r) {
     const std::vector<int>& rnd = h->rounds[r];
     for (int grp = 0; grp < h->ngroups; ++grp) {
     pbd_handle::RoundLaunch R{};
-    std::vector<DtTask> xt, yt;
+    std::vector<DtTask> xt, yt, xwt, ywt;
     for (int l = 0; l < n && !rnd.empty(); ++l) {
       const Level& L = h->lv[l];
       if (!L.active || L.cw == 0 || L.ch == 0 || h->level_group[l] != grp) continue;
@@ -455,13 +455,27 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       groups.push_back(gx);
       const int gyi = (int)groups.size();
       groups.push_back(gy);
-      for (int g0 = 0; g0 < gx.nmaps * gx.nlines; g0 += gx.lpb) xt.push_back(DtTask{gxi, g0});
-      for (int g0 = 0; g0 < gy.nmaps * gy.nlines; g0 += gy.lpb) yt.push_back(DtTask{gyi, g0});
+      auto use_wave = [&](int len) { return len <= 512 && h->dt_mode == 2; };
+      auto add_tasks = [&](const DtGroup& g, int gidx, std::vector<DtTask>& lane_t, std::vector<DtTask>& wave_t) {
+        if (use_wave(g.len)) {
+          for (int mi2 = 0; mi2 < g.nmaps; ++mi2)              // 16-line blocks, never straddling a map
+            for (int l0 = 0; l0 < g.nlines; l0 += 16) wave_t.push_back(DtTask{gidx, mi2 * g.nlines + l0});
+          wave_maxlen = std::max(wave_maxlen, g.len);
+        } else {
+          for (int g0 = 0; g0 < g.nmaps * g.nlines; g0 += g.lpb) lane_t.push_back(DtTask{gidx, g0});
+        }
+      };
+      add_tasks(gx, gxi, xt, xwt);
+      add_tasks(gy, gyi, yt, ywt);
     }
     R.xtask0 = (int)tasks.size(); R.nxtasks = (int)xt.size();
     tasks.insert(tasks.end(), xt.begin(), xt.end());
     R.ytask0 = (int)tasks.size(); R.nytasks = (int)yt.size();
     tasks.insert(tasks.end(), yt.begin(), yt.end());
+    R.xw0 = (int)tasks.size(); R.nxw = (int)xwt.size();
+    tasks.insert(tasks.end(), xwt.begin(), xwt.end());
+    R.yw0 = (int)tasks.size(); R.nyw = (int)ywt.size();
+    tasks.insert(tasks.end(), ywt.begin(), ywt.end());
     // reduce waves of this round (slot state is advanced once per wave, after the last group)
     std::vector<char> slot_w = slot_init;
     for (const std::vector<int>& wave : h->red_rounds[r]) {
@@ -508,6 +522,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     if (grp == h->ngroups - 1) slot_init = slot_w;
     }  // groups
   }
+  h->dtw_lds = wave_maxlen ? dtw_lds_bytes(wave_maxlen) : 0;
+  if (h->dtw_lds > 160 * 1024 || wave_maxlen > 512) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the wave-per-line distance transform");
   if ((rc = dev_upload(h, &h->d_dtmaps, maps))) return rc;
   if ((rc = dev_upload(h, &h->d_dtgroups, groups))) return rc;
   if ((rc = dev_upload(h, &h->d_dttasks, tasks))) return rc;
@@ -595,7 +611,9 @@ static int run_dp_min(pbd_handle* h) {
   if (h->ngroups > 1) hipEventRecord(h->ev_fork, h->stream);
   if (h->ngroups == 1) {  // default: one chain of rounds on the handle's stream
     for (auto& R : h->grl[0]) {
+      launch_dt_wave(h->d_dttasks + R.xw0, R.nxw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, h->stream);
       launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
+      launch_dt_wave(h->d_dttasks + R.yw0, R.nyw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, h->stream);
       launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
       for (auto& Wv : R.waves)
         launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
@@ -605,7 +623,9 @@ static int run_dp_min(pbd_handle* h) {
     hipStream_t s = h->gstream[g];
     hipStreamWaitEvent(s, h->ev_fork, 0);
     for (auto& R : h->grl[g]) {
+      launch_dt_wave(h->d_dttasks + R.xw0, R.nxw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, s);
       launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, s);
+      launch_dt_wave(h->d_dttasks + R.yw0, R.nyw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, s);
       launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, s);
       for (auto& Wv : R.waves)
         launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, s);
@@ -718,6 +738,7 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   int rc = ingest_model(h, model);
   if (rc) return rc;
   h->ngroups = std::min(std::max(o.reserved[0], 1), PBD_NGROUPS);
+  h->dt_mode = o.reserved[1];
   h->conv_mode = o.conv_mode;
   if (h->conv_mode == PBD_CONV_AUTO)  // a dense contraction when N x K is GEMM-sized
     h->conv_mode = ((size_t)model->nfilters * model->kh * model->kw * model->flen >= 32 * 800 && model->kh == 5 && model->kw == 5)
@@ -978,9 +999,11 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
   DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget), dt_group(1, 1, cols, rows, budget)};
   std::vector<DtTask> tasks;
-  for (int g0 = 0; g0 < rows; g0 += groups[0].lpb) tasks.push_back(DtTask{0, g0});
+  const bool use_wave_x = h->dt_mode == 2 && cols <= 512 && dtw_lds_bytes(cols) <= 160 * 1024;
+  const bool use_wave_y = h->dt_mode == 2 && rows <= 512 && dtw_lds_bytes(rows) <= 160 * 1024;
+  for (int g0 = 0; g0 < rows; g0 += (use_wave_x ? 16 : groups[0].lpb)) tasks.push_back(DtTask{0, g0});
   const int nx = (int)tasks.size();
-  for (int g0 = 0; g0 < cols; g0 += groups[1].lpb) tasks.push_back(DtTask{1, g0});
+  for (int g0 = 0; g0 < cols; g0 += (use_wave_y ? 16 : groups[1].lpb)) tasks.push_back(DtTask{1, g0});
   DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks; ReduceJob* d_job; ReduceBlock* d_rblk;
   std::vector<ReduceBlock> rblk;
   for (unsigned c0 = 0; c0 < (unsigned)HW; c0 += 256) rblk.push_back(ReduceBlock{0, c0});
@@ -999,8 +1022,10 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_job, &J, sizeof(J), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
-  launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, h->stream);
-  launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, h->stream);
+  if (use_wave_x) launch_dt_wave(d_tasks, nx, d_groups, d_maps, dtw_lds_bytes(cols), h->stream);
+  else launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, h->stream);
+  if (use_wave_y) launch_dt_wave(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, dtw_lds_bytes(rows), h->stream);
+  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, h->stream);
   launch_reduce(d_job, d_rblk, (int)rblk.size(), h->d_biasw, h->opt.dt_correct_ptr, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_out, HW * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1183,6 +1208,7 @@ int pbd_get_work(const pbd_handle* h, double work[6]) {
 int pbd_debug_dt_stamps(unsigned long long* out) { dt_debug_read(out); return PBD_OK; }
 int pbd_debug_hog_stamps(unsigned long long* out) { hog_debug_read(out); return PBD_OK; }
 int pbd_debug_conv_stamps(unsigned long long* out) { conv_debug_read(out); return PBD_OK; }
+int pbd_debug_dtw_stats(unsigned long long* out, int reset) { dtw_stats_read(out, reset); return PBD_OK; }
 
 int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes) {
   if (!h) return PBD_ERR_ARG;
