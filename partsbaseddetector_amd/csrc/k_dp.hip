@@ -30,10 +30,12 @@ __device__ unsigned long long pbd_dt_dbg[8];
 #define DT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pbd_dt_dbg[i] = wall_clock64(); } while (0)
 void dt_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_dt_dbg), sizeof(unsigned long long) * 8); }
 
-// LDS per block: 64 line pointers + 64 stack sizes + per line {Y, Z : float[S]; V, P : u16[S]}
-// + per map touched by the block a table of exact reciprocals 1/(2a*dx), dx < len (double[S]).
+// LDS per block: 64 line pointers + 64 stack sizes + per line {(Y, Z) : float2[S]; V : u8[S] (S <= 256) or
+// u16[S]} + per map touched by the block a table of exact reciprocals 1/(2a*dx), dx < len (double[S]).
+// The envelope scan is VALU-issue bound with one lane per line, and the lines resident on a CU are
+// bounded by these bytes: every byte saved per element is more active lanes per wavefront.
 size_t dt_lds_bytes(int stride, int lpb, int nmb) {
-  return (size_t)lpb * stride * (4 + 4 + 2 + 2) + 64 * (8 + 8 + 4 + 4) + (size_t)nmb * stride * 8 + 8;
+  return (size_t)lpb * stride * (4 + 4 + (stride <= 256 ? 1 : 2)) + 64 * (8 + 8 + 4 + 4) + (size_t)nmb * stride * 8 + 16;
 }
 
 // Envelope scan of one line (DistanceTransform.hpp:156-170), one lane per line.
@@ -59,8 +61,8 @@ size_t dt_lds_bytes(int stride, int lpb, int nmb) {
 // at its end), stores (y,z) of an entry as one 8-byte LDS word, and issues the push stores
 // unconditionally to slot k+1 (dead when the step pops).  The y of stack entry k overwrites the
 // consumed line element k in place (k <= q).
-template <bool EXACT>
-__device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, unsigned short* __restrict__ Vl,
+template <bool EXACT, typename VT>
+__device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, VT* __restrict__ Vl,
                                             const double* __restrict__ Rl, int len, double a, double b, int* kout) {
   const double twoa = 2 * a;
   const double r1 = Rl[1 < len ? 1 : 0];
@@ -68,7 +70,7 @@ __device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, unsigned s
   float zk = -INFINITY, nz = -INFINITY;
   double yk = (double)YZl[0].x, ny = 0.0;
   double r_top = r1;
-  unsigned suspect = 0;
+  unsigned suspect = 0;             // sticky: a quotient landed next to a float rounding boundary
   Vl[0] = 0;
   YZl[0].y = -INFINITY;
   float yq_f = YZl[min(1, len - 1)].x;
@@ -83,7 +85,7 @@ __device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, unsigned s
     const int dx = q - vk;
     const double yq = (double)yq_f;
     const double dxd = (double)dx;
-    const double num = ((yq - yk) - b * dxd) + a * (double)(dx * (q + vk));
+    const double num = ((yq - yk) - b * dxd) + a * (double)__mul24(dx, q + vk);   // x1^2 - x0^2 < 2^31, operands < 2^16
     const double den = twoa * dxd;
     double q1;
     if (EXACT) {
@@ -95,12 +97,12 @@ __device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, unsigned s
       const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
       const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
       const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-      suspect |= (unsigned)((lo29 - 0x0FFFFFFFu) <= 2u) | (unsigned)((ex - 897u) > 252u);
+      suspect = (((lo29 - 0x0FFFFFFFu) <= 2u) | ((ex - 897u) > 252u)) ? 1u : suspect;   // one v_cndmask
     }
     const float s = (float)q1;
     const bool pop = (s <= zk) && (k > 0);  // :162
     // push stores (:166-169); slot k+1 is dead if this step pops
-    Vl[k + 1] = (unsigned short)q;
+    Vl[k + 1] = (VT)q;
     YZl[k + 1] = make_float2(yq_f, s);
     // state update, selects only
     const int vk_o = vk; const double yk_o = yk; const float zk_o = zk;
@@ -122,12 +124,8 @@ __device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, unsigned s
 // One block = one wavefront = up to g.lpb lines of one group (lpb chosen per group so that every
 // block of the launch fits the same LDS budget: long lines -> fewer lines per block -> many more
 // blocks, so a whole pass is resident at once and all 4 SIMDs of every CU carry chains).
-__global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks, const DtGroup* __restrict__ groups,
-                                                const DtMap* __restrict__ maps) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  DT_STAMP(0);
-  const DtTask t = tasks[blockIdx.x];
-  const DtGroup g = groups[t.group];
+template <typename VT>
+__device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps) {
   const int lane = threadIdx.x;
   const int len = g.len, S = g.stride, lpb = g.lpb;
   const float** lptr = (const float**)smem;   // [64] source pointer of each line of this block
@@ -140,8 +138,7 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
   const int m_first = t.g0 / g.nlines, m_last = (t.g0 + nl - 1) / g.nlines;
   const int nmb = m_last - m_first + 1;
   float2* YZ = (float2*)(R + g.nmb * S);      // [lpb][S] .x: line values, then y of stack entries (in place); .y: z[k]
-  unsigned short* V = (unsigned short*)(YZ + lpb * S);  // [lpb][S] v[k]
-  unsigned short* P = V + lpb * S;            // [lpb][S] arg-max pointer per output (natural-layout staging)
+  VT* V = (VT*)(YZ + lpb * S);                // [lpb][S] v[k]
   if (lane < nl) {
     const int gi = t.g0 + lane;
     const int mi = gi / g.nlines, li = gi - mi * g.nlines;
@@ -194,13 +191,13 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
     const DtMap mp = maps[g.map0 + mi];
     const double* Rl = R + (mi - m_first) * S;
     float2* YZl = YZ + lane * S;
-    unsigned short* Vl = V + lane * S;
+    VT* Vl = V + lane * S;
     int k;
-    if (dt_envelope<false>(YZl, Vl, Rl, len, mp.a, mp.b, &k)) {
+    if (dt_envelope<false, VT>(YZl, Vl, Rl, len, mp.a, mp.b, &k)) {
       // a quotient landed within 1 ulp of a float rounding boundary: redo this line with true divisions
       const float* src = lptr[lane];
       for (int q = 0; q < len; ++q) YZl[q].x = src[q];
-      dt_envelope<true>(YZl, Vl, Rl, len, mp.a, mp.b, &k);
+      dt_envelope<true, VT>(YZl, Vl, Rl, len, mp.a, mp.b, &k);
     }
     YZl[k + 1].y = INFINITY;
     Ksz[lane] = k;
@@ -211,17 +208,21 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
   // ---- read out (:172-178) ----
   // Output q of a line depends only on the finished stack, so the 64/lpb idle lane groups share a
   // line: sub-range r of the outputs starts from a binary search for its first stack entry.
+  // Scores go out transposed (lanes of one sub-range = consecutive lines -> coalesced); pointers go
+  // straight to their plane: transposed like the scores in the y pass, natural (2-byte runs per lane,
+  // merged in L2) in the x pass — no LDS staging, that space holds more lines instead.
   {
-    const int nsub = 64 / lpb;              // lpb is a power of two <= 64
+    const int nsub = 64 / lpb;
     const int line = lane % lpb, sub = lane / lpb;
-    if (line < nl) {
+    if (line < nl && sub < nsub) {
       const int gi = t.g0 + line;
       const int mi = gi / g.nlines, li = gi - mi * g.nlines;
       const DtMap mp = maps[g.map0 + mi];
       const double a = mp.a, b = mp.b;
       const float2* YZl = YZ + line * S;
-      const unsigned short* Vl = V + line * S;
-      unsigned short* Pl = P + line * S;
+      const VT* Vl = V + line * S;
+      int16_t* pp = pptr[line];
+      const int pst = pstr[line];
       const int K = Ksz[line];
       const int chunk = (len + nsub - 1) / nsub;
       const int q0 = sub * chunk, q1 = min(len, q0 + chunk);
@@ -244,22 +245,24 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
           while (zn < fos) { k++; zn = YZl[k + 1].y; vk = Vl[k]; yk = YZl[k].x; }
           const int d = os - vk;
           dst[(size_t)q * nlines] = (float)(a * (double)(d * d) + b * (double)d + (double)yk);
-          Pl[q] = (unsigned short)vk;
+          pp[(size_t)q * pst] = (int16_t)vk;
           os++;
         }
       }
     }
   }
-  __syncthreads();
   DT_STAMP(4);
-  // ---- pointer planes: all addressing comes from LDS (no dependent global loads in the loop) ----
-  for (int i = 0; i < nl; ++i) {
-    int16_t* ptr = pptr[i];
-    const int st = pstr[i];
-    const unsigned short* Pl = P + i * S;
-    for (int q = lane; q < len; q += 64) ptr[(size_t)q * st] = (int16_t)Pl[q];
-  }
   DT_STAMP(5);
+}
+
+__global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks, const DtGroup* __restrict__ groups,
+                                                const DtMap* __restrict__ maps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DT_STAMP(0);
+  const DtTask t = tasks[blockIdx.x];
+  const DtGroup g = groups[t.group];
+  if (g.stride <= 256) dt_block<unsigned char>(smem, t, g, maps);    // stack indices < 255 fit a byte
+  else dt_block<unsigned short>(smem, t, g, maps);
 }
 
 void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,

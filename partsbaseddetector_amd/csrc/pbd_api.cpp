@@ -286,13 +286,14 @@ static void free_frame(pbd_handle* h) {
 }
 
 // DT block geometry under an LDS budget.  stride = len+1 rounded up to even (keeps the double
-// table and the float arrays 8-byte aligned); lpb = lines per block (power of two, 8..64);
+// table and the float arrays 8-byte aligned); lpb = lines per block (any value 8..64: the scan runs
+// one lane per line and is VALU-issue bound, so lanes per wave = throughput);
 // nmb = maps a block of lpb consecutive lines can touch.
 static int dt_stride_for(int len) { return (len + 2) & ~1; }
 static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (lpb + nlines - 2) / nlines + 1); }
 static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget) {
   int lpb = 64;
-  while (lpb > 8 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps)) > budget) lpb /= 2;
+  while (lpb > 8 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps)) > budget) --lpb;
   return lpb;
 }
 static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget) {
@@ -383,7 +384,9 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   // DT LDS budget: ~36 KB per block (4 blocks per CU) unless the longest line needs more at 8 lines/block
   int maxlen = 1;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
-  size_t dt_budget = std::max<size_t>(36 * 1024, dt_lds_bytes(dt_stride_for(maxlen), 8, 2));
+  size_t dt_base = 24 * 1024;   // 6 one-wave blocks per CU: measured optimum on MI355X (16..53 KB swept)
+  if (const char* e = getenv("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
+  size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 8, 2));
   if (dt_budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
   h->dt_lds = dt_budget;
   std::vector<DtMap> maps;
@@ -467,6 +470,11 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       };
       add_tasks(gx, gxi, xt, xwt);
       add_tasks(gy, gyi, yt, ywt);
+    }
+    if (const char* e = getenv("PBD_DEBUG_DUP")) {   // scaling probe: every DT block issued n times (identical outputs)
+      const int ndup = atoi(e);
+      const std::vector<DtTask> x0 = xt, y0 = yt;
+      for (int i = 1; i < ndup; ++i) { xt.insert(xt.end(), x0.begin(), x0.end()); yt.insert(yt.end(), y0.begin(), y0.end()); }
     }
     R.xtask0 = (int)tasks.size(); R.nxtasks = (int)xt.size();
     tasks.insert(tasks.end(), xt.begin(), xt.end());
@@ -995,7 +1003,7 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   HIPCHK(h, hipMemcpyAsync(d_in, in, HW * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(d_zero, 0, HW * 4, h->stream));
   DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
-  const size_t budget = std::max<size_t>(36 * 1024, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 8, 1));
+  const size_t budget = std::max<size_t>(40 * 1024, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 8, 1));
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
   DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget), dt_group(1, 1, cols, rows, budget)};
   std::vector<DtTask> tasks;
