@@ -80,6 +80,13 @@ enum {
                          bit-identical to src/filter.cpp:3899-3922 + pdf+=pdfc */
   PBD_CONV_MFMA = 2   /* fp32 MFMA implicit GEMM (k-ordered fma chain)          */
 };
+/* Scalar type T of the instantiation (src/PartsBasedDetector.cpp:132-133):
+ * PartsBasedDetector<float> (src/demo.cpp:85) or PartsBasedDetector<double>
+ * (ros/Node.hpp:121, cells/detect.cpp:93).  Features, responses, scores and
+ * the distance transform are computed and stored in T; model weights stay
+ * float and are widened where the reference widens them; candidates carry
+ * float scores for both (include/Candidate.hpp:72).                          */
+enum { PBD_SCALAR_F32 = 0, PBD_SCALAR_F64 = 1 };
 typedef struct pbd_options {
   int32_t device;        /* HIP device ordinal                                 */
   int32_t conv_mode;     /* PBD_CONV_*                                         */
@@ -89,6 +96,9 @@ typedef struct pbd_options {
                             arg-max composition                                */
   int32_t level_begin;   /* process pyramid levels [level_begin, level_end)    */
   int32_t level_end;     /* <=0: all levels (multi-GPU level sharding)         */
+  int32_t scalar_type;   /* PBD_SCALAR_F32 (default) or PBD_SCALAR_F64; a double
+                            handle runs PBD_CONV_EXACT and answers the *_f64
+                            stage entry points instead of the float ones       */
   int32_t reserved[2];   /* [0]: DP level groups on separate streams (0/1 = one chain, max 3)
                             [1]: distance transform kernel: 0/1 lane-per-line (default), 2 the
                                  experimental wave-per-line kernel (lines <= 512 elements)          */
@@ -153,18 +163,23 @@ int pbd_pyramid_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
 int pbd_get_level_image(pbd_handle* h, int level, uint8_t* out /* img_h*img_w*cn */);
 int pbd_get_level_features(pbd_handle* h, int level, float* out /* cell_h*cell_w*flen */);
 int pbd_set_level_features(pbd_handle* h, int level, const float* in);
+int pbd_get_level_features_f64(pbd_handle* h, int level, double* out);
+int pbd_set_level_features_f64(pbd_handle* h, int level, const double* in);
 /* declare a frame geometry without running the pyramid (inject features)     */
 int pbd_begin_frame(pbd_handle* h, int w, int hgt, int cn);
 /* SpatialConvolutionEngine::pdf (src/SpatialConvolutionEngine.cpp:106-124)   */
 int pbd_pdf(pbd_handle* h);
 int pbd_get_level_response(pbd_handle* h, int level, int filter, float* out /* cell_h*cell_w */);
 int pbd_set_level_response(pbd_handle* h, int level, int filter, const float* in);
+int pbd_get_level_response_f64(pbd_handle* h, int level, int filter, double* out);
+int pbd_set_level_response_f64(pbd_handle* h, int level, int filter, const double* in);
 /* DynamicProgram<T>::min (src/DynamicProgram.cpp:66-173)                      */
 int pbd_dp_min(pbd_handle* h);
 /* Ix/Iy/Ik[level][component][part][parent mixture] as int32 cell_h*cell_w     */
 int pbd_get_dp_pointers(pbd_handle* h, int level, int component, int part, int parent_mix,
                         int32_t* ix, int32_t* iy, int32_t* ik);
 int pbd_get_root(pbd_handle* h, int level, int component, float* rootv, int32_t* rooti);
+int pbd_get_root_f64(pbd_handle* h, int level, int component, double* rootv, int32_t* rooti);
 /* DynamicProgram<T>::argmin (src/DynamicProgram.cpp:189-255)                  */
 int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
                   int capacity, int* count);
@@ -175,9 +190,14 @@ int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int3
 int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols,
              double ax, double bx, double ay, double by, int osx, int osy,
              float* out, int32_t* ix, int32_t* iy);
+int pbd_dt2d_f64(pbd_handle* h, const double* in, int rows, int cols,
+                 double ax, double bx, double ay, double by, int osx, int osy,
+                 double* out, int32_t* ix, int32_t* iy);   /* DistanceTransform<double> */
 /* HOGFeatures<T>::features<uint8_t> (src/HOGFeatures.cpp:168-341), one image */
 int pbd_hog_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride,
                float* out, int* cell_w, int* cell_h);
+int pbd_hog_u8_f64(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride,
+                   double* out, int* cell_w, int* cell_h);  /* HOGFeatures<double> */
 /* cv::resize(INTER_LINEAR) / cv::pyrDown on 8-bit images as used at
  * src/HOGFeatures.cpp:116,122 (this library's definition)     */
 int pbd_resize_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride,

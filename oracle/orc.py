@@ -27,19 +27,34 @@ def lib():
         if not os.path.exists(LIB):
             build()
         L = C.CDLL(LIB)
-        for n in ("orc_frame_image", "orc_frame_feat", "orc_frame_resp", "orc_frame_ix", "orc_frame_iy",
-                  "orc_frame_ik", "orc_frame_rootv", "orc_frame_rooti"):
-            getattr(L, n).restype = C.c_void_p
-            getattr(L, n).argtypes = [C.c_void_p, C.c_int]
-        L.orc_frame_free.argtypes = [C.c_void_p]
-        L.orc_frame_nlevels.argtypes = [C.c_void_p]
-        L.orc_frame_dims.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        for sfx in ("", "_f64"):
+            for n in ("orc_frame_image", "orc_frame_feat", "orc_frame_resp", "orc_frame_ix", "orc_frame_iy",
+                      "orc_frame_ik", "orc_frame_rootv", "orc_frame_rooti"):
+                getattr(L, n + sfx).restype = C.c_void_p
+                getattr(L, n + sfx).argtypes = [C.c_void_p, C.c_int]
+            getattr(L, "orc_frame_free" + sfx).argtypes = [C.c_void_p]
+            getattr(L, "orc_frame_nlevels" + sfx).argtypes = [C.c_void_p]
+            getattr(L, "orc_frame_dims" + sfx).argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         _lib = L
     return _lib
 
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _sfx(dtype):
+    """Reference instantiation: np.float32 -> PartsBasedDetector<float> (orc_*), np.float64 -> <double> (orc_*_f64)."""
+    dt = np.dtype(dtype)
+    if dt == np.float32:
+        return ""
+    if dt == np.float64:
+        return "_f64"
+    raise ValueError("dtype must be float32 or float64")
+
+
+def _fn(name, dtype):
+    return getattr(lib(), name + _sfx(dtype))
 
 
 def geometry(w, h, sbin, interval):
@@ -75,43 +90,43 @@ def pyrdown(im):
     return out
 
 
-def hog(im, sbin):
+def hog(im, sbin, dtype=np.float32):
     im = np.ascontiguousarray(im, np.uint8)
     h, w = im.shape[:2]
     cn = _cn(im)
     cw, ch = C.c_int(0), C.c_int(0)
     lib().orc_cells_of(w, h, sbin, C.byref(cw), C.byref(ch))
-    out = np.zeros((ch.value, cw.value, 32), np.float32)
-    rc = lib().orc_hog_u8(_p(im), w, h, cn, w * cn, sbin, _p(out))
+    out = np.zeros((ch.value, cw.value, 32), dtype)
+    rc = _fn("orc_hog_u8", dtype)(_p(im), w, h, cn, w * cn, sbin, _p(out))
     assert rc == 0
     return out
 
 
-def pdf_level(feat, filters):
+def pdf_level(feat, filters, dtype=np.float32):
     """feat [H, W, 32]; filters list of kh x (kw*32) -> [nf, H, W]."""
-    feat = np.ascontiguousarray(feat, np.float32)
+    feat = np.ascontiguousarray(feat, dtype)
     H, W, flen = feat.shape
     filt = np.ascontiguousarray(np.stack(filters).astype(np.float32))
     nf, kh = filt.shape[0], filt.shape[1]
     kw = filt.shape[2] // flen
-    out = np.zeros((nf, H, W), np.float32)
-    lib().orc_pdf_level(_p(feat), H, W, flen, _p(filt), nf, kh, kw, _p(out))
+    out = np.zeros((nf, H, W), dtype)
+    _fn("orc_pdf_level", dtype)(_p(feat), H, W, flen, _p(filt), nf, kh, kw, _p(out))
     return out
 
 
-def dt1d(src, a, b, os_):
-    src = np.ascontiguousarray(src, np.float32)
+def dt1d(src, a, b, os_, dtype=np.float32):
+    src = np.ascontiguousarray(src, dtype)
     dst = np.zeros_like(src)
     ptr = np.zeros(src.shape, np.int32)
-    lib().orc_dt1d(_p(src), _p(dst), _p(ptr), src.shape[0], C.c_double(a), C.c_double(b), os_)
+    _fn("orc_dt1d", dtype)(_p(src), _p(dst), _p(ptr), src.shape[0], C.c_double(a), C.c_double(b), os_)
     return dst, ptr
 
 
-def dt2d(a, ax, bx, ay, by, osx, osy, correct_ptr=0):
-    a = np.ascontiguousarray(a, np.float32)
+def dt2d(a, ax, bx, ay, by, osx, osy, correct_ptr=0, dtype=np.float32):
+    a = np.ascontiguousarray(a, dtype)
     out = np.zeros_like(a)
     ix, iy = np.zeros(a.shape, np.int32), np.zeros(a.shape, np.int32)
-    lib().orc_dt2d(_p(a), a.shape[0], a.shape[1], C.c_double(ax), C.c_double(bx), C.c_double(ay), C.c_double(by),
+    _fn("orc_dt2d", dtype)(_p(a), a.shape[0], a.shape[1], C.c_double(ax), C.c_double(bx), C.c_double(ay), C.c_double(by),
                    osx, osy, _p(out), _p(ix), _p(iy), correct_ptr)
     return out, ix, iy
 
@@ -120,32 +135,32 @@ def ptr_planes(desc, comp):
     return lib().orc_ptr_planes(C.byref(desc), comp)
 
 
-def dp_min_level(desc, comp, resp, correct_ptr=0):
+def dp_min_level(desc, comp, resp, correct_ptr=0, dtype=np.float32):
     """resp [nf, H, W] -> Ix, Iy, Ik [planes, H, W], rootv, rooti [H, W]."""
-    resp = np.ascontiguousarray(resp, np.float32)
+    resp = np.ascontiguousarray(resp, dtype)
     _, H, W = resp.shape
     npl = ptr_planes(desc, comp)
     Ix, Iy, Ik = (np.zeros((npl, H, W), np.int32) for _ in range(3))
-    rv, ri = np.zeros((H, W), np.float32), np.zeros((H, W), np.int32)
-    lib().orc_dp_min_level(C.byref(desc), comp, _p(resp), H, W, _p(Ix), _p(Iy), _p(Ik), _p(rv), _p(ri), correct_ptr)
+    rv, ri = np.zeros((H, W), dtype), np.zeros((H, W), np.int32)
+    _fn("orc_dp_min_level", dtype)(C.byref(desc), comp, _p(resp), H, W, _p(Ix), _p(Iy), _p(Ik), _p(rv), _p(ri), correct_ptr)
     return Ix, Iy, Ik, rv, ri
 
 
 class Frame:
     """Intermediates of one orc_detect_u8 run."""
 
-    def __init__(self, ptr, model):
-        self.ptr, self.model = ptr, model
-        self.nlevels = lib().orc_frame_nlevels(ptr)
+    def __init__(self, ptr, model, dtype=np.float32):
+        self.ptr, self.model, self.dtype = ptr, model, np.dtype(dtype)
+        self.nlevels = _fn("orc_frame_nlevels", dtype)(ptr)
         self.dims = []
         for l in range(self.nlevels):
             v = [C.c_int(0) for _ in range(4)]
             s = C.c_float(0)
-            lib().orc_frame_dims(ptr, l, *[C.addressof(x) for x in v], C.addressof(s))
+            _fn("orc_frame_dims", dtype)(ptr, l, *[C.addressof(x) for x in v], C.addressof(s))
             self.dims.append(tuple(x.value for x in v) + (s.value,))
 
     def _arr(self, fn, l, shape, dtype):
-        p = getattr(lib(), fn)(self.ptr, l)
+        p = _fn(fn, self.dtype)(self.ptr, l)
         n = int(np.prod(shape))
         if n == 0:
             return np.zeros(shape, dtype)
@@ -157,10 +172,10 @@ class Frame:
         return self._arr("orc_frame_image", l, (ih, iw) + ((cn,) if cn > 1 else ()), np.uint8)
 
     def feat(self, l):
-        return self._arr("orc_frame_feat", l, (self.dims[l][3], self.dims[l][2], 32), np.float32)
+        return self._arr("orc_frame_feat", l, (self.dims[l][3], self.dims[l][2], 32), self.dtype)
 
     def resp(self, l):
-        return self._arr("orc_frame_resp", l, (len(self.model.filtersw), self.dims[l][3], self.dims[l][2]), np.float32)
+        return self._arr("orc_frame_resp", l, (len(self.model.filtersw), self.dims[l][3], self.dims[l][2]), self.dtype)
 
     def pointers(self, l, total_planes):
         sh = (total_planes, self.dims[l][3], self.dims[l][2])
@@ -168,19 +183,19 @@ class Frame:
 
     def root(self, l):
         sh = (self.model.ncomponents, self.dims[l][3], self.dims[l][2])
-        return self._arr("orc_frame_rootv", l, sh, np.float32), self._arr("orc_frame_rooti", l, sh, np.int32)
+        return self._arr("orc_frame_rootv", l, sh, self.dtype), self._arr("orc_frame_rooti", l, sh, np.int32)
 
     def free(self):
         if self.ptr:
-            lib().orc_frame_free(self.ptr)
+            _fn("orc_frame_free", self.dtype)(self.ptr)
             self.ptr = None
 
     def __del__(self):
         self.free()
 
 
-def detect(model, im, capacity=8192, keep=False, correct_ptr=0, desc=None):
-    """orc_detect_u8 -> (heads, boxes, locs, stage_ms[, Frame])."""
+def detect(model, im, capacity=8192, keep=False, correct_ptr=0, desc=None, dtype=np.float32):
+    """orc_detect_u8[_f64] -> (heads, boxes, locs, stage_ms[, Frame])."""
     im = np.ascontiguousarray(im, np.uint8)
     h, w = im.shape[:2]
     cn = _cn(im)
@@ -192,14 +207,14 @@ def detect(model, im, capacity=8192, keep=False, correct_ptr=0, desc=None):
     cnt = C.c_int(0)
     ms = (C.c_double * 5)()
     fp = C.c_void_p()
-    rc = lib().orc_detect_u8(C.byref(desc), _p(im), w, h, cn, w * cn, _p(heads), _p(boxes), _p(locs), capacity,
+    rc = _fn("orc_detect_u8", dtype)(C.byref(desc), _p(im), w, h, cn, w * cn, _p(heads), _p(boxes), _p(locs), capacity,
                              C.byref(cnt), ms, C.byref(fp) if keep else None, correct_ptr)
     if rc:
         raise ValueError("orc_detect_u8 failed (image too small?)")
     n = min(cnt.value, capacity)
     res = (heads[:n].copy(), boxes[:n].copy(), locs[:n].copy(), list(ms))
     if keep:
-        return res + (Frame(fp, model),)
+        return res + (Frame(fp, model, dtype),)
     return res
 
 

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libpbd_hip.so")
 
 PBD_OK, PBD_ERR_ARG, PBD_ERR_UNSUPPORTED, PBD_ERR_CAPACITY, PBD_ERR_HIP, PBD_ERR_STATE = range(6)
 PBD_CONV_AUTO, PBD_CONV_EXACT, PBD_CONV_MFMA = 0, 1, 2
+PBD_SCALAR_F32, PBD_SCALAR_F64 = 0, 1
 
 EXPORTS = [
     "pbd_create", "pbd_destroy", "pbd_last_error", "pbd_max_parts", "pbd_set_stream",
@@ -26,6 +27,8 @@ EXPORTS = [
     "pbd_set_level_features", "pbd_begin_frame", "pbd_pdf", "pbd_get_level_response",
     "pbd_set_level_response", "pbd_dp_min", "pbd_get_dp_pointers", "pbd_get_root", "pbd_dp_argmin",
     "pbd_dt2d", "pbd_hog_u8", "pbd_resize_u8", "pbd_pyrdown_u8", "pbd_nms_map",
+    "pbd_get_level_features_f64", "pbd_set_level_features_f64", "pbd_get_level_response_f64",
+    "pbd_set_level_response_f64", "pbd_get_root_f64", "pbd_dt2d_f64", "pbd_hog_u8_f64",
     "pbd_candidates_sort", "pbd_candidates_nms", "pbd_get_stage_ms", "pbd_set_profiling",
     "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps", "pbd_debug_dtw_stats",
 ]
@@ -34,7 +37,7 @@ EXPORTS = [
 class pbd_options(C.Structure):
     _fields_ = [("device", C.c_int32), ("conv_mode", C.c_int32), ("max_candidates", C.c_int32),
                 ("dt_correct_ptr", C.c_int32), ("level_begin", C.c_int32), ("level_end", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("scalar_type", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class pbd_candidate_head(C.Structure):
@@ -76,12 +79,18 @@ class Handle:
     """Owns one pbd_handle (one GPU, one stream)."""
 
     def __init__(self, model, device=0, conv_mode=PBD_CONV_AUTO, max_candidates=4096, dt_correct_ptr=0,
-                 level_begin=0, level_end=0, dp_groups=0, dt_mode=0):
+                 level_begin=0, level_end=0, dp_groups=0, dt_mode=0, dtype=np.float32):
+        """dtype: np.float32 = PartsBasedDetector<float>, np.float64 = PartsBasedDetector<double>."""
         self.L = lib()
         self.model = model
         self.desc = model.to_desc()
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError("dtype must be float32 or float64")
+        self._f64 = self.dtype == np.dtype(np.float64)
+        self._ct = C.c_double if self._f64 else C.c_float
         opt = pbd_options(device, conv_mode, max_candidates, dt_correct_ptr, level_begin, level_end,
-                          (C.c_int32 * 2)(dp_groups, dt_mode))
+                          PBD_SCALAR_F64 if self._f64 else PBD_SCALAR_F32, (C.c_int32 * 2)(dp_groups, dt_mode))
         self.h = C.c_void_p()
         rc = self.L.pbd_create(C.byref(self.desc), C.byref(opt), C.byref(self.h))
         if rc != PBD_OK:
@@ -102,6 +111,10 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+    def _fn(self, name):
+        """Stage entry point of this handle's instantiation (name or name_f64)."""
+        return getattr(self.L, name + ("_f64" if self._f64 else ""))
 
     def _chk(self, rc):
         if rc != PBD_OK:
@@ -181,26 +194,26 @@ class Handle:
 
     def level_features(self, l):
         g = self._geo
-        out = np.zeros((g["cell_h"][l], g["cell_w"][l], 32), np.float32)
-        self._chk(self.L.pbd_get_level_features(self.h, l, _p(out, C.c_float)))
+        out = np.zeros((g["cell_h"][l], g["cell_w"][l], 32), self.dtype)
+        self._chk(self._fn("pbd_get_level_features")(self.h, l, _p(out, self._ct)))
         return out
 
     def set_level_features(self, l, f):
-        f = np.ascontiguousarray(f, np.float32)
-        self._chk(self.L.pbd_set_level_features(self.h, l, _p(f, C.c_float)))
+        f = np.ascontiguousarray(f, self.dtype)
+        self._chk(self._fn("pbd_set_level_features")(self.h, l, _p(f, self._ct)))
 
     def pdf(self):
         self._chk(self.L.pbd_pdf(self.h))
 
     def level_response(self, l, n):
         g = self._geo
-        out = np.zeros((g["cell_h"][l], g["cell_w"][l]), np.float32)
-        self._chk(self.L.pbd_get_level_response(self.h, l, n, _p(out, C.c_float)))
+        out = np.zeros((g["cell_h"][l], g["cell_w"][l]), self.dtype)
+        self._chk(self._fn("pbd_get_level_response")(self.h, l, n, _p(out, self._ct)))
         return out
 
     def set_level_response(self, l, n, r):
-        r = np.ascontiguousarray(r, np.float32)
-        self._chk(self.L.pbd_set_level_response(self.h, l, n, _p(r, C.c_float)))
+        r = np.ascontiguousarray(r, self.dtype)
+        self._chk(self._fn("pbd_set_level_response")(self.h, l, n, _p(r, self._ct)))
 
     def dp_min(self):
         self._chk(self.L.pbd_dp_min(self.h))
@@ -216,8 +229,8 @@ class Handle:
     def root(self, l, c):
         g = self._geo
         sh = (g["cell_h"][l], g["cell_w"][l])
-        rv, ri = np.zeros(sh, np.float32), np.zeros(sh, np.int32)
-        self._chk(self.L.pbd_get_root(self.h, l, c, _p(rv, C.c_float), _p(ri, C.c_int32)))
+        rv, ri = np.zeros(sh, self.dtype), np.zeros(sh, np.int32)
+        self._chk(self._fn("pbd_get_root")(self.h, l, c, _p(rv, self._ct), _p(ri, C.c_int32)))
         return rv, ri
 
     def dp_argmin(self, capacity=4096):
@@ -229,12 +242,12 @@ class Handle:
 
     # ---- primitives ----------------------------------------------------------------
     def dt2d(self, a: np.ndarray, ax, bx, ay, by, osx, osy):
-        a = np.ascontiguousarray(a, np.float32)
+        a = np.ascontiguousarray(a, self.dtype)
         out = np.zeros_like(a)
         ix, iy = np.zeros(a.shape, np.int32), np.zeros(a.shape, np.int32)
-        self._chk(self.L.pbd_dt2d(self.h, _p(a, C.c_float), a.shape[0], a.shape[1], C.c_double(ax), C.c_double(bx),
-                                  C.c_double(ay), C.c_double(by), osx, osy, _p(out, C.c_float), _p(ix, C.c_int32),
-                                  _p(iy, C.c_int32)))
+        self._chk(self._fn("pbd_dt2d")(self.h, _p(a, self._ct), a.shape[0], a.shape[1], C.c_double(ax), C.c_double(bx),
+                                       C.c_double(ay), C.c_double(by), osx, osy, _p(out, self._ct), _p(ix, C.c_int32),
+                                       _p(iy, C.c_int32)))
         return out, ix, iy
 
     def hog(self, im: np.ndarray):
@@ -242,10 +255,10 @@ class Handle:
         hgt, w = im.shape[:2]
         cn = 1 if im.ndim == 2 else im.shape[2]
         sb = self.model.sbin
-        buf = np.zeros((hgt // sb + 2) * (w // sb + 2) * 32, np.float32)
+        buf = np.zeros((hgt // sb + 2) * (w // sb + 2) * 32, self.dtype)
         a, b = C.c_int(0), C.c_int(0)
-        self._chk(self.L.pbd_hog_u8(self.h, _p(im, C.c_uint8), w, hgt, cn, w * cn, _p(buf, C.c_float), C.byref(a),
-                                    C.byref(b)))
+        self._chk(self._fn("pbd_hog_u8")(self.h, _p(im, C.c_uint8), w, hgt, cn, w * cn, _p(buf, self._ct), C.byref(a),
+                                         C.byref(b)))
         return buf[: b.value * a.value * 32].reshape(b.value, a.value, 32).copy()
 
     def resize(self, im: np.ndarray, ow, oh):

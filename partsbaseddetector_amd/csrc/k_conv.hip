@@ -59,44 +59,81 @@ __device__ __forceinline__ void stage_feature_tile(float* __restrict__ ft, const
   }
 }
 
-template <int KH, int KW>
+// Same staging for any scalar type: 16-byte vectors (float4 / double2), LPC lanes per cell.
+template <typename T, int KH, int KW>
+__device__ __forceinline__ void stage_feature_tile_t(T* __restrict__ ft, const T* __restrict__ F, int y0, int x0,
+                                                     int H, int W, int tid) {
+  constexpr int EPV = 16 / (int)sizeof(T), LPC = PBD_FLEN / EPV;
+  constexpr int TW = CT + KW - 1, TH = CT + KH - 1, N = TH * TW * LPC, NB = (N + 255) / 256;
+  struct alignas(16) V { T e[EPV]; };
+  constexpr int BATCH = 8;
+  for (int j0 = 0; j0 < NB; j0 += BATCH) {
+    V r[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int i = min(tid + (j0 + j) * 256, N - 1);
+      const int cell = i / LPC, q = i - cell * LPC;
+      const int ty = cell / TW, tx = cell - ty * TW;
+      const int y = min(max(y0 + ty - KH / 2, 0), H - 1), x = min(max(x0 + tx - KW / 2, 0), W - 1);
+      r[j] = *(const V*)(F + ((size_t)y * W + x) * PBD_FLEN + q * EPV);
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int i = tid + (j0 + j) * 256;
+      if (i < N) {
+        const int cell = i / LPC, q = i - cell * LPC;
+        const int ty = cell / TW, tx = cell - ty * TW;
+        const int y = y0 + ty - KH / 2, x = x0 + tx - KW / 2;
+        const bool inside = (y >= 0 && y < H && x >= 0 && x < W);
+        T* d = ft + cell * CSTR + q * EPV;
+#pragma unroll
+        for (int k = 0; k < EPV; ++k) d[k] = inside ? r[j].e[k] : (T)((q == LPC - 1 && k == EPV - 1) ? 1 : 0);
+      }
+    }
+  }
+}
+
+// T = float: SpatialConvolutionEngine(CV_32F); T = double: CV_64F with the filters converted to double
+// (src/PartsBasedDetector.cpp:110-117) — wT holds them as T.
+template <typename T, int KH, int KW>
 __global__ __launch_bounds__(256) void k_conv_exact(const ConvTile* __restrict__ tiles,
                                                     const LevelDev* __restrict__ levels,
-                                                    const float* __restrict__ feat, const float* __restrict__ wT,
-                                                    float* __restrict__ resp, int nf, int nfpad, int groups_per_wg) {
+                                                    const T* __restrict__ feat, const T* __restrict__ wT,
+                                                    T* __restrict__ resp, int nf, int nfpad, int groups_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* ft = (float*)smem;  // [(CT+KH-1)][(CT+KW-1)][CSTR]
+  T* ft = (T*)smem;  // [(CT+KH-1)][(CT+KW-1)][CSTR]
   const ConvTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const int H = lv.ch, W = lv.cw;
   const int TW = CT + KW - 1, TH = CT + KH - 1;
   const int tid = threadIdx.x;
-  const float* F = feat + lv.cell_off * PBD_FLEN;
-  // stage the tile: 8 lanes x float4 per cell -> coalesced 128 B per cell
-  stage_feature_tile<KH, KW>(ft, F, t.y0, t.x0, H, W, tid);
+  const T* F = feat + lv.cell_off * PBD_FLEN;
+  // stage the tile: 8 lanes x float4 (16 x double2) per cell -> coalesced 128 B (256 B) per cell
+  if constexpr (sizeof(T) == 4) stage_feature_tile<KH, KW>(ft, F, t.y0, t.x0, H, W, tid);
+  else stage_feature_tile_t<T, KH, KW>(ft, F, t.y0, t.x0, H, W, tid);
   __syncthreads();
   const int ly = tid >> 4, lx = tid & 15;
   const int oy = t.y0 + ly, ox = t.x0 + lx;
   const bool valid = (oy < H && ox < W);
-  const float* fbase = ft + (ly * TW + lx) * CSTR;
-  float* R = resp + lv.cell_off * nf;  // level base, plane n at + n*H*W
+  const T* fbase = ft + (ly * TW + lx) * CSTR;
+  T* R = resp + lv.cell_off * nf;  // level base, plane n at + n*H*W
   const int g0 = blockIdx.y * groups_per_wg;
   for (int g = g0; g < g0 + groups_per_wg; ++g) {
     const int n0 = g * NFG;
     if (n0 >= nf) break;
-    float tot[NFG];
+    T tot[NFG];
 #pragma unroll
-    for (int n = 0; n < NFG; ++n) tot[n] = 0.f;
+    for (int n = 0; n < NFG; ++n) tot[n] = (T)0;
     for (int c = 0; c < PBD_FLEN; ++c) {
-      float acc[NFG];
+      T acc[NFG];
 #pragma unroll
-      for (int n = 0; n < NFG; ++n) acc[n] = 0.f;
+      for (int n = 0; n < NFG; ++n) acc[n] = (T)0;
 #pragma unroll
       for (int i = 0; i < KH; ++i) {
 #pragma unroll
         for (int j = 0; j < KW; ++j) {
-          const float f = fbase[(i * TW + j) * CSTR + c];
-          const float* w = wT + ((size_t)(i * KW + j) * PBD_FLEN + c) * nfpad + n0;  // wave-uniform
+          const T f = fbase[(i * TW + j) * CSTR + c];
+          const T* w = wT + ((size_t)(i * KW + j) * PBD_FLEN + c) * nfpad + n0;  // wave-uniform
 #pragma unroll
           for (int n = 0; n < NFG; ++n) acc[n] += w[n] * f;
         }
@@ -113,39 +150,38 @@ __global__ __launch_bounds__(256) void k_conv_exact(const ConvTile* __restrict__
 }
 
 // generic-size fallback (runtime kh, kw <= 9)
+template <typename T>
 __global__ __launch_bounds__(256) void k_conv_exact_generic(const ConvTile* __restrict__ tiles,
                                                             const LevelDev* __restrict__ levels,
-                                                            const float* __restrict__ feat,
-                                                            const float* __restrict__ wT, float* __restrict__ resp,
+                                                            const T* __restrict__ feat,
+                                                            const T* __restrict__ wT, T* __restrict__ resp,
                                                             int nf, int nfpad, int KH, int KW) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* ft = (float*)smem;
+  T* ft = (T*)smem;
   const ConvTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const int H = lv.ch, W = lv.cw;
   const int TW = CT + KW - 1, TH = CT + KH - 1;
   const int tid = threadIdx.x;
-  const float* F = feat + lv.cell_off * PBD_FLEN;
-  for (int i = tid; i < TH * TW * 8; i += 256) {
-    const int cell = i >> 3, q = i & 7;
+  const T* F = feat + lv.cell_off * PBD_FLEN;
+  for (int i = tid; i < TH * TW * PBD_FLEN; i += 256) {
+    const int cell = i >> 5, c = i & 31;
     const int ty = cell / TW, tx = cell - ty * TW;
     const int y = t.y0 + ty - KH / 2, x = t.x0 + tx - KW / 2;
-    float4 v;
-    if (y >= 0 && y < H && x >= 0 && x < W) v = *(const float4*)(F + ((size_t)y * W + x) * PBD_FLEN + q * 4);
-    else v = make_float4(0.f, 0.f, 0.f, q == 7 ? 1.f : 0.f);
-    float* d = ft + cell * CSTR + q * 4;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    const bool inside = (y >= 0 && y < H && x >= 0 && x < W);
+    const T v = F[((size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)) * PBD_FLEN + c];
+    ft[cell * CSTR + c] = inside ? v : (T)(c == PBD_FLEN - 1 ? 1 : 0);
   }
   __syncthreads();
   const int ly = tid >> 4, lx = tid & 15;
   const int oy = t.y0 + ly, ox = t.x0 + lx;
   const bool valid = (oy < H && ox < W);
-  const float* fbase = ft + (ly * TW + lx) * CSTR;
-  float* R = resp + lv.cell_off * nf;
+  const T* fbase = ft + (ly * TW + lx) * CSTR;
+  T* R = resp + lv.cell_off * nf;
   for (int n = blockIdx.y; n < nf; n += gridDim.y) {
-    float tot = 0.f;
+    T tot = (T)0;
     for (int c = 0; c < PBD_FLEN; ++c) {
-      float acc = 0.f;
+      T acc = (T)0;
       for (int i = 0; i < KH; ++i)
         for (int j = 0; j < KW; ++j)
           acc += wT[((size_t)(i * KW + j) * PBD_FLEN + c) * nfpad + n] * fbase[(i * TW + j) * CSTR + c];
@@ -155,22 +191,30 @@ __global__ __launch_bounds__(256) void k_conv_exact_generic(const ConvTile* __re
   }
 }
 
-void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
-                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
-  if (ntiles <= 0) return;
-  const size_t lds = sizeof(float) * (CT + kh - 1) * (CT + kw - 1) * CSTR;
+template <typename T>
+static void launch_conv_exact_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
+                                const T* wT, T* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
+  const size_t lds = sizeof(T) * (CT + kh - 1) * (CT + kw - 1) * CSTR;
   if (kh == 5 && kw == 5) {
-    static bool cfg = false;
-    if (!cfg) { hipFuncSetAttribute((const void*)k_conv_exact<5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+    static bool cfg = false;   // one per instantiation
+    if (!cfg) { hipFuncSetAttribute((const void*)k_conv_exact<T, 5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
     const int groups = (nf + NFG - 1) / NFG;
     const int gpw = 4;
     dim3 grid(ntiles, (groups + gpw - 1) / gpw);
-    hipLaunchKernelGGL((k_conv_exact<5, 5>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, gpw);
+    hipLaunchKernelGGL((k_conv_exact<T, 5, 5>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, gpw);
   } else {
-    hipFuncSetAttribute((const void*)k_conv_exact_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_conv_exact_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(ntiles, nf < 16 ? nf : 16);
-    hipLaunchKernelGGL(k_conv_exact_generic, grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, kh, kw);
+    hipLaunchKernelGGL(k_conv_exact_generic<T>, grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, kh, kw);
   }
+}
+
+// ts = sizeof(T): 4 -> SpatialConvolutionEngine(CV_32F), 8 -> CV_64F
+void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const void* feat, const void* wT,
+                       void* resp, int ts, int nf, int nfpad, int kh, int kw, hipStream_t s) {
+  if (ntiles <= 0) return;
+  if (ts == 8) launch_conv_exact_t<double>(tiles, ntiles, levels, (const double*)feat, (const double*)wT, (double*)resp, nf, nfpad, kh, kw, s);
+  else launch_conv_exact_t<float>(tiles, ntiles, levels, (const float*)feat, (const float*)wT, (float*)resp, nf, nfpad, kh, kw, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -280,7 +324,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const ConvTile* __restrict__ 
 void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
   if (ntiles <= 0) return;
-  if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, kh, kw, s); return; }
+  if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, 4, nf, nfpad, kh, kw, s); return; }
   const size_t lds = sizeof(float) * (CT + 4) * (CT + 4) * CSTR;
   static bool cfg = false;
   if (!cfg) { hipFuncSetAttribute((const void*)k_conv_mfma<5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }

@@ -34,9 +34,12 @@ void dt_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBO
 // u16[S]} + per map touched by the block a table of exact reciprocals 1/(2a*dx), dx < len (double[S]).
 // The envelope scan is VALU-issue bound with one lane per line, and the lines resident on a CU are
 // bounded by these bytes: every byte saved per element is more active lanes per wavefront.
-size_t dt_lds_bytes(int stride, int lpb, int nmb) {
-  return (size_t)lpb * stride * (4 + 4 + (stride <= 256 ? 1 : 2)) + 64 * (8 + 8 + 4 + 4) + (size_t)nmb * stride * 8 + 16;
+size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts) {   // ts = sizeof(T): (Y, Z) is float2 or double2
+  return (size_t)lpb * stride * (2 * ts + (stride <= 256 ? 1 : 2)) + 64 * (8 + 8 + 4 + 4) + (size_t)nmb * stride * 8 + 16;
 }
+template <typename T> struct Pair;                       // (y, z) of one stack entry: one LDS word pair
+template <> struct Pair<float> { typedef float2 type; };
+template <> struct Pair<double> { typedef double2 type; };
 
 // Envelope scan of one line (DistanceTransform.hpp:156-170), one lane per line.
 //
@@ -61,26 +64,26 @@ size_t dt_lds_bytes(int stride, int lpb, int nmb) {
 // at its end), stores (y,z) of an entry as one 8-byte LDS word, and issues the push stores
 // unconditionally to slot k+1 (dead when the step pops).  The y of stack entry k overwrites the
 // consumed line element k in place (k <= q).
-template <bool EXACT, typename VT>
-__device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, VT* __restrict__ Vl,
+template <bool EXACT, typename VT, typename T>
+__device__ __forceinline__ bool dt_envelope(typename Pair<T>::type* __restrict__ YZl, VT* __restrict__ Vl,
                                             const double* __restrict__ Rl, int len, double a, double b, int* kout) {
   const double twoa = 2 * a;
   const double r1 = Rl[1 < len ? 1 : 0];
   int k = 0, q = 1, vk = 0, nv = 0;
-  float zk = -INFINITY, nz = -INFINITY;
+  T zk = -INFINITY, nz = -INFINITY;
   double yk = (double)YZl[0].x, ny = 0.0;
   double r_top = r1;
   unsigned suspect = 0;             // sticky: a quotient landed next to a float rounding boundary
   Vl[0] = 0;
   YZl[0].y = -INFINITY;
-  float yq_f = YZl[min(1, len - 1)].x;
+  T yq_f = YZl[min(1, len - 1)].x;
   while (q < len) {
     // prefetches (addresses known now, values used after the arithmetic below)
     const int k2 = max(k - 2, 0);
     const int pv = Vl[k2];
-    const float2 pyz = YZl[k2];
+    const typename Pair<T>::type pyz = YZl[k2];
     const double r_nxt = Rl[max(q - nv, 0)];   // reciprocal for the entry below the top (used if this step pops)
-    const float ynext_f = YZl[min(q + 1, len - 1)].x;
+    const T ynext_f = YZl[min(q + 1, len - 1)].x;
     // intersection with the stack top
     const int dx = q - vk;
     const double yq = (double)yq_f;
@@ -99,13 +102,13 @@ __device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, VT* __rest
       const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
       suspect = (((lo29 - 0x0FFFFFFFu) <= 2u) | ((ex - 897u) > 252u)) ? 1u : suspect;   // one v_cndmask
     }
-    const float s = (float)q1;
+    const T s = (T)q1;                          // `T s = f(...)` (:161): narrowed for float, kept for double
     const bool pop = (s <= zk) && (k > 0);  // :162
     // push stores (:166-169); slot k+1 is dead if this step pops
     Vl[k + 1] = (VT)q;
-    YZl[k + 1] = make_float2(yq_f, s);
+    { typename Pair<T>::type e; e.x = yq_f; e.y = s; YZl[k + 1] = e; }
     // state update, selects only
-    const int vk_o = vk; const double yk_o = yk; const float zk_o = zk;
+    const int vk_o = vk; const double yk_o = yk; const T zk_o = zk;
     k = pop ? k - 1 : k + 1;
     vk = pop ? nv : q;
     yk = pop ? ny : yq;
@@ -124,11 +127,12 @@ __device__ __forceinline__ bool dt_envelope(float2* __restrict__ YZl, VT* __rest
 // One block = one wavefront = up to g.lpb lines of one group (lpb chosen per group so that every
 // block of the launch fits the same LDS budget: long lines -> fewer lines per block -> many more
 // blocks, so a whole pass is resident at once and all 4 SIMDs of every CU carry chains).
-template <typename VT>
+template <typename T, typename VT>
 __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps) {
   const int lane = threadIdx.x;
   const int len = g.len, S = g.stride, lpb = g.lpb;
-  const float** lptr = (const float**)smem;   // [64] source pointer of each line of this block
+  typedef typename Pair<T>::type P2;
+  const T** lptr = (const T**)smem;   // [64] source pointer of each line of this block
   int16_t** pptr = (int16_t**)(smem + 64 * 8);  // [64] pointer-output base of each line
   int* pstr = (int*)(smem + 64 * 16);         // [64] pointer-output element stride of each line
   int* Ksz = (int*)(smem + 64 * 20);          // [64] final stack size of each line
@@ -137,13 +141,13 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   const int nl = min(lpb, total - t.g0);
   const int m_first = t.g0 / g.nlines, m_last = (t.g0 + nl - 1) / g.nlines;
   const int nmb = m_last - m_first + 1;
-  float2* YZ = (float2*)(R + g.nmb * S);      // [lpb][S] .x: line values, then y of stack entries (in place); .y: z[k]
+  P2* YZ = (P2*)(R + g.nmb * S);      // [lpb][S] .x: line values, then y of stack entries (in place); .y: z[k]
   VT* V = (VT*)(YZ + lpb * S);                // [lpb][S] v[k]
   if (lane < nl) {
     const int gi = t.g0 + lane;
     const int mi = gi / g.nlines, li = gi - mi * g.nlines;
     const DtMap& mp0 = maps[g.map0 + mi];
-    lptr[lane] = mp0.src + (size_t)li * len;
+    lptr[lane] = (const T*)mp0.src + (size_t)li * len;
     // pointers: transposed like dst (y pass -> natural layout) or natural (x pass)
     const bool nat = mp0.ptr_natural != 0;
     pptr[lane] = mp0.ptr + (nat ? (size_t)li * len : (size_t)li);
@@ -164,7 +168,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const int CH = (len + 63) >> 6;          // 64-element chunks per line
     const int nch = nl * CH;
     for (int c0 = 0; c0 < nch; c0 += 16) {
-      float r[16];
+      T r[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int c = min(c0 + j, nch - 1);
@@ -190,14 +194,17 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const int mi = gi / g.nlines;
     const DtMap mp = maps[g.map0 + mi];
     const double* Rl = R + (mi - m_first) * S;
-    float2* YZl = YZ + lane * S;
+    P2* YZl = YZ + lane * S;
     VT* Vl = V + lane * S;
     int k;
-    if (dt_envelope<false, VT>(YZl, Vl, Rl, len, mp.a, mp.b, &k)) {
+    if constexpr (sizeof(T) == 8) {
+      // DistanceTransform<double>: s is not narrowed, so every intersection takes the IEEE division
+      dt_envelope<true, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, &k);
+    } else if (dt_envelope<false, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, &k)) {
       // a quotient landed within 1 ulp of a float rounding boundary: redo this line with true divisions
-      const float* src = lptr[lane];
+      const T* src = lptr[lane];
       for (int q = 0; q < len; ++q) YZl[q].x = src[q];
-      dt_envelope<true, VT>(YZl, Vl, Rl, len, mp.a, mp.b, &k);
+      dt_envelope<true, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, &k);
     }
     YZl[k + 1].y = INFINITY;
     Ksz[lane] = k;
@@ -219,7 +226,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       const int mi = gi / g.nlines, li = gi - mi * g.nlines;
       const DtMap mp = maps[g.map0 + mi];
       const double a = mp.a, b = mp.b;
-      const float2* YZl = YZ + line * S;
+      const P2* YZl = YZ + line * S;
       const VT* Vl = V + line * S;
       int16_t* pp = pptr[line];
       const int pst = pstr[line];
@@ -230,21 +237,21 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         int os = mp.os + q0;
         // first k with !(z[k+1] < os): z is strictly increasing, z[K+1] = +inf
         int lo = 0, hi = K;
-        const float f0 = (float)os;
+        const T f0 = (T)os;
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
           if (YZl[mid + 1].y < f0) lo = mid + 1; else hi = mid;
         }
         int k = lo;
         int vk = Vl[k];
-        float yk = YZl[k].x, zn = YZl[k + 1].y;
-        float* dst = mp.dst + li;
+        T yk = YZl[k].x, zn = YZl[k + 1].y;
+        T* dst = (T*)mp.dst + li;
         const int nlines = g.nlines;
         for (int q = q0; q < q1; ++q) {
-          const float fos = (float)os;
+          const T fos = (T)os;                   // `z[k+1] < os`: int promoted to T (:174)
           while (zn < fos) { k++; zn = YZl[k + 1].y; vk = Vl[k]; yk = YZl[k].x; }
           const int d = os - vk;
-          dst[(size_t)q * nlines] = (float)(a * (double)(d * d) + b * (double)d + (double)yk);
+          dst[(size_t)q * nlines] = (T)(a * (double)(d * d) + b * (double)d + (double)yk);
           pp[(size_t)q * pst] = (int16_t)vk;
           os++;
         }
@@ -255,30 +262,39 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   DT_STAMP(5);
 }
 
+template <typename T>
 __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks, const DtGroup* __restrict__ groups,
                                                 const DtMap* __restrict__ maps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   DT_STAMP(0);
   const DtTask t = tasks[blockIdx.x];
   const DtGroup g = groups[t.group];
-  if (g.stride <= 256) dt_block<unsigned char>(smem, t, g, maps);    // stack indices < 255 fit a byte
-  else dt_block<unsigned short>(smem, t, g, maps);
+  if (g.stride <= 256) dt_block<T, unsigned char>(smem, t, g, maps);    // stack indices < 255 fit a byte
+  else dt_block<T, unsigned short>(smem, t, g, maps);
 }
 
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,
-                    hipStream_t s) {
-  if (ntasks <= 0) return;
-  static size_t configured = 0;
+template <typename T>
+static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,
+                             hipStream_t s) {
+  static size_t configured = 0;   // one per instantiation
   if (lds > configured) {
-    hipFuncSetAttribute((const void*)k_dt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_dt_pass<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = lds;
   }
-  hipLaunchKernelGGL(k_dt_pass, dim3(ntasks), dim3(64), lds, s, tasks, groups, maps);
+  hipLaunchKernelGGL(k_dt_pass<T>, dim3(ntasks), dim3(64), lds, s, tasks, groups, maps);
+}
+// ts = sizeof(T): DistanceTransform<float> / DistanceTransform<double>
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, int ts,
+                    hipStream_t s) {
+  if (ntasks <= 0) return;
+  if (ts == 8) launch_dt_pass_t<double>(tasks, ntasks, groups, maps, lds, s);
+  else launch_dt_pass_t<float>(tasks, ntasks, groups, maps, lds, s);
 }
 
 // ---------------------------------------------------------------------------
 // reduce over child mixtures, one thread per cell of one (level, child part)
 // ---------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jobs, const ReduceBlock* __restrict__ blocks,
                                                 const float* __restrict__ biasw, int correct_ptr) {
   // block -> (job, first cell) comes from a host-built table; the job descriptor (pointers, bias
@@ -298,28 +314,28 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
   const int m_ = cell / W, n_ = cell - m_ * W;
   constexpr int ML = 8;            // parent mixtures handled with all their gathers in flight at once
   if (L <= ML) {
-    float acc[ML];
+    T acc[ML];
 #pragma unroll
-    for (int m = 0; m < ML; ++m) acc[m] = (m < L) ? J.par_in[m][cell] : 0.f;
+    for (int m = 0; m < ML; ++m) acc[m] = (m < L) ? ((const T*)J.par_in[m])[cell] : (T)0;
     for (int c = 0; c < J.nch; ++c) {
       const ReduceChild& C = J.ch[c];
       const int K = C.K;
       int bi[ML];
-      float v[ML];
+      T v[ML];
       if (K == 1) {  // Math::reduceMax K==1 shortcut: copy (Math.hpp:154-158)
-        const float sd = C.sdt[cell];
+        const T sd = ((const T*)C.sdt)[cell];
 #pragma unroll
-        for (int m = 0; m < ML; ++m) { bi[m] = 0; v[m] = (m < L) ? sd + biasw[C.bias_off[0] + m] : 0.f; }
+        for (int m = 0; m < ML; ++m) { bi[m] = 0; v[m] = (m < L) ? sd + biasw[C.bias_off[0] + m] : (T)0; }
       } else {
 #pragma unroll
         for (int m = 0; m < ML; ++m) { bi[m] = 0; v[m] = -INFINITY; }
         for (int mm = 0; mm < K; ++mm) {
-          const float sd = C.sdt[(size_t)mm * HW + cell];
+          const T sd = ((const T*)C.sdt)[(size_t)mm * HW + cell];
           const int bo = C.bias_off[mm];
 #pragma unroll
           for (int m = 0; m < ML; ++m) {
             if (m < L) {
-              const float wv = sd + biasw[bo + m];              // DynamicProgram.cpp:139
+              const T wv = sd + biasw[bo + m];              // DynamicProgram.cpp:139
               if (wv > v[m]) { bi[m] = mm; v[m] = wv; }         // strict >: first max wins
             }
           }
@@ -348,22 +364,22 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
       }
     }
 #pragma unroll
-    for (int m = 0; m < ML; ++m) if (m < L) J.par_out[m][cell] = acc[m];
+    for (int m = 0; m < ML; ++m) if (m < L) ((T*)J.par_out[m])[cell] = acc[m];
     return;
   }
   for (int m = 0; m < L; ++m) {   // generic path (more than 8 parent mixtures)
-    float acc = J.par_in[m][cell];
+    T acc = ((const T*)J.par_in[m])[cell];
     for (int c = 0; c < J.nch; ++c) {
       const ReduceChild& C = J.ch[c];
       const int K = C.K;
-      float v;
+      T v;
       int bi = 0;
       if (K == 1) {
-        v = C.sdt[cell] + biasw[C.bias_off[0] + m];
+        v = ((const T*)C.sdt)[cell] + biasw[C.bias_off[0] + m];
       } else {
         v = -INFINITY;
         for (int mm = 0; mm < K; ++mm) {
-          const float wv = C.sdt[(size_t)mm * HW + cell] + biasw[C.bias_off[mm] + m];
+          const T wv = ((const T*)C.sdt)[(size_t)mm * HW + cell] + biasw[C.bias_off[mm] + m];
           if (wv > v) { bi = mm; v = wv; }
         }
       }
@@ -381,19 +397,21 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
       C.ok[o] = (uint8_t)bi;
       acc = acc + v;
     }
-    J.par_out[m][cell] = acc;
+    ((T*)J.par_out[m])[cell] = acc;
   }
 }
 
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
-                   hipStream_t s) {
+                   int ts, hipStream_t s) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(k_reduce, dim3(nblocks), dim3(256), 0, s, jobs, blocks, biasw, correct_ptr);
+  if (ts == 8) hipLaunchKernelGGL(k_reduce<double>, dim3(nblocks), dim3(256), 0, s, jobs, blocks, biasw, correct_ptr);
+  else hipLaunchKernelGGL(k_reduce<float>, dim3(nblocks), dim3(256), 0, s, jobs, blocks, biasw, correct_ptr);
 }
 
 // ---------------------------------------------------------------------------
 // root: bias + max over root mixtures, threshold, compaction
 // ---------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, int njobs, double thresh,
                                               int* __restrict__ count, CandRec* __restrict__ rec, int capacity) {
   const unsigned gid = blockIdx.x * 256u + threadIdx.x;
@@ -405,18 +423,19 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
   const RootJob& J = jobs[lo];
   const unsigned cell = gid - J.cell0;
   if (cell >= (unsigned)J.H * J.W) return;
-  float v;
+  T v;
   int bi = 0;
+  const T bias = J.bias;                             // `T bias = root.bias(0)[0]` (:165)
   if (J.K == 1) {
-    v = J.score[0][cell] + J.bias;
+    v = ((const T*)J.score[0])[cell] + bias;
   } else {
     v = -INFINITY;
     for (int m = 0; m < J.K; ++m) {
-      const float wv = J.score[m][cell] + J.bias;  // DynamicProgram.cpp:169
+      const T wv = ((const T*)J.score[m])[cell] + bias;  // DynamicProgram.cpp:169
       if (wv > v) { bi = m; v = wv; }
     }
   }
-  J.rootv[cell] = v;
+  ((T*)J.rootv)[cell] = v;
   J.rooti[cell] = bi;
   if ((double)v > thresh) {  // :208 strict >
     const int idx = atomicAdd(count, 1);
@@ -429,15 +448,16 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
 }
 
 void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
-                 int capacity, hipStream_t s) {
+                 int capacity, int ts, hipStream_t s) {
   if (njobs <= 0 || total_cells == 0) return;
-  hipLaunchKernelGGL(k_root, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec,
-                     capacity);
+  if (ts == 8) hipLaunchKernelGGL(k_root<double>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity);
+  else hipLaunchKernelGGL(k_root<float>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity);
 }
 
 // ---------------------------------------------------------------------------
 // backtrack: one lane per candidate; record = head | boxes[max_parts][4] | locs[max_parts][3]
 // ---------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count, const CandRec* __restrict__ rec,
                                                   int capacity, const BackLevel* __restrict__ back, int ncomp,
                                                   const int* __restrict__ parent, const int* __restrict__ plane0,
@@ -454,12 +474,12 @@ __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count,
   int32_t* boxes = (int32_t*)(o + sizeof(pbd_candidate_head));
   int32_t* locs = boxes + (size_t)max_parts * 4;
   const int np = nparts[r.comp];
-  head->score = B.rootv[(size_t)r.y * B.W + r.x];
+  head->score = (float)((const T*)B.rootv)[(size_t)r.y * B.W + r.x];   // Candidate::addPart(Rect, float), Candidate.hpp:72
   head->component = r.comp;
   head->level = r.level;
   head->nparts = np;
-  const float scale = B.scale;
-  const int sz = __float2int_rn((float)kh * scale);  // Point(xsize,ysize)*scale, cvRound
+  const T scale = B.scale;                             // `T scale = scales[n]` (:198): Point * T rounds with cvRound
+  const int sz = t_round((T)kh * scale);               // Point(xsize,ysize)*scale
   for (int p = 0; p < np; ++p) {
     int x, y, m;
     if (p == 0) {
@@ -471,7 +491,7 @@ __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count,
       x = B.px[off]; y = B.py[off]; m = B.pk[off];
     }
     locs[p * 3] = x; locs[p * 3 + 1] = y; locs[p * 3 + 2] = m;
-    const int x1 = __float2int_rn((float)(x - 1) * scale), y1 = __float2int_rn((float)(y - 1) * scale);
+    const int x1 = t_round((T)(x - 1) * scale), y1 = t_round((T)(y - 1) * scale);
     const int x2 = x1 + sz - 1, y2 = y1 + sz - 1;
     boxes[p * 4] = min(x1, x2); boxes[p * 4 + 1] = min(y1, y2);
     boxes[p * 4 + 2] = max(x1, x2) - min(x1, x2); boxes[p * 4 + 3] = max(y1, y2) - min(y1, y2);
@@ -484,9 +504,9 @@ __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count,
 
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh, char* out,
-                      size_t out_stride, hipStream_t s) {
-  hipLaunchKernelGGL(k_backtrack, dim3((capacity + 63) / 64), dim3(64), 0, s, count, rec, capacity, back, ncomp,
-                     parent, plane0, nparts, max_parts, kh, out, out_stride);
+                      size_t out_stride, int ts, hipStream_t s) {
+  if (ts == 8) hipLaunchKernelGGL(k_backtrack<double>, dim3((capacity + 63) / 64), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride);
+  else hipLaunchKernelGGL(k_backtrack<float>, dim3((capacity + 63) / 64), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride);
 }
 
 // ---------------------------------------------------------------------------

@@ -262,7 +262,7 @@ __device__ __forceinline__ void dtw_block(char* smem, const DtTask& t, const DtG
 
   for (int li = wave * 4; li < wave * 4 + 4 && li < nl; ++li) {
     const int line = l0 + li;
-    const float* src = mp.src + (size_t)line * len;
+    const float* src = (const float*)mp.src + (size_t)line * len;   // float instantiation only
 #pragma unroll
     for (int c = 0; c < NCH; ++c) w.y[c * 64 + lane] = src[min(c * 64 + lane, len - 1)];
     DTW_SYNC();
@@ -296,7 +296,7 @@ __device__ __forceinline__ void dtw_block(char* smem, const DtTask& t, const DtG
   for (int i = tid; i < len * DTW_LINES; i += 256) {
     const int q = i / DTW_LINES, li = i - q * DTW_LINES;
     if (li < nl) {
-      mp.dst[(size_t)q * nlines + l0 + li] = so[i];
+      ((float*)mp.dst)[(size_t)q * nlines + l0 + li] = so[i];
       if (!mp.ptr_natural) mp.ptr[(size_t)q * nlines + l0 + li] = (int16_t)sp[i];
     }
   }

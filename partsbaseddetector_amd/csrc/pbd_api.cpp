@@ -224,8 +224,13 @@ static int upload_model(pbd_handle* h) {
         for (int c = 0; c < m.flen; ++c)
           wT[((size_t)(i * m.kw + j) * m.flen + c) * h->nfpad + n] =
               h->filters[(((size_t)n * m.kh + i) * m.kw + j) * m.flen + c];
-  HIPCHK(h, hipMalloc(&h->d_wT, wT.size() * sizeof(float)));
-  HIPCHK(h, hipMemcpy(h->d_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMalloc(&h->d_wT, wT.size() * h->ts));
+  if (h->ts == 8) {   // filters convertTo(DataType<double>), src/PartsBasedDetector.cpp:113-117 (exact widening)
+    std::vector<double> wd(wT.begin(), wT.end());
+    HIPCHK(h, hipMemcpy(h->d_wT, wd.data(), wd.size() * sizeof(double), hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(h, hipMemcpy(h->d_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   // biasw plus one trailing 0 (used by the stand-alone pbd_dt2d)
   std::vector<float> bw(h->biasw);
   bw.push_back(0.f);
@@ -291,16 +296,16 @@ static void free_frame(pbd_handle* h) {
 // nmb = maps a block of lpb consecutive lines can touch.
 static int dt_stride_for(int len) { return (len + 2) & ~1; }
 static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (lpb + nlines - 2) / nlines + 1); }
-static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget) {
+static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget, int ts) {
   int lpb = 64;
-  while (lpb > 8 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps)) > budget) --lpb;
+  while (lpb > 8 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts) > budget) --lpb;
   return lpb;
 }
-static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget) {
+static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts) {
   DtGroup g{};
   g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len;
   g.stride = dt_stride_for(len);
-  g.lpb = dt_lpb_for(g.stride, nlines, nmaps, budget);
+  g.lpb = dt_lpb_for(g.stride, nlines, nmaps, budget, ts);
   g.nmb = dt_nmb_for(g.lpb, nlines, nmaps);
   return g;
 }
@@ -332,13 +337,14 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   int rc;
   if ((rc = dev_alloc(h, &h->d_img, (size_t)w * hgt * cn))) return rc;
   if ((rc = dev_alloc(h, &h->d_pyr, pyr))) return rc;
-  if ((rc = dev_alloc(h, &h->d_feat, cells * PBD_FLEN))) return rc;
-  if ((rc = dev_alloc(h, &h->d_resp, cells * m.nfilters))) return rc;
-  if ((rc = dev_alloc(h, &h->d_acc, cells * h->nslots))) return rc;
+  const size_t ts = (size_t)h->ts;   // sizeof(T); T buffers are char* addressed as elements * ts
+  if ((rc = dev_alloc(h, &h->d_feat, cells * PBD_FLEN * ts))) return rc;
+  if ((rc = dev_alloc(h, &h->d_resp, cells * m.nfilters * ts))) return rc;
+  if ((rc = dev_alloc(h, &h->d_acc, cells * h->nslots * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_px, cells * std::max(h->nplanes, 1)))) return rc;
   if ((rc = dev_alloc(h, &h->d_py, cells * std::max(h->nplanes, 1)))) return rc;
   if ((rc = dev_alloc(h, &h->d_pk, cells * std::max(h->nplanes, 1)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_rootv, cells * m.ncomponents))) return rc;
+  if ((rc = dev_alloc(h, &h->d_rootv, cells * m.ncomponents * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_rooti, cells * m.ncomponents))) return rc;
 
   std::vector<LevelDev> ld(n);
@@ -350,8 +356,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
 
   // HOG tiles: TC x TC cells; shrink the tile until its LDS footprint fits
   h->hog_tc = 16;
-  while (h->hog_tc > 2 && hog_lds_bytes(m.sbin, h->hog_tc) > 150 * 1024) h->hog_tc /= 2;
-  if (hog_lds_bytes(m.sbin, h->hog_tc) > 150 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "sbin too large");
+  while (h->hog_tc > 2 && hog_lds_bytes(m.sbin, h->hog_tc, h->ts) > 150 * 1024) h->hog_tc /= 2;
+  if (hog_lds_bytes(m.sbin, h->hog_tc, h->ts) > 150 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "sbin too large");
   std::vector<HogTile> ht;
   std::vector<ConvTile> ct;
   for (int l = 0; l < n; ++l) {
@@ -376,8 +382,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   size_t allmaps = 0;
   for (const PartInfo& P : h->parts) if (P.p > 0) allmaps += P.K;
   h->dt_cap_elems = std::max<size_t>(1, allmaps * act_cells);
-  if ((rc = dev_alloc(h, &h->d_dt_tmpT, h->dt_cap_elems))) return rc;
-  if ((rc = dev_alloc(h, &h->d_dt_sdt, h->dt_cap_elems))) return rc;
+  if ((rc = dev_alloc(h, &h->d_dt_tmpT, h->dt_cap_elems * ts))) return rc;
+  if ((rc = dev_alloc(h, &h->d_dt_sdt, h->dt_cap_elems * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_ixT, h->dt_cap_elems))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_iy, h->dt_cap_elems))) return rc;
 
@@ -386,7 +392,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
   size_t dt_base = 24 * 1024;   // 6 one-wave blocks per CU: measured optimum on MI355X (16..53 KB swept)
   if (const char* e = getenv("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
-  size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 8, 2));
+  size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 8, 2, h->ts));
   if (dt_budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
   h->dt_lds = dt_budget;
   std::vector<DtMap> maps;
@@ -413,7 +419,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     for (int l = 0; l < n; ++l) {
       const Level& L = h->lv[l];
       if (L.active && L.cw > 0 && L.ch > 0) {
-        const DtGroup gx = dt_group(0, (int)maxK, L.ch, L.cw, dt_budget);
+        const DtGroup gx = dt_group(0, (int)maxK, L.ch, L.cw, dt_budget, h->ts);
         const size_t b = ((size_t)maxK * L.ch + gx.lpb - 1) / gx.lpb;
         if (blocks + b > 800 && blocks > 0 && gcur < h->ngroups - 1) { gcur++; blocks = 0; }
         blocks += b;
@@ -440,19 +446,19 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
         for (int mm = 0; mm < P.K; ++mm) {
           const int fid = P.filterid[mm], did = P.defid[mm];
           const size_t so = scr_of(fp, l, mm);
-          const float* src = slot_init[P.slot[mm]] ? h->d_acc + L.cell_off * h->nslots + (size_t)P.slot[mm] * HW
-                                                   : h->d_resp + L.cell_off * m.nfilters + (size_t)fid * HW;
+          const char* src = slot_init[P.slot[mm]] ? h->d_acc + (L.cell_off * h->nslots + (size_t)P.slot[mm] * HW) * ts
+                                                  : h->d_resp + (L.cell_off * m.nfilters + (size_t)fid * HW) * ts;
           const float* wv = &h->defw[(size_t)did * 4];
-          DtMap mx{src, h->d_dt_tmpT + so, h->d_dt_ixT + so, -(double)wv[0], -(double)wv[1], h->anchors[did * 2], 1};
-          DtMap my{h->d_dt_tmpT + so, h->d_dt_sdt + so, h->d_dt_iy + so, -(double)wv[2], -(double)wv[3],
+          DtMap mx{src, h->d_dt_tmpT + so * ts, h->d_dt_ixT + so, -(double)wv[0], -(double)wv[1], h->anchors[did * 2], 1};
+          DtMap my{h->d_dt_tmpT + so * ts, h->d_dt_sdt + so * ts, h->d_dt_iy + so, -(double)wv[2], -(double)wv[3],
                    h->anchors[did * 2 + 1], 0};
           maps.push_back(mx);
           ymaps.push_back(my);
           gx_nmaps++;
         }
       }
-      const DtGroup gx = dt_group(gx_map0, gx_nmaps, L.ch, L.cw, dt_budget);
-      const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, dt_budget);
+      const DtGroup gx = dt_group(gx_map0, gx_nmaps, L.ch, L.cw, dt_budget, h->ts);
+      const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, dt_budget, h->ts);
       for (auto& my : ymaps) maps.push_back(my);
       const int gxi = (int)groups.size();
       groups.push_back(gx);
@@ -502,8 +508,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
           ReduceJob J{};
           J.H = L.ch; J.W = L.cw; J.L = Par.K;
           for (int pm = 0; pm < Par.K; ++pm) {
-            float* accp = h->d_acc + L.cell_off * h->nslots + (size_t)Par.slot[pm] * HW;
-            J.par_in[pm] = slot_w[Par.slot[pm]] ? accp : h->d_resp + L.cell_off * m.nfilters + (size_t)Par.filterid[pm] * HW;
+            char* accp = h->d_acc + (L.cell_off * h->nslots + (size_t)Par.slot[pm] * HW) * ts;
+            J.par_in[pm] = slot_w[Par.slot[pm]] ? accp : h->d_resp + (L.cell_off * m.nfilters + (size_t)Par.filterid[pm] * HW) * ts;
             J.par_out[pm] = accp;
           }
           for (int fp : wave) {  // `wave` is in descending child order
@@ -511,7 +517,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
             if (h->part_offset[P.comp] + P.parent != pf) continue;
             ReduceChild& C = J.ch[J.nch++];
             const size_t so = scr_of(fp, l, 0);
-            C.sdt = h->d_dt_sdt + so; C.ix = h->d_dt_ixT + so; C.iy = h->d_dt_iy + so;
+            C.sdt = h->d_dt_sdt + so * ts; C.ix = h->d_dt_ixT + so; C.iy = h->d_dt_iy + so;
             const size_t po = L.cell_off * h->nplanes + (size_t)P.plane0 * HW;
             C.ox = h->d_px + po; C.oy = h->d_py + po; C.ok = h->d_pk + po;
             C.K = P.K;
@@ -549,16 +555,16 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       BackLevel& B = bl[(size_t)l * m.ncomponents + c];
       const size_t po = L.cell_off * h->nplanes + (size_t)h->comp_plane0[c] * HW;
       B.px = h->d_px + po; B.py = h->d_py + po; B.pk = h->d_pk + po;
-      B.rootv = h->d_rootv + L.cell_off * m.ncomponents + (size_t)c * HW;
+      B.rootv = h->d_rootv + (L.cell_off * m.ncomponents + (size_t)c * HW) * ts;
       B.rooti = h->d_rooti + L.cell_off * m.ncomponents + (size_t)c * HW;
       B.H = L.ch; B.W = L.cw; B.scale = L.scale;
       if (!L.active || HW == 0) continue;
       const PartInfo& R0 = h->parts[h->part_offset[c]];
       RootJob J{};
       for (int k = 0; k < R0.K; ++k)
-        J.score[k] = slot_init[R0.slot[k]] ? h->d_acc + L.cell_off * h->nslots + (size_t)R0.slot[k] * HW
-                                           : h->d_resp + L.cell_off * m.nfilters + (size_t)R0.filterid[k] * HW;
-      J.rootv = (float*)B.rootv; J.rooti = (int*)B.rooti;
+        J.score[k] = slot_init[R0.slot[k]] ? h->d_acc + (L.cell_off * h->nslots + (size_t)R0.slot[k] * HW) * ts
+                                           : h->d_resp + (L.cell_off * m.nfilters + (size_t)R0.filterid[k] * HW) * ts;
+      J.rootv = (void*)B.rootv; J.rooti = (int*)B.rooti;
       J.H = L.ch; J.W = L.cw; J.K = R0.K; J.level = l; J.comp = c;
       J.bias = h->biasw[R0.biasid[0]];  // root.bias(0)[0], DynamicProgram.cpp:165
       J.cell0 = rcells;
@@ -598,7 +604,7 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
 }
 
 static int run_hog(pbd_handle* h) {
-  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->fcn, h->md.sbin, h->hog_tc, h->stream);
+  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->stream);
   h->have_feat = true;
   return PBD_OK;
 }
@@ -606,9 +612,9 @@ static int run_hog(pbd_handle* h) {
 static int run_pdf(pbd_handle* h) {
   const pbd_model_desc& m = h->md;
   if (h->conv_mode == PBD_CONV_MFMA)
-    launch_conv_mfma(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat, h->d_wT, h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
+    launch_conv_mfma(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT, (float*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
   else
-    launch_conv_exact(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat, h->d_wT, h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
+    launch_conv_exact(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat, h->d_wT, h->d_resp, h->ts, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
   h->have_resp = true;
   return PBD_OK;
 }
@@ -620,11 +626,11 @@ static int run_dp_min(pbd_handle* h) {
   if (h->ngroups == 1) {  // default: one chain of rounds on the handle's stream
     for (auto& R : h->grl[0]) {
       launch_dt_wave(h->d_dttasks + R.xw0, R.nxw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, h->stream);
-      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
+      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->stream);
       launch_dt_wave(h->d_dttasks + R.yw0, R.nyw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, h->stream);
-      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->stream);
+      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->stream);
       for (auto& Wv : R.waves)
-        launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->stream);
+        launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
     }
   }
   for (int g = 0; g < h->ngroups && h->ngroups > 1; ++g) {
@@ -632,18 +638,18 @@ static int run_dp_min(pbd_handle* h) {
     hipStreamWaitEvent(s, h->ev_fork, 0);
     for (auto& R : h->grl[g]) {
       launch_dt_wave(h->d_dttasks + R.xw0, R.nxw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, s);
-      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, s);
+      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, s);
       launch_dt_wave(h->d_dttasks + R.yw0, R.nyw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, s);
-      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, s);
+      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, s);
       for (auto& Wv : R.waves)
-        launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, s);
+        launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, s);
     }
     hipEventRecord(h->ev_join[g], s);
     hipStreamWaitEvent(h->stream, h->ev_join[g], 0);  // join
   }
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
   launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
-              h->opt.max_candidates, h->stream);
+              h->opt.max_candidates, h->ts, h->stream);
   if (h->dp_timer_on) hipEventRecord(h->ev_dp1, h->stream);
   h->have_dp = true;
   return PBD_OK;
@@ -653,7 +659,7 @@ static const int kFirstCopy = 192;  // records fetched together with the count
 
 static int run_argmin_enqueue(pbd_handle* h) {
   launch_backtrack(h->d_cand_count, h->d_cand_rec, h->opt.max_candidates, h->d_back, h->md.ncomponents, h->d_parent,
-                   h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, h->d_cand_out, h->cand_stride, h->stream);
+                   h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, h->d_cand_out, h->cand_stride, h->ts, h->stream);
   HIPCHK(h, hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   const int first = std::min(kFirstCopy, h->opt.max_candidates);
   HIPCHK(h, hipMemcpyAsync(h->h_cand_out, h->d_cand_out, h->cand_stride * first, hipMemcpyDeviceToHost, h->stream));
@@ -743,6 +749,8 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   if (opt) o = *opt;
   if (o.max_candidates <= 0) o.max_candidates = 4096;
   h->opt = o;
+  if (o.scalar_type != PBD_SCALAR_F32 && o.scalar_type != PBD_SCALAR_F64) return fail(h, PBD_ERR_ARG, "scalar_type: PBD_SCALAR_F32 or PBD_SCALAR_F64");
+  h->ts = (o.scalar_type == PBD_SCALAR_F64) ? 8 : 4;
   int rc = ingest_model(h, model);
   if (rc) return rc;
   h->ngroups = std::min(std::max(o.reserved[0], 1), PBD_NGROUPS);
@@ -751,6 +759,11 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   if (h->conv_mode == PBD_CONV_AUTO)  // a dense contraction when N x K is GEMM-sized
     h->conv_mode = ((size_t)model->nfilters * model->kh * model->kw * model->flen >= 32 * 800 && model->kh == 5 && model->kw == 5)
                        ? PBD_CONV_MFMA : PBD_CONV_EXACT;
+  if (h->ts == 8) {   // PartsBasedDetector<double>: the tap-ordered VALU filter bank and the lane-per-line DT
+    if (o.conv_mode == PBD_CONV_MFMA) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_MFMA is the fp32 MFMA kernel; the double instantiation uses PBD_CONV_EXACT");
+    if (o.reserved[1] == 2) return fail(h, PBD_ERR_UNSUPPORTED, "the wave-per-line distance transform is float only");
+    h->conv_mode = PBD_CONV_EXACT;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(h, PBD_ERR_HIP, "no HIP device visible");
   if (o.device < 0 || o.device >= ndev) return fail(h, PBD_ERR_ARG, "bad device ordinal");
@@ -894,22 +907,33 @@ int pbd_get_level_image(pbd_handle* h, int level, uint8_t* out) {
   HIPCHK(h, hipMemcpy(out, h->d_pyr + L.img_off, (size_t)L.iw * L.ih * h->fcn, hipMemcpyDeviceToHost));
   return PBD_OK;
 }
-int pbd_get_level_features(pbd_handle* h, int level, float* out) {
+// The float / _f64 entry points share one body; a handle only answers the pair that matches the
+// instantiation it was created for (cv::Mat depth CV_32F vs CV_64F in the reference).
+#define CHECK_SCALAR(h, want) \
+  do { if ((h)->ts != (want)) return fail((h), PBD_ERR_STATE, (want) == 4 ? "handle is PartsBasedDetector<double>: use the _f64 entry point" \
+                                                                         : "handle is PartsBasedDetector<float>: use the float entry point"); } while (0)
+static int get_level_features_(pbd_handle* h, int level, void* out, int ts) {
   CHECK_LEVEL(h, level);
+  CHECK_SCALAR(h, ts);
   if (!h->have_feat) return fail(h, PBD_ERR_STATE, "features not computed");
   const Level& L = h->lv[level];
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(out, h->d_feat + L.cell_off * PBD_FLEN, (size_t)L.cw * L.ch * PBD_FLEN * 4, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out, h->d_feat + L.cell_off * PBD_FLEN * ts, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyDeviceToHost));
   return PBD_OK;
 }
-int pbd_set_level_features(pbd_handle* h, int level, const float* in) {
+static int set_level_features_(pbd_handle* h, int level, const void* in, int ts) {
   CHECK_LEVEL(h, level);
+  CHECK_SCALAR(h, ts);
   const Level& L = h->lv[level];
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(h->d_feat + L.cell_off * PBD_FLEN, in, (size_t)L.cw * L.ch * PBD_FLEN * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_feat + L.cell_off * PBD_FLEN * ts, in, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyHostToDevice));
   h->have_feat = true;
   return PBD_OK;
 }
+int pbd_get_level_features(pbd_handle* h, int level, float* out) { return get_level_features_(h, level, out, 4); }
+int pbd_get_level_features_f64(pbd_handle* h, int level, double* out) { return get_level_features_(h, level, out, 8); }
+int pbd_set_level_features(pbd_handle* h, int level, const float* in) { return set_level_features_(h, level, in, 4); }
+int pbd_set_level_features_f64(pbd_handle* h, int level, const double* in) { return set_level_features_(h, level, in, 8); }
 int pbd_pdf(pbd_handle* h) {
   if (!h) return PBD_ERR_ARG;
   if (!h->have_feat) return fail(h, PBD_ERR_STATE, "pdf() before pyramid()");
@@ -918,26 +942,32 @@ int pbd_pdf(pbd_handle* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return PBD_OK;
 }
-int pbd_get_level_response(pbd_handle* h, int level, int filter, float* out) {
+static int get_level_response_(pbd_handle* h, int level, int filter, void* out, int ts) {
   CHECK_LEVEL(h, level);
+  CHECK_SCALAR(h, ts);
   if (!h->have_resp) return fail(h, PBD_ERR_STATE, "responses not computed");
   if (filter < 0 || filter >= h->md.nfilters) return fail(h, PBD_ERR_ARG, "filter out of range");
   const Level& L = h->lv[level];
   const size_t HW = (size_t)L.cw * L.ch;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(out, h->d_resp + L.cell_off * h->md.nfilters + filter * HW, HW * 4, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out, h->d_resp + (L.cell_off * h->md.nfilters + filter * HW) * ts, HW * ts, hipMemcpyDeviceToHost));
   return PBD_OK;
 }
-int pbd_set_level_response(pbd_handle* h, int level, int filter, const float* in) {
+static int set_level_response_(pbd_handle* h, int level, int filter, const void* in, int ts) {
   CHECK_LEVEL(h, level);
+  CHECK_SCALAR(h, ts);
   if (filter < 0 || filter >= h->md.nfilters) return fail(h, PBD_ERR_ARG, "filter out of range");
   const Level& L = h->lv[level];
   const size_t HW = (size_t)L.cw * L.ch;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(h->d_resp + L.cell_off * h->md.nfilters + filter * HW, in, HW * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_resp + (L.cell_off * h->md.nfilters + filter * HW) * ts, in, HW * ts, hipMemcpyHostToDevice));
   h->have_resp = true;
   return PBD_OK;
 }
+int pbd_get_level_response(pbd_handle* h, int level, int filter, float* out) { return get_level_response_(h, level, filter, out, 4); }
+int pbd_get_level_response_f64(pbd_handle* h, int level, int filter, double* out) { return get_level_response_(h, level, filter, out, 8); }
+int pbd_set_level_response(pbd_handle* h, int level, int filter, const float* in) { return set_level_response_(h, level, filter, in, 4); }
+int pbd_set_level_response_f64(pbd_handle* h, int level, int filter, const double* in) { return set_level_response_(h, level, filter, in, 8); }
 int pbd_dp_min(pbd_handle* h) {
   if (!h) return PBD_ERR_ARG;
   if (!h->have_resp) return fail(h, PBD_ERR_STATE, "min() before pdf()");
@@ -967,17 +997,20 @@ int pbd_get_dp_pointers(pbd_handle* h, int level, int component, int part, int p
   for (size_t i = 0; i < HW; ++i) { if (ix) ix[i] = a[i]; if (iy) iy[i] = b[i]; if (ik) ik[i] = c[i]; }
   return PBD_OK;
 }
-int pbd_get_root(pbd_handle* h, int level, int component, float* rootv, int32_t* rooti) {
+static int get_root_(pbd_handle* h, int level, int component, void* rootv, int32_t* rooti, int ts) {
   CHECK_LEVEL(h, level);
+  CHECK_SCALAR(h, ts);
   if (!h->have_dp) return fail(h, PBD_ERR_STATE, "min() not run");
   if (component < 0 || component >= h->md.ncomponents) return fail(h, PBD_ERR_ARG, "component out of range");
   const Level& L = h->lv[level];
   const size_t HW = (size_t)L.cw * L.ch;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (rootv) HIPCHK(h, hipMemcpy(rootv, h->d_rootv + L.cell_off * h->md.ncomponents + component * HW, HW * 4, hipMemcpyDeviceToHost));
+  if (rootv) HIPCHK(h, hipMemcpy(rootv, h->d_rootv + (L.cell_off * h->md.ncomponents + component * HW) * ts, HW * ts, hipMemcpyDeviceToHost));
   if (rooti) HIPCHK(h, hipMemcpy(rooti, h->d_rooti + L.cell_off * h->md.ncomponents + component * HW, HW * 4, hipMemcpyDeviceToHost));
   return PBD_OK;
 }
+int pbd_get_root(pbd_handle* h, int level, int component, float* rootv, int32_t* rooti) { return get_root_(h, level, component, rootv, rooti, 4); }
+int pbd_get_root_f64(pbd_handle* h, int level, int component, double* rootv, int32_t* rooti) { return get_root_(h, level, component, rootv, rooti, 8); }
 int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
   if (!h) return PBD_ERR_ARG;
   if (!h->have_dp) return fail(h, PBD_ERR_STATE, "argmin() before min()");
@@ -987,25 +1020,27 @@ int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int3
 }
 
 // ---- stand-alone primitives -------------------------------------------------
-int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, double bx, double ay, double by, int osx,
-             int osy, float* out, int32_t* ix, int32_t* iy) {
+static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, double bx, double ay, double by, int osx,
+                 int osy, void* out, int32_t* ix, int32_t* iy, int tsz) {
   if (!h || !in || rows <= 0 || cols <= 0 || rows > 32767 || cols > 32767) return PBD_ERR_ARG;
+  CHECK_SCALAR(h, tsz);
   if (ax == 0 || ay == 0) return fail(h, PBD_ERR_ARG, "a must be non-zero");
   HIPCHK(h, hipSetDevice(h->opt.device));
   const size_t HW = (size_t)rows * cols;
-  float *d_in, *d_tmp, *d_sdt, *d_zero, *d_out;
+  const size_t ts = (size_t)tsz;
+  char *d_in, *d_tmp, *d_sdt, *d_zero, *d_out;
   int16_t *d_ixT, *d_iy, *d_ox, *d_oy;
   uint8_t* d_ok;
-  HIPCHK(h, hipMalloc(&d_in, HW * 4)); HIPCHK(h, hipMalloc(&d_tmp, HW * 4)); HIPCHK(h, hipMalloc(&d_sdt, HW * 4));
-  HIPCHK(h, hipMalloc(&d_zero, HW * 4)); HIPCHK(h, hipMalloc(&d_out, HW * 4));
+  HIPCHK(h, hipMalloc(&d_in, HW * ts)); HIPCHK(h, hipMalloc(&d_tmp, HW * ts)); HIPCHK(h, hipMalloc(&d_sdt, HW * ts));
+  HIPCHK(h, hipMalloc(&d_zero, HW * ts)); HIPCHK(h, hipMalloc(&d_out, HW * ts));
   HIPCHK(h, hipMalloc(&d_ixT, HW * 2)); HIPCHK(h, hipMalloc(&d_iy, HW * 2));
   HIPCHK(h, hipMalloc(&d_ox, HW * 2)); HIPCHK(h, hipMalloc(&d_oy, HW * 2)); HIPCHK(h, hipMalloc(&d_ok, HW));
-  HIPCHK(h, hipMemcpyAsync(d_in, in, HW * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemsetAsync(d_zero, 0, HW * 4, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_in, in, HW * ts, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemsetAsync(d_zero, 0, HW * ts, h->stream));
   DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
-  const size_t budget = std::max<size_t>(40 * 1024, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 8, 1));
+  const size_t budget = std::max<size_t>(40 * 1024, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 8, 1, tsz));
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
-  DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget), dt_group(1, 1, cols, rows, budget)};
+  DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz), dt_group(1, 1, cols, rows, budget, tsz)};
   std::vector<DtTask> tasks;
   const bool use_wave_x = h->dt_mode == 2 && cols <= 512 && dtw_lds_bytes(cols) <= 160 * 1024;
   const bool use_wave_y = h->dt_mode == 2 && rows <= 512 && dtw_lds_bytes(rows) <= 160 * 1024;
@@ -1031,12 +1066,12 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   HIPCHK(h, hipMemcpyAsync(d_job, &J, sizeof(J), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
   if (use_wave_x) launch_dt_wave(d_tasks, nx, d_groups, d_maps, dtw_lds_bytes(cols), h->stream);
-  else launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, h->stream);
+  else launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, tsz, h->stream);
   if (use_wave_y) launch_dt_wave(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, dtw_lds_bytes(rows), h->stream);
-  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, h->stream);
-  launch_reduce(d_job, d_rblk, (int)rblk.size(), h->d_biasw, h->opt.dt_correct_ptr, h->stream);
+  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, tsz, h->stream);
+  launch_reduce(d_job, d_rblk, (int)rblk.size(), h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
-  HIPCHK(h, hipMemcpyAsync(out, d_out, HW * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out, d_out, HW * ts, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(hx.data(), d_ox, HW * 2, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(hy.data(), d_oy, HW * 2, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1045,9 +1080,18 @@ int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, doub
   hipFree(d_ox); hipFree(d_oy); hipFree(d_ok); hipFree(d_rblk); hipFree(d_maps); hipFree(d_groups); hipFree(d_tasks); hipFree(d_job);
   return PBD_OK;
 }
+int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, double bx, double ay, double by, int osx,
+             int osy, float* out, int32_t* ix, int32_t* iy) {
+  return dt2d_(h, in, rows, cols, ax, bx, ay, by, osx, osy, out, ix, iy, 4);
+}
+int pbd_dt2d_f64(pbd_handle* h, const double* in, int rows, int cols, double ax, double bx, double ay, double by, int osx,
+                 int osy, double* out, int32_t* ix, int32_t* iy) {
+  return dt2d_(h, in, rows, cols, ax, bx, ay, by, osx, osy, out, ix, iy, 8);
+}
 
-int pbd_hog_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, float* out, int* cell_w, int* cell_h) {
+static int hog_u8_(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, void* out, int* cell_w, int* cell_h, int ts) {
   if (!h || !im || w < 3 || hgt < 3 || (cn != 1 && cn != 3) || stride < w * cn) return PBD_ERR_ARG;
+  CHECK_SCALAR(h, ts);
   HIPCHK(h, hipSetDevice(h->opt.device));
   const int sbin = h->md.sbin;
   LevelDev L{};
@@ -1058,20 +1102,26 @@ int pbd_hog_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int str
   if (cell_h) *cell_h = L.ch;
   if (L.cw == 0 || L.ch == 0) return PBD_OK;
   int tc = 16;
-  while (tc > 2 && hog_lds_bytes(sbin, tc) > 150 * 1024) tc /= 2;
+  while (tc > 2 && hog_lds_bytes(sbin, tc, ts) > 150 * 1024) tc /= 2;
   std::vector<HogTile> tiles;
   for (int y = 0; y < L.ch; y += tc) for (int x = 0; x < L.cw; x += tc) tiles.push_back(HogTile{0, y, x, 0});
-  uint8_t* d_im; float* d_feat; LevelDev* d_lv; HogTile* d_tiles;
-  HIPCHK(h, hipMalloc(&d_im, (size_t)w * hgt * cn)); HIPCHK(h, hipMalloc(&d_feat, (size_t)L.cw * L.ch * PBD_FLEN * 4));
+  uint8_t* d_im; char* d_feat; LevelDev* d_lv; HogTile* d_tiles;
+  HIPCHK(h, hipMalloc(&d_im, (size_t)w * hgt * cn)); HIPCHK(h, hipMalloc(&d_feat, (size_t)L.cw * L.ch * PBD_FLEN * ts));
   HIPCHK(h, hipMalloc(&d_lv, sizeof(L))); HIPCHK(h, hipMalloc(&d_tiles, sizeof(HogTile) * tiles.size()));
   HIPCHK(h, hipMemcpy2D(d_im, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_lv, &L, sizeof(L), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_tiles, tiles.data(), sizeof(HogTile) * tiles.size(), hipMemcpyHostToDevice));
-  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, cn, sbin, tc, h->stream);
+  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, ts, cn, sbin, tc, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(out, d_feat, (size_t)L.cw * L.ch * PBD_FLEN * 4, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out, d_feat, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyDeviceToHost));
   hipFree(d_im); hipFree(d_feat); hipFree(d_lv); hipFree(d_tiles);
   return PBD_OK;
+}
+int pbd_hog_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, float* out, int* cell_w, int* cell_h) {
+  return hog_u8_(h, im, w, hgt, cn, stride, out, cell_w, cell_h, 4);
+}
+int pbd_hog_u8_f64(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, double* out, int* cell_w, int* cell_h) {
+  return hog_u8_(h, im, w, hgt, cn, stride, out, cell_w, cell_h, 8);
 }
 
 int pbd_resize_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, uint8_t* out, int ow, int oh) {

@@ -52,9 +52,11 @@ struct LevelDev {    // per level, device copy
 };
 struct ConvTile { int level, y0, x0, pad; };
 
+// Score data is T = float or double (the handle's instantiation, pbd_options.scalar_type); the work
+// tables carry untyped pointers and the kernels are instantiated for both.
 struct DtMap {       // one 1-D pass over one score map
-  const float* src;  // lines contiguous: line i at src + i*len
-  float* dst;        // transposed out: element q of line i at dst + q*nlines + i
+  const void* src;   // T: lines contiguous: line i at src + i*len
+  void* dst;         // T: transposed out: element q of line i at dst + q*nlines + i
   int16_t* ptr;      // same layout as dst
   double a, b;       // Quadratic(a, b)
   int os, ptr_natural;  // ptr_natural: write ptr row-major [line][q] instead of transposed
@@ -64,7 +66,7 @@ struct DtTask { int group, g0; };
 
 #define PBD_MAX_CH 8   // children of one parent folded into one reduce job
 struct ReduceChild {     // one child part's distance-transformed mixtures
-  const float* sdt;      // [K][H][W] distance-transformed child scores
+  const void* sdt;       // T [K][H][W] distance-transformed child scores
   const int16_t* ix;     // [K][H][W] x pointers (row-major)
   const int16_t* iy;     // [K][H][W] y pointers
   int16_t* ox; int16_t* oy; uint8_t* ok;  // output pointer planes of this child, [L][H][W]
@@ -73,21 +75,21 @@ struct ReduceChild {     // one child part's distance-transformed mixtures
 };
 struct ReduceJob {       // one (level, parent): fold the messages of nch children, in the reference's order
   int H, W, L, nch;
-  const float* par_in[PBD_MAX_MIX];  // parent mixture m: current score (resp plane or acc slot)
-  float* par_out[PBD_MAX_MIX];       // parent mixture m: acc slot
+  const void* par_in[PBD_MAX_MIX];   // T: parent mixture m: current score (resp plane or acc slot)
+  void* par_out[PBD_MAX_MIX];        // T: parent mixture m: acc slot
   ReduceChild ch[PBD_MAX_CH];        // descending child index (src/DynamicProgram.cpp:95)
 };
 struct ReduceBlock { int job; unsigned cell0; };  // one 256-thread block of k_reduce
 struct RootJob {
-  const float* score[PBD_MAX_MIX]; // root mixture m current score
-  float* rootv; int* rooti;
+  const void* score[PBD_MAX_MIX];  // T: root mixture m current score
+  void* rootv; int* rooti;         // rootv: T
   int H, W, K, level, comp;
   float bias;
   unsigned cell0;
 };
 struct BackLevel {   // per (level, comp) info for backtracking
   const int16_t* px; const int16_t* py; const uint8_t* pk; // plane 0 of this comp at this level
-  const float* rootv; const int* rooti;
+  const void* rootv; const int* rooti;   // rootv: T
   int H, W; float scale;
 };
 struct CandRec { int level, comp, y, x; };
@@ -117,7 +119,8 @@ struct pbd_handle {
   int conv_mode = PBD_CONV_EXACT;
 
   // device model
-  float* d_wT = nullptr;     // [kh*kw][flen][nfpad] filters transposed for the conv kernels
+  int ts = 4;                // sizeof(T): 4 = PartsBasedDetector<float>, 8 = PartsBasedDetector<double>
+  void* d_wT = nullptr;      // T [kh*kw][flen][nfpad] filters transposed (and converted to T) for the conv kernels
   int nfpad = 0;
   float* d_biasw = nullptr;
   int* d_parent = nullptr;   // [ncomp][max_parts] parent of each part
@@ -133,10 +136,10 @@ struct pbd_handle {
   // device frame buffers
   uint8_t* d_img = nullptr; size_t img_cap = 0;
   uint8_t* d_pyr = nullptr;
-  float* d_feat = nullptr; float* d_resp = nullptr; float* d_acc = nullptr;
+  char* d_feat = nullptr; char* d_resp = nullptr; char* d_acc = nullptr;   // T data, addressed in bytes (elements * ts)
   int16_t* d_px = nullptr; int16_t* d_py = nullptr; uint8_t* d_pk = nullptr;
-  float* d_rootv = nullptr; int* d_rooti = nullptr;
-  float* d_dt_tmpT = nullptr; float* d_dt_sdt = nullptr; int16_t* d_dt_ixT = nullptr; int16_t* d_dt_iy = nullptr;
+  char* d_rootv = nullptr; int* d_rooti = nullptr;
+  char* d_dt_tmpT = nullptr; char* d_dt_sdt = nullptr; int16_t* d_dt_ixT = nullptr; int16_t* d_dt_iy = nullptr;
   size_t dt_cap_elems = 0;
   LevelDev* d_levels = nullptr;
   HogTile* d_hog_tiles = nullptr; int n_hog_tiles = 0; int hog_tc = 16;
@@ -176,26 +179,38 @@ struct pbd_handle {
   std::vector<void*> frame_allocs;  // everything freed on re-plan
 };
 
+// ---- scalar helpers: the reference's std:: overloads resolve on T ---------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float t_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double t_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float t_floor(float v) { return floorf(v); }
+__device__ __forceinline__ double t_floor(double v) { return floor(v); }
+__device__ __forceinline__ float t_fmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double t_fmin(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ int t_round(float v) { return __float2int_rn(v); }    // cvRound: half to even
+__device__ __forceinline__ int t_round(double v) { return __double2int_rn(v); }
+#endif
+
 // ---- kernel launchers (k_*.hip) ----------------------------------------------
 void launch_resize(const ResizeArgs& a, const uint8_t* src, uint8_t* pyr, hipStream_t s);
 void launch_pyrdown(const PyrDownArgs& a, uint8_t* pyr, hipStream_t s);
-void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, float* feat,
+void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
                 int cn, int sbin, int tc, hipStream_t s);
-size_t hog_lds_bytes(int sbin, int tc);
-void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
-                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
+size_t hog_lds_bytes(int sbin, int tc, int ts);
+void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const void* feat,
+                       const void* wT, void* resp, int ts, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, int ts,
                     hipStream_t s);
-size_t dt_lds_bytes(int stride, int lpb, int nmb);
+size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts);
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
-                   hipStream_t s);
+                   int ts, hipStream_t s);
 void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
-                 int capacity, hipStream_t s);
+                 int capacity, int ts, hipStream_t s);
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
-                      char* out, size_t out_stride, hipStream_t s);
+                      char* out, size_t out_stride, int ts, hipStream_t s);
 void dt_debug_read(unsigned long long* out);
 void launch_dt_wave(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, hipStream_t s);
 size_t dtw_lds_bytes(int len);

@@ -1,18 +1,44 @@
 // demo.cpp — the reference's canonical caller (src/demo.cpp:55-118) against the MI355X path:
-//   pbd_demo model.bin image.raw width height channels [stagewise]
+//   pbd_demo model.bin image.raw width height channels [stagewise|double|stagewise-double]
 // deserialize -> distributeModel -> detect -> Candidate::sort, then prints the candidates (the
 // reference shows them in a window; here they go to stdout so tests can compare them).
 // `stagewise` walks pyramid -> pdf -> min -> argmin through the interface classes instead of the
-// fused detect() (src/PartsBasedDetector.cpp:73-89).
+// fused detect() (src/PartsBasedDetector.cpp:73-89); `double` runs PartsBasedDetector<double> like the
+// ROS node and the ecto cell (ros/Node.hpp:121, cells/detect.cpp:93) instead of <float> (src/demo.cpp:85).
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include "pbd_filestorage.hpp"
 using namespace pbd;
 
+template <typename T>
+static void run(Model& model, const Mat& im, bool stagewise) {
+  PartsBasedDetector<T> pbd(0, PBD_CONV_EXACT);
+  pbd.distributeModel(model);
+  vectorCandidate candidates;
+  if (stagewise) {
+    vectorMat pyramid;
+    pbd.features().pyramid(im, pyramid);
+    vector2DMat pdf, rootv, rooti;
+    pbd.convolutionEngine().pdf(pyramid, pdf);
+    pbd.dp().min(rootv, rooti, pbd.ncomponents(), pdf);
+    pbd.dp().argmin(candidates);
+  } else {
+    Mat depth;
+    pbd.detect(im, depth, candidates);
+  }
+  printf("Number of candidates: %ld\n", (long)candidates.size());
+  Candidate::sort(candidates);
+  for (const Candidate& c : candidates) {
+    printf("%.9g %d %d", c.score(), c.component(), c.level);
+    for (const Rect& r : c.parts()) printf(" %d,%d,%d,%d", r.x, r.y, r.width, r.height);
+    printf("\n");
+  }
+}
+
 int main(int argc, char** argv) {
   if (argc != 6 && argc != 7) {
-    printf("Usage: pbd_demo model_file image.raw width height channels [stagewise]\n");
+    printf("Usage: pbd_demo model_file image.raw width height channels [stagewise|double|stagewise-double]\n");
     exit(-1);
   }
   // determine the type of model to read (src/demo.cpp:63-82)
@@ -32,28 +58,11 @@ int main(int argc, char** argv) {
     exit(-4);
   }
   fclose(f);
+  const std::string mode = argc == 7 ? argv[6] : "";
+  const bool stagewise = mode.find("stagewise") != std::string::npos;
   try {
-    PartsBasedDetector<float> pbd(0, PBD_CONV_EXACT);
-    pbd.distributeModel(model);
-    vectorCandidate candidates;
-    if (argc == 7) {
-      vectorMat pyramid;
-      pbd.features().pyramid(im, pyramid);
-      vector2DMat pdf, rootv, rooti;
-      pbd.convolutionEngine().pdf(pyramid, pdf);
-      pbd.dp().min(rootv, rooti, pbd.ncomponents(), pdf);
-      pbd.dp().argmin(candidates);
-    } else {
-      Mat depth;
-      pbd.detect(im, depth, candidates);
-    }
-    printf("Number of candidates: %ld\n", (long)candidates.size());
-    Candidate::sort(candidates);
-    for (const Candidate& c : candidates) {
-      printf("%.9g %d %d", c.score(), c.component(), c.level);
-      for (const Rect& r : c.parts()) printf(" %d,%d,%d,%d", r.x, r.y, r.width, r.height);
-      printf("\n");
-    }
+    if (mode.find("double") != std::string::npos) run<double>(model, im, stagewise);
+    else run<float>(model, im, stagewise);
   } catch (const Exception& e) {
     printf("error %d: %s\n", e.code, e.what());
     return 1;

@@ -12,7 +12,8 @@
 // The reference passes cv::Mat; OpenCV is not a dependency of this library, so a minimal dense
 // matrix (pbd::Mat: rows, cols, channels, 8U/32S/32F) carries the same data.  The OpenCV-typed
 // adaptors for dropping the engines into the reference tree itself are in INTEGRATION.md.
-// All numerics run in libpbd_hip.so; this header only marshals.  T = float.
+// All numerics run in libpbd_hip.so; this header only marshals.  T = float or double, the two
+// instantiations the reference declares (src/PartsBasedDetector.cpp:132-133).
 #ifndef PBD_HOST_HPP_
 #define PBD_HOST_HPP_
 
@@ -29,7 +30,10 @@
 
 namespace pbd {
 
-enum { PBD_8U = 0, PBD_32S = 4, PBD_32F = 5 };  // depth codes (numerically OpenCV's CV_8U/32S/32F)
+enum { PBD_8U = 0, PBD_32S = 4, PBD_32F = 5, PBD_64F = 6 };  // depth codes (numerically OpenCV's CV_8U/32S/32F/64F)
+template <typename T> struct DataType;               // cv::DataType<T>::type
+template <> struct DataType<float> { enum { type = PBD_32F, scalar = PBD_SCALAR_F32 }; };
+template <> struct DataType<double> { enum { type = PBD_64F, scalar = PBD_SCALAR_F64 }; };
 
 class Exception : public std::runtime_error {   // plays the role of cv::Exception
  public:
@@ -49,7 +53,7 @@ class Mat {
   bool empty() const { return buf_.empty(); }
   int depth() const { return depth_; }
   int channels() const { return cn_; }
-  size_t elem1() const { return depth_ == PBD_8U ? 1 : 4; }
+  size_t elem1() const { return depth_ == PBD_8U ? 1 : depth_ == PBD_64F ? 8 : 4; }
   size_t step() const { return (size_t)cols * cn_ * elem1(); }
   template <typename T> T* ptr(int r = 0) { return (T*)(buf_.data() + (size_t)r * step()); }
   template <typename T> const T* ptr(int r = 0) const { return (const T*)(buf_.data() + (size_t)r * step()); }
@@ -202,9 +206,10 @@ class BinaryModel : public Model {
 class Device {
  public:
   pbd_handle* h = nullptr;
+  int scalar = PBD_SCALAR_F32;   // T of the detector that owns this device (cv::DataType<T>::type)
   std::vector<float> filters, defw, biasw;
   std::vector<int32_t> anchors, part_offset, parentid, mix_offset, filterid, defid, biasid;
-  Device(Model& m, int device, int conv_mode) {
+  Device(Model& m, int device, int conv_mode, int scalar_type = PBD_SCALAR_F32) {
     pbd_model_desc d{};
     const int kh = m.filters()[0].rows, kw = m.filters()[0].cols / m.flen();
     for (Mat& f : m.filters()) filters.insert(filters.end(), f.ptr<float>(), f.ptr<float>() + (size_t)kh * kw * m.flen());
@@ -232,7 +237,8 @@ class Device {
     d.part_offset = part_offset.data(); d.parentid = parentid.data(); d.mix_offset = mix_offset.data();
     d.filterid = filterid.data(); d.defid = defid.data(); d.biasid = biasid.data();
     pbd_options opt{};
-    opt.device = device; opt.conv_mode = conv_mode;
+    opt.device = device; opt.conv_mode = conv_mode; opt.scalar_type = scalar_type;
+    scalar = scalar_type;
     const int rc = pbd_create(&d, &opt, &h);
     if (rc != PBD_OK) { std::string msg = h ? pbd_last_error(h) : "pbd_create failed"; if (h) pbd_destroy(h); h = nullptr; throw Exception(rc, msg); }
   }
@@ -267,8 +273,11 @@ class HipHOGFeatures : public IFeatures {          // include/HOGFeatures.hpp:52
     dev_->check(pbd_pyramid_geometry(dev_->h, im.cols, im.rows, &n, 0, 0, cw.data(), ch.data(), scales_.data()));
     pyrafeatures.clear(); pyrafeatures.resize(n);
     for (int l = 0; l < n; ++l) {
-      pyrafeatures[l].create(ch[l], cw[l] * 32, PBD_32F);
-      if (ch[l] > 0 && cw[l] > 0) dev_->check(pbd_get_level_features(dev_->h, l, pyrafeatures[l].ptr<float>()));
+      const bool f64 = dev_->scalar == PBD_SCALAR_F64;   // HOGFeatures<T>: Mat of DataType<T>::type
+      pyrafeatures[l].create(ch[l], cw[l] * 32, f64 ? PBD_64F : PBD_32F);
+      if (ch[l] > 0 && cw[l] > 0)
+        dev_->check(f64 ? pbd_get_level_features_f64(dev_->h, l, pyrafeatures[l].ptr<double>())
+                        : pbd_get_level_features(dev_->h, l, pyrafeatures[l].ptr<float>()));
     }
   }
 };
@@ -291,8 +300,11 @@ class HipConvolutionEngine : public IConvolutionEngine {   // include/SpatialCon
     responses.assign(features.size(), vectorMat(nfilters_));
     for (size_t l = 0; l < features.size(); ++l)
       for (size_t n = 0; n < nfilters_; ++n) {
-        responses[l][n].create(features[l].rows, features[l].cols / 32, PBD_32F);
-        if (!responses[l][n].empty()) dev_->check(pbd_get_level_response(dev_->h, (int)l, (int)n, responses[l][n].ptr<float>()));
+        const bool f64 = dev_->scalar == PBD_SCALAR_F64;   // SpatialConvolutionEngine(type_)
+        responses[l][n].create(features[l].rows, features[l].cols / 32, f64 ? PBD_64F : PBD_32F);
+        if (!responses[l][n].empty())
+          dev_->check(f64 ? pbd_get_level_response_f64(dev_->h, (int)l, (int)n, responses[l][n].ptr<double>())
+                          : pbd_get_level_response(dev_->h, (int)l, (int)n, responses[l][n].ptr<float>()));
       }
   }
 };
@@ -327,11 +339,13 @@ class DynamicProgram {
     rooti.assign(scores.size(), vectorMat(ncomponents));
     for (size_t l = 0; l < scores.size(); ++l)
       for (int c = 0; c < ncomponents; ++c) {
-        rootv[l][c].create(scores[l][0].rows, scores[l][0].cols, PBD_32F);
+        rootv[l][c].create(scores[l][0].rows, scores[l][0].cols, DataType<T>::type);
         rooti[l][c].create(scores[l][0].rows, scores[l][0].cols, PBD_32S);
-        if (!rootv[l][c].empty()) dev_->check(pbd_get_root(dev_->h, (int)l, c, rootv[l][c].ptr<float>(), rooti[l][c].ptr<int32_t>()));
+        if (!rootv[l][c].empty()) dev_->check(get_root(dev_->h, (int)l, c, rootv[l][c].template ptr<T>(), rooti[l][c].ptr<int32_t>()));
       }
   }
+  static int get_root(pbd_handle* h, int l, int c, float* v, int32_t* i) { return pbd_get_root(h, l, c, v, i); }
+  static int get_root(pbd_handle* h, int l, int c, double* v, int32_t* i) { return pbd_get_root_f64(h, l, c, v, i); }
   void argmin(vectorCandidate& candidates, int capacity = 4096) {
     const int mp = pbd_max_parts(dev_->h);
     std::vector<pbd_candidate_head> heads(capacity);
@@ -359,10 +373,11 @@ class PartsBasedDetector {
   DynamicProgram<T>& dp() { return dp_; }
   int ncomponents() const { return ncomponents_; }
   void distributeModel(Model& model) {             // src/PartsBasedDetector.cpp:102-127
-    static_assert(sizeof(T) == sizeof(float), "T = float (double: SURVEY 8f)");
     name_ = model.name();
     ncomponents_ = model.ncomponents();
-    dev_ = std::make_shared<Device>(model, device_, conv_mode_);
+    // DataType<T>::type selects the instantiation (:110,113-117); the double one runs the exact filter bank
+    const int cm = (DataType<T>::scalar == PBD_SCALAR_F64 && conv_mode_ == PBD_CONV_AUTO) ? PBD_CONV_EXACT : conv_mode_;
+    dev_ = std::make_shared<Device>(model, device_, cm, (int)DataType<T>::scalar);
     features_.reset(new HipHOGFeatures(dev_, model.binsize(), model.nscales()));
     convolution_engine_.reset(new HipConvolutionEngine(dev_));
     convolution_engine_->setFilters(model.filters());
