@@ -23,11 +23,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def pick_threshold(capi, model, d_img, w, h, q=99.9):
+def pick_threshold(capi, model, d_img, w, h, q=99.9, dtype=np.float32):
     """99.9-th percentile of the root scores of the seed frame, computed with the
     product path itself (pbd_get_root), so roughly 140 candidates per frame are back-tracked."""
     model.thresh = 3.0e38
-    hd = capi.Handle(model, device=d_img.device.index, conv_mode=capi.PBD_CONV_AUTO)
+    hd = capi.Handle(model, device=d_img.device.index, conv_mode=capi.PBD_CONV_AUTO if dtype == np.float32 else capi.PBD_CONV_EXACT,
+                     dtype=dtype)
     hd.detect_dev(d_img.data_ptr(), w, h, 3)
     hd._geo = hd.geometry(w, h)
     vals = np.concatenate([hd.root(l, 0)[0].ravel() for l in range(hd._geo["nlevels"])])
@@ -47,6 +48,9 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--mixtures", type=int, default=6)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
+                    help="instantiation: f32 = PartsBasedDetector<float> (BASELINE.json metric), f64 = <double> "
+                         "(SURVEY 8f-3: the ROS node / ecto cell instantiation; exact VALU filter bank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU-side smoke runs)")
     args = ap.parse_args()
@@ -75,14 +79,17 @@ def main():
     W, H = args.width, args.height
     model = make_person_model(K=args.mixtures)
     conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA}[args.conv]
+    dtype = np.float64 if args.dtype == "f64" else np.float32
+    if args.dtype == "f64":
+        conv = capi.PBD_CONV_EXACT
     # distinct frames per rank and per step slot (32 seeds as in configs[2]); resident in HBM
     nimg = 8
     frames = [torch.from_numpy(make_image(rank * nimg + i, W, H)).to(dev) for i in range(nimg)]
     torch.cuda.synchronize()
-    model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).to(dev), W, H)
+    model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).to(dev), W, H, dtype=dtype)
 
     S = max(1, args.inflight)
-    handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=4096) for _ in range(S)]
+    handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=4096, dtype=dtype) for _ in range(S)]
     for hd in handles:
         hd.set_profiling(True)
 
@@ -154,7 +161,7 @@ def main():
         pdf_tf = work["F_pdf"] / (stage["pdf"] * 1e-3) / 1e12 if stage["pdf"] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_dp.json")
-        if os.path.exists(tpath) and (W, H, args.mixtures) == (640, 480, 6):
+        if os.path.exists(tpath) and (W, H, args.mixtures, args.dtype) == (640, 480, 6, "f32"):
             traffic = json.load(open(tpath))["hbm_bytes_per_frame_corrected"]
         if stage["dp_min"] >= stage["pdf"]:
             roof = {"kernel": "dp_min stage = 18 x k_dt_pass + 9 x k_reduce + k_root per frame", "bound": "hbm",
@@ -162,15 +169,17 @@ def main():
                     "traffic": traffic, "launch_ms": round(float(dp_ms), 4), "algorithmic_bytes": work["B_dp"],
                     "timing": f"HIP events around the stage, mean of {nseq} sequential frames after the timed loop"}
         else:
+            peak = 78.6 if args.dtype == "f64" else 157.3     # dense vector/matrix FMA peak of the dtype (MI355X_MICROARCH.md)
             roof = {"kernel": "pdf filter bank (k_conv_mfma, fp32 MFMA)" if conv != capi.PBD_CONV_EXACT
-                    else "pdf filter bank (k_conv_exact, VALU)", "bound": "mfma", "achieved": round(pdf_tf, 3),
-                    "peak": 157.3, "unit": "TFLOP/s", "frac": round(pdf_tf / 157.3, 5), "traffic": None,
+                    else f"pdf filter bank (k_conv_exact<{args.dtype}>, VALU, reference summation order)", "bound": "mfma",
+                    "achieved": round(pdf_tf, 3),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(pdf_tf / peak, 5), "traffic": None,
                     "launch_ms": round(float(stage["pdf"]), 4), "algorithmic_flops": work["F_pdf"]}
         line = {
             "metric": "detect() frames/sec, 640x480, 26-part person model",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"person 26 parts x {args.mixtures} mixtures ({len(model.filtersw)} 5x5x32 filters), "
                                    f"{W}x{H} BGR, full pyramid ({hd.geometry(W, H)['nlevels']} levels), "
                                    f"threshold = 99.9th pct of root scores",
@@ -187,7 +196,7 @@ def main():
             from oracle import orc
             im = make_image(0, W, H)
             t = time.perf_counter()
-            _, _, _, ms = orc.detect(model, im)[:4]
+            _, _, _, ms = orc.detect(model, im, dtype=dtype)[:4]
             cdt = time.perf_counter() - t
             line["cpu_baseline"] = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": orc.num_threads(),
                                     "kind": "port", "sample": "1 frame 640x480, same model, oracle/pbd_oracle.c "

@@ -149,6 +149,103 @@ __global__ __launch_bounds__(256) void k_conv_exact(const ConvTile* __restrict__
   }
 }
 
+// double instantiation of the exact filter bank.  A 20x20-cell tile of 32 doubles is 105 KB of LDS (one
+// workgroup per CU), so the tile is staged in two 16-channel halves (53 KB: three workgroups per CU).  The
+// reference's order survives: channels are still visited 0..31, each channel's tap chain starts from
+// zero and the channel partials are added to the running total in channel order (`pdf += pdfc`, :92);
+// the totals of the workgroup's GPW filter groups simply stay in registers across the two halves.
+#define CHALF 16     // channels staged per pass
+#define CSTRH 17     // LDS doubles per cell and pass (16 + 1 pad)
+template <int KH, int KW, int GPW>
+__global__ __launch_bounds__(256) void k_conv_exact_f64(const ConvTile* __restrict__ tiles,
+                                                        const LevelDev* __restrict__ levels,
+                                                        const double* __restrict__ feat, const double* __restrict__ wT,
+                                                        double* __restrict__ resp, int nf, int nfpad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* ft = (double*)smem;  // [(CT+KH-1)][(CT+KW-1)][CSTRH]
+  const ConvTile t = tiles[blockIdx.x];
+  const LevelDev lv = levels[t.level];
+  const int H = lv.ch, W = lv.cw;
+  constexpr int TW = CT + KW - 1, TH = CT + KH - 1;
+  const int tid = threadIdx.x;
+  const double* F = feat + lv.cell_off * PBD_FLEN;
+  const int ly = tid >> 4, lx = tid & 15;
+  const int oy = t.y0 + ly, ox = t.x0 + lx;
+  const bool valid = (oy < H && ox < W);
+  const double* fbase = ft + (ly * TW + lx) * CSTRH;
+  double* R = resp + lv.cell_off * nf;
+  const int g0 = blockIdx.y * GPW;
+  double tot[GPW][NFG];
+#pragma unroll
+  for (int g = 0; g < GPW; ++g)
+#pragma unroll
+    for (int n = 0; n < NFG; ++n) tot[g][n] = 0.0;
+  for (int half = 0; half < PBD_FLEN / CHALF; ++half) {
+    if (half) __syncthreads();   // everyone is done with the previous half
+    {  // stage 16 channels of every cell: 8 lanes x double2 per cell, batches of independent loads
+      constexpr int LPC = CHALF / 2, N = TH * TW * LPC, NB = (N + 255) / 256, BATCH = 7;
+      for (int j0 = 0; j0 < NB; j0 += BATCH) {
+        double2 r[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const int i = min(tid + (j0 + j) * 256, N - 1);
+          const int cell = i / LPC, q = i - cell * LPC;
+          const int ty = cell / TW, tx = cell - ty * TW;
+          const int y = min(max(t.y0 + ty - KH / 2, 0), H - 1), x = min(max(t.x0 + tx - KW / 2, 0), W - 1);
+          r[j] = *(const double2*)(F + ((size_t)y * W + x) * PBD_FLEN + half * CHALF + q * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const int i = tid + (j0 + j) * 256;
+          if (i < N) {
+            const int cell = i / LPC, q = i - cell * LPC;
+            const int ty = cell / TW, tx = cell - ty * TW;
+            const int y = t.y0 + ty - KH / 2, x = t.x0 + tx - KW / 2;
+            double2 v = r[j];
+            if (!(y >= 0 && y < H && x >= 0 && x < W))     // border 0, 1 for the truncation channel (:147-155)
+              v = make_double2(0.0, (half == PBD_FLEN / CHALF - 1 && q == LPC - 1) ? 1.0 : 0.0);
+            double* d = ft + cell * CSTRH + q * 2;
+            d[0] = v.x; d[1] = v.y;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+      const int n0 = (g0 + g) * NFG;
+      if (n0 >= nf) break;
+      for (int cc = 0; cc < CHALF; ++cc) {
+        const int c = half * CHALF + cc;
+        double acc[NFG];
+#pragma unroll
+        for (int n = 0; n < NFG; ++n) acc[n] = 0.0;
+#pragma unroll
+        for (int i = 0; i < KH; ++i) {
+#pragma unroll
+          for (int j = 0; j < KW; ++j) {
+            const double f = fbase[(i * TW + j) * CSTRH + cc];
+            const double* w = wT + ((size_t)(i * KW + j) * PBD_FLEN + c) * nfpad + n0;  // wave-uniform
+#pragma unroll
+            for (int n = 0; n < NFG; ++n) acc[n] += w[n] * f;
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NFG; ++n) tot[g][n] += acc[n];
+      }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+      const int n0 = (g0 + g) * NFG;
+#pragma unroll
+      for (int n = 0; n < NFG; ++n)
+        if (n0 + n < nf) R[(size_t)(n0 + n) * H * W + (size_t)oy * W + ox] = tot[g][n];
+    }
+  }
+}
+
 // generic-size fallback (runtime kh, kw <= 9)
 template <typename T>
 __global__ __launch_bounds__(256) void k_conv_exact_generic(const ConvTile* __restrict__ tiles,
@@ -195,6 +292,18 @@ template <typename T>
 static void launch_conv_exact_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
                                 const T* wT, T* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
   const size_t lds = sizeof(T) * (CT + kh - 1) * (CT + kw - 1) * CSTR;
+  if constexpr (sizeof(T) == 8) {
+    if (kh == 5 && kw == 5) {
+      constexpr int GPW = 4;
+      const size_t ldsh = sizeof(double) * (CT + 4) * (CT + 4) * CSTRH;
+      static bool cfg64 = false;
+      if (!cfg64) { hipFuncSetAttribute((const void*)k_conv_exact_f64<5, 5, GPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh); cfg64 = true; }
+      const int groups = (nf + NFG - 1) / NFG;
+      dim3 grid(ntiles, (groups + GPW - 1) / GPW);
+      hipLaunchKernelGGL((k_conv_exact_f64<5, 5, GPW>), grid, dim3(256), ldsh, s, tiles, levels, feat, wT, resp, nf, nfpad);
+      return;
+    }
+  }
   if (kh == 5 && kw == 5) {
     static bool cfg = false;   // one per instantiation
     if (!cfg) { hipFuncSetAttribute((const void*)k_conv_exact<T, 5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }

@@ -1244,19 +1244,20 @@ int pbd_get_work(const pbd_handle* h, double work[6]) {
     C += (double)h->lv[l].cw * h->lv[l].ch;
     pix += (double)h->lv[l].iw * h->lv[l].ih * h->fcn;
   }
-  // reference element types (float32 scores, int32 pointers)
+  // reference element types (scores of type T: 4 or 8 bytes, int32 pointers)
+  const double ts = h->ts;
   double per_cell = 0, dtmaps = 0;
   for (int c = 0; c < m.ncomponents; ++c) {
     const int p0 = h->part_offset[c], cnp = h->part_offset[c + 1] - p0;
     for (int p = 1; p < cnp; ++p) {
       const double K = h->parts[p0 + p].K, L = h->parts[p0 + h->parts[p0 + p].parent].K;
-      per_cell += 4 * K + 12 * L + 8 * L;
+      per_cell += ts * K + 12 * L + 2 * ts * L;
       dtmaps += K;
     }
-    per_cell += 4 * h->parts[p0].K + 8;
+    per_cell += ts * h->parts[p0].K + ts + 4;
   }
-  work[0] = pix + 128.0 * C;
-  work[1] = 128.0 * C + 4.0 * m.nfilters * C + 4.0 * m.nfilters * m.kh * m.kw * m.flen;
+  work[0] = pix + 32.0 * ts * C;
+  work[1] = 32.0 * ts * C + ts * m.nfilters * C + ts * m.nfilters * m.kh * m.kw * m.flen;
   work[2] = 2.0 * C * m.nfilters * m.kh * m.kw * m.flen;
   work[3] = C * per_cell;
   work[4] = C;

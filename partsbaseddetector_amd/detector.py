@@ -173,11 +173,13 @@ class DynamicProgram:
 
 
 class PartsBasedDetector:
-    """PartsBasedDetector<float> (include/PartsBasedDetector.hpp:152-175)."""
+    """PartsBasedDetector<T> (include/PartsBasedDetector.hpp:152-175); dtype = np.float32 (src/demo.cpp:85)
+    or np.float64 (ros/Node.hpp:121, cells/detect.cpp:93) picks the instantiation."""
 
     def __init__(self, device: int = 0, conv_mode: int = capi.PBD_CONV_AUTO, max_candidates: int = 4096,
-                 level_begin: int = 0, level_end: int = 0):
+                 level_begin: int = 0, level_end: int = 0, dtype=np.float32):
         self._device, self._conv, self._cap = device, conv_mode, max_candidates
+        self._dtype = np.dtype(dtype)
         self._lb, self._le = level_begin, level_end
         self._h: Optional[capi.Handle] = None
         self._name = ""
@@ -189,7 +191,8 @@ class PartsBasedDetector:
     def distributeModel(self, model: Model) -> None:
         """src/PartsBasedDetector.cpp:102-127."""
         self._name = model.name
-        self._h = capi.Handle(model, self._device, self._conv, self._cap, 0, self._lb, self._le)
+        conv = capi.PBD_CONV_EXACT if (self._dtype == np.float64 and self._conv == capi.PBD_CONV_AUTO) else self._conv
+        self._h = capi.Handle(model, self._device, conv, self._cap, 0, self._lb, self._le, dtype=self._dtype)
         self.features_ = HOGFeatures(self._h)
         self.convolution_engine_ = SpatialConvolutionEngine(self._h)
         self.convolution_engine_.setFilters(model.filtersw)

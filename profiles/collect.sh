@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
+#   bash profiles/collect.sh r01c
+# writes gpurun_out/<tag>/{stats_seq,stats,pmc_fetch,pmc_write,pmc_clk}/ + bench JSON lines; afterwards
+#   python profiles/summarize.py gpurun_out/<tag> <tag>     (here, on the merged gpurun_out)
+# turns them into profiles/<tag>_*.  Counters run in their own passes (--pmc with --kernel-trace only).
+set -u
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+B="python $REPO/bench.py"
+# throughput line (default flags) and the sequential line
+$B --steps 300 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+$B --steps 100 --inflight 1 --no-cpu-baseline > "$OUT/bench_n1_inflight1.json" 2>> "$OUT/bench_n1.err"
+$B --steps 50 --dtype f64 > "$OUT/bench_n1_f64.json" 2>> "$OUT/bench_n1.err"
+# per-kernel durations: sequential (undisturbed) and default (3 frames in flight)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_seq" -o run -- $B --steps 20 --warmup 3 --inflight 1 --no-cpu-baseline > "$OUT/stats_seq.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $B --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_f64" -o run -- $B --steps 10 --warmup 2 --inflight 1 --dtype f64 --no-cpu-baseline > "$OUT/stats_f64.log" 2>&1
+# HBM traffic and clock: one counter per pass
+for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o run -- $B --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline > "$OUT/pmc_$c.log" 2>&1
+done
+ls -R "$OUT" | head -60

@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Turn the rocprofv3 CSVs written by profiles/collect.sh into the committed summaries.
+
+    python profiles/summarize.py gpurun_out/r01c r01c
+
+writes profiles/<tag>_rocprof_summary.md, profiles/<tag>_kernel_stats*.csv, profiles/<tag>_bench_*.json
+and refreshes profiles/traffic_dp.json (HBM bytes per frame of the dp_min stage from the PMC passes,
+FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes; per-pass frame counts are read from the trace).
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "")
+    return n
+
+
+def stats_table(d):
+    f = glob.glob(os.path.join(src, d, "*kernel_stats.csv")) + glob.glob(os.path.join(src, d, "*", "*kernel_stats.csv"))
+    if not f:
+        return None, None
+    rows = list(csv.DictReader(open(f[0])))
+    out = ["| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---|---|---|---|---|---|"]
+    for r in rows:
+        out.append(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | "
+                   f"{r['Percentage']} | {int(r['MinNs']) / 1e3:.2f} | {int(r['MaxNs']) / 1e3:.2f} |")
+    return "\n".join(out), f[0]
+
+
+def pmc(counter):
+    f = glob.glob(os.path.join(src, f"pmc_{counter}", "*counter_collection.csv")) + \
+        glob.glob(os.path.join(src, f"pmc_{counter}", "*", "*counter_collection.csv"))
+    if not f:
+        return {}
+    acc = {}
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        a = acc.setdefault(k, [0, 0.0, 0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+        a[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return acc
+
+
+md = [f"# {tag}: rocprofv3 summaries (MI355X, gfx950).  Collected by `profiles/collect.sh {tag}` (run from the repo root "
+      "through gpurun), summarised by `profiles/summarize.py`.  bench.py = 26x6 person model, 640x480.", ""]
+for d, title in (("stats_seq", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --inflight 1 --no-cpu-baseline\n"
+                  "(sequential frames: per-kernel durations undisturbed)"),
+                 ("stats", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline\n"
+                  "(default: 3 frames in flight on 3 streams; kernels of different frames overlap)"),
+                 ("stats_f64", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --inflight 1 --dtype f64 --no-cpu-baseline\n"
+                  "(PartsBasedDetector<double>, sequential)")):
+    t, path = stats_table(d)
+    if t:
+        md += [f"## {title}", t, ""]
+        shutil.copy(path, os.path.join(HERE, f"{tag}_kernel_{d}.csv"))
+fetch, write, clk = pmc("FETCH_SIZE"), pmc("WRITE_SIZE"), pmc("GRBM_GUI_ACTIVE")
+if fetch:
+    nframes = max(1, fetch.get("k_root<float>", fetch.get("k_root", [1]))[0])
+    md += ["## PMC passes (one counter per run): rocprofv3 --pmc <C> --kernel-trace -- python bench.py --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline",
+           f"({nframes} frames per run.)  FETCH_SIZE / WRITE_SIZE are in KB; gfx950 note (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
+           "under-reports coalesced streaming reads by 2x — RAW values here, `traffic_dp.json` applies the x2.  "
+           "GRBM_GUI_ACTIVE sums the 8 XCDs: clock = value / 8 / duration.",
+           "| kernel | calls | FETCH KB/call | WRITE KB/call | FETCH MB/frame (raw) | WRITE MB/frame | clock GHz |", "|---|---|---|---|---|---|---|"]
+    for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+        f_, w_ = fetch[k], write.get(k, [1, 0.0, 1])
+        c_ = clk.get(k)
+        ghz = f"{c_[1] / 8 / c_[2]:.2f}" if c_ and c_[2] else "-"
+        md.append(f"| `{k}` | {f_[0]} | {f_[1] / f_[0]:.1f} | {w_[1] / max(w_[0], 1):.1f} | {f_[1] / nframes / 1e3:.1f} | "
+                  f"{w_[1] / nframes / 1e3:.1f} | {ghz} |")
+    dpk = [k for k in fetch if k.startswith(("k_dt_pass", "k_reduce", "k_root"))]
+    fb = sum(fetch[k][1] for k in dpk) * 1e3 / nframes
+    wb = sum(write.get(k, [0, 0.0])[1] for k in dpk) * 1e3 / nframes
+    json.dump({"round": tag, "source": f"profiles/{tag}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --inflight 1)",
+               "kernels": sorted(dpk), "fetch_bytes_raw": fb, "write_bytes": wb,
+               "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated, taken as is",
+               "hbm_bytes_per_frame_corrected": 2 * fb + wb}, open(os.path.join(HERE, "traffic_dp.json"), "w"), indent=1)
+    md += ["", f"dp_min stage ({', '.join(sorted(dpk))}): fetch {fb / 1e6:.1f} MB raw (x2 = {2 * fb / 1e6:.1f} MB) + write {wb / 1e6:.1f} MB "
+           f"= {(2 * fb + wb) / 1e6:.1f} MB per frame (algorithmic B_dp: see bench line)."]
+for b in ("bench_n1.json", "bench_n1_inflight1.json", "bench_n1_f64.json"):
+    p = os.path.join(src, b)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(HERE, f"{tag}_{b}"))
+        md += ["", f"## {b}", "```", open(p).read().strip(), "```"]
+open(os.path.join(HERE, f"{tag}_rocprof_summary.md"), "w").write("\n".join(md) + "\n")
+print("wrote", os.path.join(HERE, f"{tag}_rocprof_summary.md"))

@@ -65,5 +65,45 @@ def main():
     print("wrote", os.path.join(OUT, "golden_v1.npz"), sum(v.nbytes for v in g.values()), "bytes raw")
 
 
+def main_f64():
+    """Regression vectors of the T = double instantiation (oracle/pbd_oracle_T.inc with T = double)."""
+    F = np.float64
+    rng = np.random.default_rng(20260928)
+    g = {}
+    for i, (r, c) in enumerate([(7, 9), (23, 31), (40, 57)]):
+        a = rng.normal(0, 1.5, (r, c))
+        if i == 2:
+            a = np.round(a)
+        par = (-0.01 - 0.01 * i, 0.002 * i, -0.02, -0.001 * i, i - 1, 1 - i)
+        out, ix, iy = orc.dt2d(a, *par, dtype=F)
+        g[f"dt{i}_in"], g[f"dt{i}_par"] = a, np.asarray(par, F)
+        g[f"dt{i}_out"], g[f"dt{i}_ix"], g[f"dt{i}_iy"] = out, ix.astype(np.int16), iy.astype(np.int16)
+    im = make_image(11, 72, 56)
+    g["im"] = im
+    g["hog_sbin4"] = orc.hog(im, 4, dtype=F)
+    g["hog_gray_sbin4"] = orc.hog(np.ascontiguousarray(im[..., 1]), 4, dtype=F)
+    m = make_tree_model([-1, 0, 0], 2, seed=42)
+    feat = orc.hog(make_image(12, 60, 48), 4, dtype=F)
+    g["pdf_resp"] = orc.pdf_level(feat, m.filtersw, dtype=F)
+    resp = rng.normal(0, 1, (len(m.filtersw), 11, 14))
+    Ix, Iy, Ik, rv, ri = orc.dp_min_level(m.to_desc(), 0, resp, dtype=F)
+    g["dp_resp"], g["dp_ix"], g["dp_iy"], g["dp_ik"] = resp, Ix.astype(np.int16), Iy.astype(np.int16), Ik.astype(np.int8)
+    g["dp_rootv"], g["dp_rooti"] = rv, ri.astype(np.int8)
+    model, img = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5), make_image(0, 120, 90)
+    model.thresh = -1e30
+    fr = orc.detect(model, img, capacity=1, keep=True, dtype=F)[4]
+    vals = np.concatenate([fr.root(l)[0].ravel() for l in range(fr.nlevels)])
+    fr.free()
+    model.thresh = float(np.float32(np.percentile(vals, 99.0)))
+    heads, boxes, locs, _ = orc.detect(model, img, dtype=F)
+    g["e2e_tree_thresh"] = np.float32(model.thresh)
+    g["e2e_tree_heads"] = np.stack([heads["score"].view(np.int32), heads["component"], heads["level"], heads["nparts"]], 1)
+    g["e2e_tree_boxes"], g["e2e_tree_locs"] = boxes.astype(np.int16), locs.astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, "golden_f64_v1.npz"), **g)
+    print("wrote", os.path.join(OUT, "golden_f64_v1.npz"), sum(v.nbytes for v in g.values()), "bytes raw")
+
+
 if __name__ == "__main__":
-    main()
+    if "--f64-only" not in sys.argv:
+        main()
+    main_f64()

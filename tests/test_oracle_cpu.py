@@ -216,3 +216,80 @@ def test_person_model_layout():
     d = m.to_desc()
     assert (d.nfilters, d.ndefs, d.nbias, d.ncomponents) == (156, 150, 901, 1)
     assert m.max_parts == 26 and all(m.parentid[0][p] < p for p in range(1, 26))
+
+
+# ---------------------------------------------------------------- T = double instantiation (oracle/pbd_oracle_T.inc)
+GOLD64 = os.path.join(os.path.dirname(__file__), "golden", "golden_f64_v1.npz")
+F64 = np.float64
+
+
+def _b64(a):
+    return np.ascontiguousarray(a, F64).view(np.uint64)
+
+
+def test_golden_f64(orc):
+    gold = np.load(GOLD64)
+    for i in range(3):
+        par = gold[f"dt{i}_par"]
+        out, ix, iy = orc.dt2d(gold[f"dt{i}_in"], *[float(x) for x in par[:4]], int(par[4]), int(par[5]), dtype=F64)
+        np.testing.assert_array_equal(_b64(out), _b64(gold[f"dt{i}_out"]))
+        np.testing.assert_array_equal(ix, gold[f"dt{i}_ix"]); np.testing.assert_array_equal(iy, gold[f"dt{i}_iy"])
+    im = gold["im"]
+    np.testing.assert_array_equal(_b64(orc.hog(im, 4, dtype=F64)), _b64(gold["hog_sbin4"]))
+    np.testing.assert_array_equal(_b64(orc.hog(np.ascontiguousarray(im[..., 1]), 4, dtype=F64)), _b64(gold["hog_gray_sbin4"]))
+    m = make_tree_model([-1, 0, 0], 2, seed=42)
+    feat = orc.hog(make_image(12, 60, 48), 4, dtype=F64)
+    np.testing.assert_array_equal(_b64(orc.pdf_level(feat, m.filtersw, dtype=F64)), _b64(gold["pdf_resp"]))
+    Ix, Iy, Ik, rv, ri = orc.dp_min_level(m.to_desc(), 0, gold["dp_resp"], dtype=F64)
+    np.testing.assert_array_equal(Ix, gold["dp_ix"]); np.testing.assert_array_equal(Iy, gold["dp_iy"])
+    np.testing.assert_array_equal(Ik, gold["dp_ik"]); np.testing.assert_array_equal(_b64(rv), _b64(gold["dp_rootv"]))
+    np.testing.assert_array_equal(ri, gold["dp_rooti"])
+    model = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    model.thresh = float(gold["e2e_tree_thresh"])
+    heads, boxes, locs, _ = orc.detect(model, make_image(0, 120, 90), dtype=F64)
+    exp = gold["e2e_tree_heads"]
+    assert len(heads) == len(exp) > 5
+    np.testing.assert_array_equal(heads["score"].view(np.int32), exp[:, 0])
+    np.testing.assert_array_equal(boxes, gold["e2e_tree_boxes"]); np.testing.assert_array_equal(locs, gold["e2e_tree_locs"])
+
+
+def test_f64_dt_equals_bruteforce_maxplus(orc):
+    """DistanceTransform<double> against the definition; without the float narrowing of s the scores
+    agree with the brute force to double rounding."""
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(9, 12))
+    ax, bx, ay, by, osx, osy = -0.02, 0.004, -0.03, -0.001, 1, -2
+    out, ix, iy = orc.dt2d(a, ax, bx, ay, by, osx, osy, correct_ptr=1, dtype=F64)
+    M, N = a.shape
+    mm, nn = np.mgrid[0:M, 0:N]
+    for m in range(M):
+        for n in range(N):
+            dx, dy = n + osx - nn, m + osy - mm
+            v = a + ax * dx ** 2 + bx * dx + ay * dy ** 2 + by * dy
+            assert abs(v.max() - out[m, n]) < 1e-13
+            assert (iy[m, n], ix[m, n]) == np.unravel_index(np.argmax(v), v.shape)
+
+
+def test_f64_and_f32_instantiations_track_each_other(orc):
+    """Same algorithm in two precisions: features/responses/root scores agree to float rounding, and the
+    double pdf equals an independent float64 correlation to 1e-12."""
+    im = make_image(3, 96, 72)
+    h32, h64 = orc.hog(im, 4), orc.hog(im, 4, dtype=F64)
+    assert h64.dtype == F64 and np.abs(h64 - h32).max() < 1e-6 and np.any(h64 != h32)
+    m = make_tree_model([-1, 0, 0], 2, seed=7)
+    r64 = orc.pdf_level(h64, m.filtersw, dtype=F64)
+    H, W, _ = h64.shape
+    pad = np.zeros((H + 4, W + 4, 32)); pad[..., 31] = 1.0                      # border: 0, truncation channel 1
+    pad[2:-2, 2:-2] = h64
+    f = np.asarray(m.filtersw[1], F64).reshape(5, 5, 32)
+    direct = np.zeros((H, W))
+    for i in range(5):
+        for j in range(5):
+            direct += (pad[i:i + H, j:j + W] * f[i, j]).sum(-1)
+    assert np.abs(direct - r64[1]).max() < 1e-12
+    m.thresh = -1e30
+    f32 = orc.detect(m, im, capacity=1, keep=True)[4]
+    f64 = orc.detect(m, im, capacity=1, keep=True, dtype=F64)[4]
+    for l in (0, f32.nlevels - 1):
+        assert np.abs(f64.root(l)[0] - f32.root(l)[0]).max() < 1e-4
+    f32.free(); f64.free()
