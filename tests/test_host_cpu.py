@@ -157,3 +157,25 @@ def test_bench_line_schema_fields():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert f'"{key}"' in src
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The ctypes mirrors of pbd_options / pbd_model_desc / pbd_candidate_head must have the C layout
+    (compiled from include/pbd_c.h with gcc: sizes and the offsets of the fields added last)."""
+    import ctypes as C
+    import subprocess
+    from partsbaseddetector_amd import model as M
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pbd_c.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(pbd_options), offsetof(pbd_options, scalar_type),'
+                   ' offsetof(pbd_options, reserved), sizeof(pbd_model_desc), offsetof(pbd_model_desc, biasid),'
+                   ' sizeof(pbd_candidate_head)); return 0;}\n')
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-I", inc, "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    desc_t = type(M.make_tree_model([-1, 0], 1).to_desc())
+    exp = [C.sizeof(capi.pbd_options), capi.pbd_options.scalar_type.offset, capi.pbd_options.reserved.offset,
+           C.sizeof(desc_t), desc_t.biasid.offset, C.sizeof(capi.pbd_candidate_head)]
+    assert got == exp, (got, exp)
+    assert capi.PBD_SCALAR_F32 == 0 and capi.PBD_SCALAR_F64 == 1
