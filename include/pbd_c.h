@@ -78,7 +78,9 @@ enum {
   PBD_CONV_AUTO = 0,  /* MFMA filter bank when nfilters*flen is a real GEMM     */
   PBD_CONV_EXACT = 1, /* VALU direct correlation, reference summation order:
                          bit-identical to src/filter.cpp:3899-3922 + pdf+=pdfc */
-  PBD_CONV_MFMA = 2   /* fp32 MFMA implicit GEMM (k-ordered fma chain)          */
+  PBD_CONV_MFMA = 2   /* MFMA implicit GEMM (k-ordered fma chain): fp32
+                         v_mfma_f32_32x32x2 for float handles, fp64
+                         v_mfma_f64_16x16x4 for double handles                 */
 };
 /* Scalar type T of the instantiation (src/PartsBasedDetector.cpp:132-133):
  * PartsBasedDetector<float> (src/demo.cpp:85) or PartsBasedDetector<double>
@@ -97,8 +99,8 @@ typedef struct pbd_options {
   int32_t level_begin;   /* process pyramid levels [level_begin, level_end)    */
   int32_t level_end;     /* <=0: all levels (multi-GPU level sharding)         */
   int32_t scalar_type;   /* PBD_SCALAR_F32 (default) or PBD_SCALAR_F64; a double
-                            handle runs PBD_CONV_EXACT and answers the *_f64
-                            stage entry points instead of the float ones       */
+                            handle answers the *_f64 stage entry points
+                            instead of the float ones                          */
   int32_t reserved[2];   /* [0]: DP level groups on separate streams (0/1 = one chain, max 3)
                             [1]: distance transform kernel: 0/1 lane-per-line (default), 2 the
                                  experimental wave-per-line kernel (lines <= 512 elements)          */

@@ -440,3 +440,127 @@ void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels,
   dim3 grid(ntiles, (nf + 31) / 32);
   hipLaunchKernelGGL((k_conv_mfma<5, 5>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
 }
+
+// ---------------------------------------------------------------------------
+// fp64 MFMA implicit GEMM (v_mfma_f64_16x16x4_f64) for the double instantiation: M = cells,
+// N = filters, K = kh*kw*32.  Measured on MI355X (tests/tools/mfma64_probe.hip): 64 cycles per
+// instruction and SIMD = 72 TFLOP/s; operand layout A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D[i = 4*reg + (l>>4)][j = l&15].
+// Workgroup = 4 waves: 16x16 cells x ONE 16-filter n-tile, grid = (tiles, nfpad/16).  Wave w owns cell
+// rows 4w..4w+3 = four 16-cell M-tiles = four accumulators (32 VGPRs).  The 20x20-cell feature tile is
+// staged in two 16-channel halves like k_conv_exact_f64 (54 KB: three workgroups per CU), cell stride 17
+// doubles (conflict-free across the 16 cells of an M-tile).  B: one double per lane and k-step, a whole
+// tap (4 k-steps) loaded from the L2-resident [tap][channel][nfpad] array one tap ahead, ping-pong.
+// Accumulation is a k-ordered fp64 fma chain (half, tap, channel): |delta| vs the reference order ~1e-14.
+// ---------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void k_conv_mfma_f64(const ConvTile* __restrict__ tiles,
+                                                       const LevelDev* __restrict__ levels,
+                                                       const double* __restrict__ feat, const double* __restrict__ wT,
+                                                       double* __restrict__ resp, int nf, int nfpad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TW = CT + KW - 1, TH = CT + KH - 1, NTAP = KH * KW;
+  double* ft = (double*)smem;               // [TH][TW][CSTRH]
+  const ConvTile t = tiles[blockIdx.x];
+  const LevelDev lv = levels[t.level];
+  const int H = lv.ch, W = lv.cw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nbase = blockIdx.y * 16;
+  const double* F = feat + lv.cell_off * PBD_FLEN;
+  const int ai = lane & 15, ak = lane >> 4;
+  const double* bsrc = wT + (size_t)ak * nfpad + nbase + ai;     // B[k = ak][j = ai] of k-step 0, tap 0, half 0
+  f64x4 acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = 0.0;
+  const double* abase = ft + ((4 * wave) * TW + ai) * CSTRH + ak;   // M-tile m adds m*TW*CSTRH
+
+  for (int half = 0; half < PBD_FLEN / CHALF; ++half) {
+    if (half) __syncthreads();
+    const double* bh = bsrc + (size_t)(half * CHALF) * nfpad;
+    double b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b0[u] = bh[(size_t)(4 * u) * nfpad];   // tap 0, issued before the staging
+    {  // stage 16 channels of every cell (same scheme as k_conv_exact_f64)
+      constexpr int LPC = CHALF / 2, N = TH * TW * LPC, NB = (N + 255) / 256, BATCH = 7;
+      for (int j0 = 0; j0 < NB; j0 += BATCH) {
+        double2 r[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const int i = min(tid + (j0 + j) * 256, N - 1);
+          const int cell = i / LPC, q = i - cell * LPC;
+          const int ty = cell / TW, tx = cell - ty * TW;
+          const int y = min(max(t.y0 + ty - KH / 2, 0), H - 1), x = min(max(t.x0 + tx - KW / 2, 0), W - 1);
+          r[j] = *(const double2*)(F + ((size_t)y * W + x) * PBD_FLEN + half * CHALF + q * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const int i = tid + (j0 + j) * 256;
+          if (i < N) {
+            const int cell = i / LPC, q = i - cell * LPC;
+            const int ty = cell / TW, tx = cell - ty * TW;
+            const int y = t.y0 + ty - KH / 2, x = t.x0 + tx - KW / 2;
+            double2 v = r[j];
+            if (!(y >= 0 && y < H && x >= 0 && x < W))
+              v = make_double2(0.0, (half == PBD_FLEN / CHALF - 1 && q == LPC - 1) ? 1.0 : 0.0);
+            double* d = ft + cell * CSTRH + q * 2;
+            d[0] = v.x; d[1] = v.y;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    auto load_tap = [&](double (&dst)[4], int tap) {
+      const double* bs = bh + (size_t)min(tap, NTAP - 1) * PBD_FLEN * nfpad;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[u] = bs[(size_t)(4 * u) * nfpad];
+    };
+    auto mma_tap = [&](const double (&bw)[4], int tap) {
+      const int ti = tap / KW, tj = tap - ti * KW;
+      const double* a = abase + (ti * TW + tj) * CSTRH;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m * TW * CSTRH + 4 * u], bw[u], acc[m], 0, 0, 0);
+      }
+    };
+    for (int tap = 0; tap < NTAP; tap += 2) {
+      load_tap(b1, tap + 1);
+      mma_tap(b0, tap);
+      if (tap + 1 < NTAP) {
+        load_tap(b0, tap + 2);
+        mma_tap(b1, tap + 1);
+      }
+    }
+  }
+  __syncthreads();  // all waves are done reading the feature tile: reuse it for the epilogue
+  // Epilogue: transpose the wave's 64-cell x 16-filter slab through LDS so lanes run along cells.
+  double* R = resp + lv.cell_off * nf;
+  double* tr = ft + wave * (16 * 65);      // per-wave [16 filters][64 cells + 1]
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tr[ai * 65 + m * 16 + 4 * r + ak] = acc[m][r];   // D[i = 4r + ak][j = ai] of M-tile m
+  __syncthreads();
+  const int py = t.y0 + 4 * wave + (lane >> 4), pxx = t.x0 + (lane & 15);
+  const bool pvalid = (py < H && pxx < W);
+  for (int j = 0; j < 16; ++j) {
+    const int fn = nbase + j;
+    if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[j * 65 + lane];
+  }
+}
+
+void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
+                          const double* wT, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
+  if (ntiles <= 0) return;
+  if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, 8, nf, nfpad, kh, kw, s); return; }
+  const size_t lds = sizeof(double) * (CT + 4) * (CT + 4) * CSTRH;
+  static bool cfg = false;
+  if (!cfg) { hipFuncSetAttribute((const void*)k_conv_mfma_f64<5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+  dim3 grid(ntiles, (nf + 15) / 16);
+  hipLaunchKernelGGL((k_conv_mfma_f64<5, 5>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
+}

@@ -612,7 +612,8 @@ static int run_hog(pbd_handle* h) {
 static int run_pdf(pbd_handle* h) {
   const pbd_model_desc& m = h->md;
   if (h->conv_mode == PBD_CONV_MFMA)
-    launch_conv_mfma(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT, (float*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
+    if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT, (double*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
+    else launch_conv_mfma(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT, (float*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
   else
     launch_conv_exact(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat, h->d_wT, h->d_resp, h->ts, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
   h->have_resp = true;
@@ -759,11 +760,7 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   if (h->conv_mode == PBD_CONV_AUTO)  // a dense contraction when N x K is GEMM-sized
     h->conv_mode = ((size_t)model->nfilters * model->kh * model->kw * model->flen >= 32 * 800 && model->kh == 5 && model->kw == 5)
                        ? PBD_CONV_MFMA : PBD_CONV_EXACT;
-  if (h->ts == 8) {   // PartsBasedDetector<double>: the tap-ordered VALU filter bank and the lane-per-line DT
-    if (o.conv_mode == PBD_CONV_MFMA) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_MFMA is the fp32 MFMA kernel; the double instantiation uses PBD_CONV_EXACT");
-    if (o.reserved[1] == 2) return fail(h, PBD_ERR_UNSUPPORTED, "the wave-per-line distance transform is float only");
-    h->conv_mode = PBD_CONV_EXACT;
-  }
+  if (h->ts == 8 && o.reserved[1] == 2) return fail(h, PBD_ERR_UNSUPPORTED, "the wave-per-line distance transform is float only");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(h, PBD_ERR_HIP, "no HIP device visible");
   if (o.device < 0 || o.device >= ndev) return fail(h, PBD_ERR_ARG, "bad device ordinal");

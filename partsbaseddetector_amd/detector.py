@@ -191,8 +191,7 @@ class PartsBasedDetector:
     def distributeModel(self, model: Model) -> None:
         """src/PartsBasedDetector.cpp:102-127."""
         self._name = model.name
-        conv = capi.PBD_CONV_EXACT if (self._dtype == np.float64 and self._conv == capi.PBD_CONV_AUTO) else self._conv
-        self._h = capi.Handle(model, self._device, conv, self._cap, 0, self._lb, self._le, dtype=self._dtype)
+        self._h = capi.Handle(model, self._device, self._conv, self._cap, 0, self._lb, self._le, dtype=self._dtype)
         self.features_ = HOGFeatures(self._h)
         self.convolution_engine_ = SpatialConvolutionEngine(self._h)
         self.convolution_engine_.setFilters(model.filtersw)

@@ -375,9 +375,8 @@ class PartsBasedDetector {
   void distributeModel(Model& model) {             // src/PartsBasedDetector.cpp:102-127
     name_ = model.name();
     ncomponents_ = model.ncomponents();
-    // DataType<T>::type selects the instantiation (:110,113-117); the double one runs the exact filter bank
-    const int cm = ((int)DataType<T>::scalar == (int)PBD_SCALAR_F64 && conv_mode_ == PBD_CONV_AUTO) ? PBD_CONV_EXACT : conv_mode_;
-    dev_ = std::make_shared<Device>(model, device_, cm, (int)DataType<T>::scalar);
+    // DataType<T>::type selects the instantiation (:110,113-117)
+    dev_ = std::make_shared<Device>(model, device_, conv_mode_, (int)DataType<T>::scalar);
     features_.reset(new HipHOGFeatures(dev_, model.binsize(), model.nscales()));
     convolution_engine_.reset(new HipConvolutionEngine(dev_));
     convolution_engine_->setFilters(model.filters());

@@ -158,7 +158,7 @@ def test_dp_min_f64_single_mixture_and_multi_component(gpu_required, orc):
 def _e2e64(orc, model, im, q=99.5):
     model.thresh = _thresh64(orc, model, im, q)
     ref = orc.detect(model, im, dtype=F64)[:3]
-    hd = capi.Handle(model, dtype=F64)
+    hd = capi.Handle(model, conv_mode=capi.PBD_CONV_EXACT, dtype=F64)
     got = hd.detect(im)
     hd.close()
     return got, ref
@@ -202,10 +202,45 @@ def test_detect_f64_differs_from_float_instantiation(gpu_required, orc):
     h32.close(); h64_.close()
 
 
+# ---------------------------------------------------------------- fp64 MFMA filter bank (k_conv_mfma_f64)
+def test_pdf_f64_mfma_tolerance(gpu_required, orc):
+    """v_mfma_f64_16x16x4_f64 accumulates in (half, tap, channel) order: not the reference's order, so it is
+    held to a tolerance — 1e-12, eight orders inside the north_star's 1e-4."""
+    for nparts, K, seed in ((5, 4, 13), (9, 5, 14)):      # 20 and 45 filters: partial 16-filter n-tiles
+        m = make_tree_model([-1] + [0] * (nparts - 1), K, seed=seed)
+        h = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA, dtype=F64)
+        h.pyramid(make_image(seed, 120, 90))
+        g = h._geo
+        h.pdf()
+        for l in (0, 3, g["nlevels"] - 1):
+            ref = orc.pdf_level(h.level_features(l), m.filtersw, dtype=F64)
+            for n in range(len(m.filtersw)):
+                assert np.abs(h.level_response(l, n) - ref[n]).max() < 1e-12
+        h.close()
+
+
+def test_detect_f64_mfma_person_matches_oracle(gpu_required, orc):
+    """AUTO picks the fp64 MFMA filter bank for the person model; candidates, part locations and boxes
+    equal the oracle's, scores to 1e-6 (they are narrowed to float in the candidate record)."""
+    m = make_person_model(K=2)
+    im = make_image(7, 640, 480)
+    m.thresh = _thresh64(orc, m, im, 99.9)
+    ref = orc.detect(m, im, dtype=F64)[:3]
+    hd = capi.Handle(m, dtype=F64)                         # PBD_CONV_AUTO
+    got = hd.detect(im)
+    hd.close()
+    key = lambda r: sorted(zip(r[0]["level"].tolist(), r[0]["component"].tolist(), map(tuple, r[2].reshape(len(r[0]), -1).tolist())))
+    gk, rk = key(got), key(ref)
+    common = set(gk) & set(rk)
+    assert len(common) >= len(rk) - 2 and len(gk) <= len(rk) + 2      # a score within 1e-13 of the threshold may flip
+    if len(gk) == len(rk):
+        assert_candidates_equal(got, ref, score_tol=1e-6)
+
+
 def test_f64_handle_type_checks(gpu_required):
     m = make_tree_model([-1, 0], 2, seed=1)
     with pytest.raises(capi.PbdError) as e:
-        capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA, dtype=F64)
+        capi.Handle(m, dt_mode=2, dtype=F64)            # the wave-per-line DT is float only
     assert e.value.code == capi.PBD_ERR_UNSUPPORTED
     h = capi.Handle(m, dtype=F64)
     h.pyramid(make_image(0, 64, 48))
