@@ -17,6 +17,7 @@
 //    order; the fast path when nfilters*flen is a real dense contraction.
 // Both stage a (T+kh-1)x(T+kw-1)-cell feature tile with halo in LDS once per
 // workgroup (border values materialised there) and write plane-major outputs.
+#include <algorithm>
 #include "pbd_internal.hpp"
 
 // debug: per-phase wall-clock stamps (100 MHz) of one workgroup of the last k_conv_mfma launch
@@ -442,59 +443,78 @@ void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels,
 }
 
 // ---------------------------------------------------------------------------
-// fp64 MFMA implicit GEMM (v_mfma_f64_16x16x4_f64) for the double instantiation: M = cells,
-// N = filters, K = kh*kw*32.  Measured on MI355X (tests/tools/mfma64_probe.hip): 64 cycles per
-// instruction and SIMD = 72 TFLOP/s; operand layout A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
-// D[i = 4*reg + (l>>4)][j = l&15].
+// 16x16x4 MFMA implicit GEMM, instantiated for double (v_mfma_f64_16x16x4_f64: the filter bank of the
+// double instantiation) and for float (v_mfma_f32_16x16x4_f32).  M = cells, N = filters, K = kh*kw*32.
+// Measured on MI355X (tests/tools/mfma64_probe.hip, mfma16_probe.hip): f64 64 cycles per instruction and
+// SIMD = 72 TFLOP/s; operand layout A[i = l&15][k = l>>4], B[k = l>>4][j = l&15] for both; result
+// D[i = 4*reg + (l>>4)][j = l&15] (f64) / D[i = 4*(l>>4) + reg][j = l&15] (f32).
 // Workgroup = 4 waves: 16x16 cells x ONE 16-filter n-tile, grid = (tiles, nfpad/16).  Wave w owns cell
-// rows 4w..4w+3 = four 16-cell M-tiles = four accumulators (32 VGPRs).  The 20x20-cell feature tile is
-// staged in two 16-channel halves like k_conv_exact_f64 (54 KB: three workgroups per CU), cell stride 17
-// doubles (conflict-free across the 16 cells of an M-tile).  B: one double per lane and k-step, a whole
-// tap (4 k-steps) loaded from the L2-resident [tap][channel][nfpad] array one tap ahead, ping-pong.
-// Accumulation is a k-ordered fp64 fma chain (half, tap, channel): |delta| vs the reference order ~1e-14.
+// rows 4w..4w+3 = four 16-cell M-tiles = four accumulators.  The 20x20-cell feature tile is staged in
+// NHALF channel groups (double: two 16-channel halves, 54 KB -> three workgroups per CU), cell stride
+// CH+1 elements (conflict-free across the 16 cells of an M-tile).  B: one element per lane and k-step, a
+// whole tap loaded from the L2-resident [tap][channel][nfpad] array one tap ahead, ping-pong registers.
+// Accumulation is a k-ordered fma chain (half, tap, channel): not the reference's order, tolerance-based.
 // ---------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct Mfma16;
+template <> struct Mfma16<double> {
+  typedef f64x4 acc_t;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int drow(int reg, int ak) { return 4 * reg + ak; }
+};
+template <> struct Mfma16<float> {
+  typedef f32x4 acc_t;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int drow(int reg, int ak) { return 4 * ak + reg; }
+};
 
-template <int KH, int KW>
-__global__ __launch_bounds__(256) void k_conv_mfma_f64(const ConvTile* __restrict__ tiles,
-                                                       const LevelDev* __restrict__ levels,
-                                                       const double* __restrict__ feat, const double* __restrict__ wT,
-                                                       double* __restrict__ resp, int nf, int nfpad) {
+template <typename T, int KH, int KW, int NHALF, int WPE>   // WPE: waves per SIMD the register allocation must allow
+__global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __restrict__ tiles,
+                                                     const LevelDev* __restrict__ levels,
+                                                     const T* __restrict__ feat, const T* __restrict__ wT,
+                                                     T* __restrict__ resp, int nf, int nfpad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Mfma16<T> MM;
   constexpr int TW = CT + KW - 1, TH = CT + KH - 1, NTAP = KH * KW;
-  double* ft = (double*)smem;               // [TH][TW][CSTRH]
+  constexpr int CH = PBD_FLEN / NHALF, CS = CH + 1, KS = CH / 4;   // channels per pass, LDS cell stride, k-steps per tap
+  constexpr int EPV = 16 / (int)sizeof(T), LPC = CH / EPV;         // elements per 16-byte vector, lanes per cell
+  struct alignas(16) V { T e[EPV]; };
+  T* ft = (T*)smem;                         // [TH][TW][CS]
+  CONV_STAMP(0);
   const ConvTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const int H = lv.ch, W = lv.cw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nbase = blockIdx.y * 16;
-  const double* F = feat + lv.cell_off * PBD_FLEN;
+  const T* F = feat + lv.cell_off * PBD_FLEN;
   const int ai = lane & 15, ak = lane >> 4;
-  const double* bsrc = wT + (size_t)ak * nfpad + nbase + ai;     // B[k = ak][j = ai] of k-step 0, tap 0, half 0
-  f64x4 acc[4];
+  const T* bsrc = wT + (size_t)ak * nfpad + nbase + ai;     // B[k = ak][j = ai] of k-step 0, tap 0, half 0
+  typename MM::acc_t acc[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[m][r] = 0.0;
-  const double* abase = ft + ((4 * wave) * TW + ai) * CSTRH + ak;   // M-tile m adds m*TW*CSTRH
+    for (int r = 0; r < 4; ++r) acc[m][r] = (T)0;
+  const T* abase = ft + ((4 * wave) * TW + ai) * CS + ak;   // M-tile m adds m*TW*CS
 
-  for (int half = 0; half < PBD_FLEN / CHALF; ++half) {
+#pragma unroll 1
+  for (int half = 0; half < NHALF; ++half) {
     if (half) __syncthreads();
-    const double* bh = bsrc + (size_t)(half * CHALF) * nfpad;
-    double b0[4], b1[4];
+    const T* bh = bsrc + (size_t)(half * CH) * nfpad;
+    T b0[KS], b1[KS];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b0[u] = bh[(size_t)(4 * u) * nfpad];   // tap 0, issued before the staging
-    {  // stage 16 channels of every cell (same scheme as k_conv_exact_f64)
-      constexpr int LPC = CHALF / 2, N = TH * TW * LPC, NB = (N + 255) / 256, BATCH = 7;
+    for (int u = 0; u < KS; ++u) b0[u] = bh[(size_t)(4 * u) * nfpad];   // tap 0, issued before the staging
+    {  // stage CH channels of every cell: LPC lanes x 16 B per cell, batches of independent loads
+      constexpr int N = TH * TW * LPC, NB = (N + 255) / 256, BATCH = 7;
       for (int j0 = 0; j0 < NB; j0 += BATCH) {
-        double2 r[BATCH];
+        V r[BATCH];
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
           const int i = min(tid + (j0 + j) * 256, N - 1);
           const int cell = i / LPC, q = i - cell * LPC;
           const int ty = cell / TW, tx = cell - ty * TW;
           const int y = min(max(t.y0 + ty - KH / 2, 0), H - 1), x = min(max(t.x0 + tx - KW / 2, 0), W - 1);
-          r[j] = *(const double2*)(F + ((size_t)y * W + x) * PBD_FLEN + half * CHALF + q * 2);
+          r[j] = *(const V*)(F + ((size_t)y * W + x) * PBD_FLEN + half * CH + q * EPV);
         }
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
@@ -503,48 +523,55 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f64(const ConvTile* __restric
             const int cell = i / LPC, q = i - cell * LPC;
             const int ty = cell / TW, tx = cell - ty * TW;
             const int y = t.y0 + ty - KH / 2, x = t.x0 + tx - KW / 2;
-            double2 v = r[j];
-            if (!(y >= 0 && y < H && x >= 0 && x < W))
-              v = make_double2(0.0, (half == PBD_FLEN / CHALF - 1 && q == LPC - 1) ? 1.0 : 0.0);
-            double* d = ft + cell * CSTRH + q * 2;
-            d[0] = v.x; d[1] = v.y;
+            const bool inside = (y >= 0 && y < H && x >= 0 && x < W);
+            T* d = ft + cell * CS + q * EPV;
+#pragma unroll
+            for (int k = 0; k < EPV; ++k)   // border 0, 1 for the truncation channel (:147-155)
+              d[k] = inside ? r[j].e[k] : (T)((half == NHALF - 1 && q == LPC - 1 && k == EPV - 1) ? 1 : 0);
           }
         }
       }
     }
     __syncthreads();
-    auto load_tap = [&](double (&dst)[4], int tap) {
-      const double* bs = bh + (size_t)min(tap, NTAP - 1) * PBD_FLEN * nfpad;
+    CONV_STAMP(1 + 2 * half);
+    auto load_tap = [&](T (&dst)[KS], int tap) {
+      const T* bs = bh + (size_t)min(tap, NTAP - 1) * PBD_FLEN * nfpad;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) dst[u] = bs[(size_t)(4 * u) * nfpad];
+      for (int u = 0; u < KS; ++u) dst[u] = bs[(size_t)(4 * u) * nfpad];
     };
-    auto mma_tap = [&](const double (&bw)[4], int tap) {
+    auto mma_tap = [&](const T (&bw)[KS], int tap) {
       const int ti = tap / KW, tj = tap - ti * KW;
-      const double* a = abase + (ti * TW + tj) * CSTRH;
+      const T* a = abase + (ti * TW + tj) * CS;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < KS; ++u) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m * TW * CSTRH + 4 * u], bw[u], acc[m], 0, 0, 0);
+        for (int m = 0; m < 4; ++m) acc[m] = MM::mma(a[m * TW * CS + 4 * u], bw[u], acc[m]);
       }
     };
-    for (int tap = 0; tap < NTAP; tap += 2) {
+    auto tap_pair = [&](int tap) {
       load_tap(b1, tap + 1);
       mma_tap(b0, tap);
       if (tap + 1 < NTAP) {
         load_tap(b0, tap + 2);
         mma_tap(b1, tap + 1);
       }
+    };
+    if constexpr (NHALF == 1) {
+      for (int tap = 0; tap < NTAP; tap += 2) tap_pair(tap);
+    } else {   // with half the k-steps per tap hipcc would unroll all taps and run out of registers
+      _Pragma("unroll 1") for (int tap = 0; tap < NTAP; tap += 2) tap_pair(tap);
     }
+    CONV_STAMP(2 + 2 * half);
   }
   __syncthreads();  // all waves are done reading the feature tile: reuse it for the epilogue
+  CONV_STAMP(5);
   // Epilogue: transpose the wave's 64-cell x 16-filter slab through LDS so lanes run along cells.
-  double* R = resp + lv.cell_off * nf;
-  double* tr = ft + wave * (16 * 65);      // per-wave [16 filters][64 cells + 1]
+  T* R = resp + lv.cell_off * nf;
+  T* tr = ft + wave * (16 * 65);           // per-wave [16 filters][64 cells + 1]
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tr[ai * 65 + m * 16 + 4 * r + ak] = acc[m][r];   // D[i = 4r + ak][j = ai] of M-tile m
+    for (int r = 0; r < 4; ++r) tr[ai * 65 + m * 16 + MM::drow(r, ak)] = acc[m][r];   // D[i][j = ai] of M-tile m
   __syncthreads();
   const int py = t.y0 + 4 * wave + (lane >> 4), pxx = t.x0 + (lane & 15);
   const bool pvalid = (py < H && pxx < W);
@@ -552,15 +579,34 @@ __global__ __launch_bounds__(256) void k_conv_mfma_f64(const ConvTile* __restric
     const int fn = nbase + j;
     if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[j * 65 + lane];
   }
+  CONV_STAMP(6);
+}
+
+template <typename T, int NHALF, int WPE>
+static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
+                                 const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
+  const size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + 1), sizeof(T) * 4 * 16 * 65);
+  static bool cfg = false;   // one per instantiation
+  if (!cfg) { hipFuncSetAttribute((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+  dim3 grid(ntiles, (nf + 15) / 16);
+  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
 }
 
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
                           const double* wT, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
   if (ntiles <= 0) return;
   if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, 8, nf, nfpad, kh, kw, s); return; }
-  const size_t lds = sizeof(double) * (CT + 4) * (CT + 4) * CSTRH;
-  static bool cfg = false;
-  if (!cfg) { hipFuncSetAttribute((const void*)k_conv_mfma_f64<5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
-  dim3 grid(ntiles, (nf + 15) / 16);
-  hipLaunchKernelGGL((k_conv_mfma_f64<5, 5>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
+  launch_conv_mfma16_t<double, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
+}
+
+// float instantiations of the same kernel: nhalf 1 = whole 32-channel tile in LDS (default fp32 filter bank),
+// 2 / 3 = two channel halves at 5 / 3 waves per SIMD (probe variants).  Tried and dropped: a persistent
+// variant keeping the tile resident across a chunk of n-tiles with a register-direct epilogue (0.49 ms vs
+// 0.44 ms, and long-running workgroups hurt the overlap with other frames' kernels).
+void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
+                            const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s) {
+  if (ntiles <= 0) return;
+  if (nhalf == 2) launch_conv_mfma16_t<float, 2, 5>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
+  else if (nhalf == 3) launch_conv_mfma16_t<float, 2, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
+  else launch_conv_mfma16_t<float, 1, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
 }

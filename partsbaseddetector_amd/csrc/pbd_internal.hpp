@@ -203,6 +203,8 @@ void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels,
                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
                           const double* wT, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
+void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
+                            const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s);
 void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, int ts,
                     hipStream_t s);
 size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts);
