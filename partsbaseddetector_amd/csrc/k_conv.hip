@@ -602,7 +602,8 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
 // float instantiations of the same kernel: nhalf 1 = whole 32-channel tile in LDS (default fp32 filter bank),
 // 2 / 3 = two channel halves at 5 / 3 waves per SIMD (probe variants).  Tried and dropped: a persistent
 // variant keeping the tile resident across a chunk of n-tiles with a register-direct epilogue (0.49 ms vs
-// 0.44 ms, and long-running workgroups hurt the overlap with other frames' kernels).
+// 0.44 ms, and long-running workgroups hurt the overlap with other frames' kernels); capping the kernel at
+// two workgroups per CU to leave LDS and wave slots to co-running DT kernels (716 vs 751 frames/s).
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                             const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s) {
   if (ntiles <= 0) return;
