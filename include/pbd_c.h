@@ -121,6 +121,12 @@ typedef struct pbd_candidate_head {
 
 typedef struct pbd_handle pbd_handle;
 
+/* Restrict the handle to an arbitrary SET of pyramid levels (n = 0: all levels again), intersected with
+ * [level_begin, level_end).  Levels never interact (src/DynamicProgram.cpp:83-87 loops over (level,
+ * component) pairs independently), so one large frame shards across GPUs by level with no data-path
+ * collective: every rank rebuilds the (cheap) image pyramid and runs HOG / pdf / min / argmin on its own
+ * cost-balanced level set (SURVEY 8e, configs[3]); the union of the ranks' candidates is the frame's.   */
+int pbd_set_levels(pbd_handle* h, const int32_t* levels, int n);
 /* PartsBasedDetector<T>::distributeModel (src/PartsBasedDetector.cpp:102-127)
  * incl. SpatialConvolutionEngine::setFilters (src/SpatialConvolutionEngine.cpp:133-159)
  * and Parts construction (include/Parts.hpp:229-235).                        */

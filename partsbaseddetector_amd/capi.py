@@ -27,7 +27,7 @@ EXPORTS = [
     "pbd_set_level_features", "pbd_begin_frame", "pbd_pdf", "pbd_get_level_response",
     "pbd_set_level_response", "pbd_dp_min", "pbd_get_dp_pointers", "pbd_get_root", "pbd_dp_argmin",
     "pbd_dt2d", "pbd_hog_u8", "pbd_resize_u8", "pbd_pyrdown_u8", "pbd_nms_map",
-    "pbd_get_level_features_f64", "pbd_set_level_features_f64", "pbd_get_level_response_f64",
+    "pbd_set_levels", "pbd_get_level_features_f64", "pbd_set_level_features_f64", "pbd_get_level_response_f64",
     "pbd_set_level_response_f64", "pbd_get_root_f64", "pbd_dt2d_f64", "pbd_hog_u8_f64",
     "pbd_candidates_sort", "pbd_candidates_nms", "pbd_get_stage_ms", "pbd_set_profiling",
     "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps", "pbd_debug_dtw_stats",
@@ -158,6 +158,11 @@ class Handle:
         self._chk(self.L.pbd_detect_collect(self.h, heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32),
                                             _p(locs, C.c_int32), capacity, C.byref(cnt)))
         return self._out(heads, boxes, locs, cnt.value)
+
+    def set_levels(self, levels):
+        """Process only this set of pyramid levels (empty = all): multi-GPU level sharding."""
+        a = np.ascontiguousarray(list(levels), np.int32)
+        self._chk(self.L.pbd_set_levels(self.h, _p(a, C.c_int32) if len(a) else None, len(a)))
 
     def set_stream(self, stream_ptr: int):
         self._chk(self.L.pbd_set_stream(self.h, C.c_void_p(stream_ptr)))

@@ -327,7 +327,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   size_t cells = 0, pyr = 0;
   for (int l = 0; l < n; ++l) {
     Level& L = h->lv[l];
-    L.active = (l >= lb && l < le);
+    L.active = (l >= lb && l < le) && (h->level_set.empty() || (l < (int)h->level_set.size() && h->level_set[l]));
     if (L.cw > 32767 || L.ch > 32767) return fail(h, PBD_ERR_UNSUPPORTED, "level too large for 16-bit pointers");
     L.img_off = pyr; pyr += (size_t)L.iw * L.ih * cn;
     L.cell_off = cells; cells += (size_t)L.cw * L.ch;
@@ -808,6 +808,21 @@ int pbd_destroy(pbd_handle* h) {
 }
 
 const char* pbd_last_error(const pbd_handle* h) { return h ? h->err.c_str() : "null handle"; }
+int pbd_set_levels(pbd_handle* h, const int32_t* levels, int n) {
+  if (!h || n < 0 || (n > 0 && !levels)) return PBD_ERR_ARG;
+  std::vector<char> set;
+  for (int i = 0; i < n; ++i) {
+    if (levels[i] < 0 || levels[i] >= PBD_MAX_LEVELS) return fail(h, PBD_ERR_ARG, "level index out of range");
+    if ((int)set.size() <= levels[i]) set.resize(levels[i] + 1, 0);
+    set[levels[i]] = 1;
+  }
+  if (n > 0 && set.empty()) return fail(h, PBD_ERR_ARG, "empty level set");
+  if (h->pending) return fail(h, PBD_ERR_STATE, "a frame is in flight: collect it first");
+  hipStreamSynchronize(h->stream);
+  h->level_set.swap(set);
+  free_frame(h);   // the work tables are per geometry AND level set: re-planned on the next frame
+  return PBD_OK;
+}
 int pbd_max_parts(const pbd_handle* h) { return h ? h->max_parts : 0; }
 
 int pbd_set_stream(pbd_handle* h, void* s) {

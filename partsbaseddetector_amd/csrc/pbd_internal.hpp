@@ -111,6 +111,7 @@ struct pbd_handle {
   std::vector<int> anchors, part_offset, parentid, mix_offset, filterid, defid, biasid;
   pbd_options opt;
   int max_parts = 0, nslots = 0, nplanes = 0;
+  std::vector<char> level_set;   // pbd_set_levels: levels this handle processes (empty = all), intersected with [level_begin, level_end)
   std::vector<PartInfo> parts;                 // flat parts
   std::vector<std::vector<int>> rounds;        // flat part ids whose DT runs in round r
   std::vector<std::vector<std::vector<int>>> red_rounds;  // [round][wave] -> flat child part ids reduced (grouped by parent at plan time)

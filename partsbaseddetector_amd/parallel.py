@@ -44,6 +44,20 @@ def shard_levels_contiguous(cells: Sequence[int], world: int) -> List[Tuple[int,
     return out
 
 
+def shard_levels_lpt(cells: Sequence[int], world: int) -> List[List[int]]:
+    """Longest-processing-time greedy bin packing of levels onto `world` ranks (cost of a level is
+    proportional to its cells): levels in decreasing cost, each to the least loaded rank.
+    Returns one sorted level list per rank for pbd_set_levels / Handle.set_levels; the makespan is within
+    4/3 of optimal and never below max(level 0, total/world)."""
+    loads = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for l in sorted(range(len(cells)), key=lambda i: (-cells[i], i)):
+        r = min(range(world), key=lambda k: (loads[k], k))
+        out[r].append(l)
+        loads[r] += cells[l]
+    return [sorted(x) for x in out]
+
+
 def pack_candidates(cands, max_parts: int, capacity: int) -> np.ndarray:
     """(heads, boxes, locs) -> int32 [1 + capacity * (4 + 7*max_parts)] : count, then records."""
     heads, boxes, locs = cands
@@ -91,8 +105,13 @@ def gather_candidates(cands, max_parts: int, capacity: int = 1024, device=None):
 
 
 def merge_candidates(per_rank):
-    """Concatenate gathered candidates in rank order (then Candidate::sort / NMS on the host)."""
+    """Concatenate gathered candidates and put them in the order of a single-threaded reference run —
+    (level, component, root row, root column), src/DynamicProgram.cpp:197-253 — which is also the order one
+    handle produces; then Candidate::sort / NMS on the host as usual."""
     heads = np.concatenate([p[0] for p in per_rank])
     boxes = np.concatenate([p[1] for p in per_rank])
     locs = np.concatenate([p[2] for p in per_rank])
+    if len(heads):
+        order = np.lexsort((locs[:, 0, 0], locs[:, 0, 1], heads["component"], heads["level"]))
+        heads, boxes, locs = heads[order], boxes[order], locs[order]
     return heads, boxes, locs

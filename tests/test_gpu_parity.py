@@ -313,6 +313,34 @@ def test_level_sharding_union_equals_full(gpu_required, orc):
     assert_candidates_equal(merged, ref)
 
 
+def test_level_sets_lpt_union_equals_full(gpu_required, orc):
+    """pbd_set_levels: arbitrary (LPT-balanced) level sets on separate handles reproduce the full frame; a handle
+    can be re-targeted between frames and reset to all levels."""
+    from partsbaseddetector_amd import parallel
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    im = make_image(0, 320, 240)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.0)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    ref = h.detect(im)
+    assert len(ref[0]) > 20
+    g = h.geometry(320, 240)
+    cells = (g["cell_w"].astype(np.int64) * g["cell_h"]).tolist()
+    sets = parallel.shard_levels_lpt(cells, 4)
+    assert any(np.any(np.diff(s_) > 1) for s_ in sets)           # genuinely non-contiguous sets
+    parts = []
+    for s_ in sets:                                              # ONE handle re-targeted per "rank"
+        h.set_levels(s_)
+        got = h.detect(im)
+        assert set(got[0]["level"].tolist()) <= set(s_)
+        parts.append(got)
+    assert_candidates_equal(parallel.merge_candidates(parts), ref)
+    h.set_levels([])                                             # back to every level
+    assert_candidates_equal(h.detect(im), ref)
+    with pytest.raises(capi.PbdError):
+        h.set_levels([500])
+    h.close()
+
+
 def test_device_resident_and_async_entry_points(gpu_required, orc):
     import torch
     m = make_tree_model([-1, 0, 0], 2, seed=6)

@@ -94,6 +94,14 @@ def test_level_and_frame_sharding(orc):
         assert all(rng_[i][1] == rng_[i + 1][0] for i in range(world - 1))
         loads = [sum(cells[b:e]) for b, e in rng_]
         assert max(loads) <= sum(cells) / world + max(cells)
+    # LPT level sets (SURVEY 8e, configs[3]: one 1920x1080 frame on 8 GPUs; level 0 holds 13.1 % of the cells)
+    for world in (1, 2, 4, 8):
+        sets = parallel.shard_levels_lpt(cells, world)
+        assert sorted(sum(sets, [])) == list(range(len(cells)))
+        loads = [sum(cells[l] for l in s_) for s_ in sets]
+        assert max(loads) <= max(max(cells), sum(cells) / world) * 1.05          # within 5 % of the lower bound
+        assert max(loads) <= max(sum(cells[b:e]) for b, e in parallel.shard_levels_contiguous(cells, world))
+    assert sum(cells) / max(sum(cells[l] for l in s_) for s_ in parallel.shard_levels_lpt(cells, 8)) > 7.3  # ideal speed-up
     assert parallel.shard_frames(32, 8, 3) == [3, 11, 19, 27]
     assert sorted(sum((parallel.shard_frames(32, 8, r) for r in range(8)), [])) == list(range(32))
 
