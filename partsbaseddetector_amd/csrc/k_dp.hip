@@ -23,6 +23,7 @@
 // k_root      root bias + reduceMax (:163-171), strict threshold (:208) and
 //             compaction of the hits.
 // k_backtrack argmin (:219-245): one lane per candidate walks the part tree.
+#include <type_traits>
 #include "pbd_internal.hpp"
 
 // debug: per-phase timestamps (100 MHz wall clock) of block 0 of the last k_dt_pass launch
@@ -124,6 +125,69 @@ __device__ __forceinline__ bool dt_envelope(typename Pair<T>::type* __restrict__
   return suspect != 0;
 }
 
+// Cooperative envelope scan: LPL (2 or 4) adjacent lanes share one line.  Lane j of the group holds stack
+// entry k-j and evaluates the intersection of ITS entry with the current element q — exactly the value the
+// reference computes when its pop loop reaches that entry (`s = f(v[k], q, ...)` after j pops, :161-165).
+// pop_j = (s_j <= z[k-j]) && (k-j > 0); the reference pops while that holds, so the number of pops is
+// p = index of the first lane whose test fails.  p < LPL: lane p pushes q with its own s at slot k-p+1 and
+// the element is consumed — a push with up to LPL-1 pops costs ONE iteration; p == LPL: all LPL entries pop
+// and the same element meets the next LPL entries.  Same comparisons, same values, same results, about
+// one iteration per element instead of 1.5, and the extra lanes are lanes that LDS capacity leaves idle
+// anyway (a block holds 14-16 lines of 158 elements).  Loop state is just (k, q): entries are re-read
+// from the LDS stack every iteration (a wave's LDS operations are ordered; the fence keeps the compiler
+// from hoisting a lane's read above another lane's push).
+template <bool EXACT, int LPL, typename VT, typename T>
+__device__ __forceinline__ bool dt_envelope_m(typename Pair<T>::type* __restrict__ YZl, VT* __restrict__ Vl,
+                                              const double* __restrict__ Rl, int len, double a, double b, int j,
+                                              int lane, int* kout) {
+  typedef typename Pair<T>::type P2;
+  const double twoa = 2 * a;
+  const int gshift = lane & ~(LPL - 1);
+  int k = 0, q = 1;
+  unsigned suspect = 0;
+  if (j == 0) { Vl[0] = 0; YZl[0].y = -INFINITY; }
+  while (q < len) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int e = k - j, ec = max(e, 0);
+    const int v = Vl[ec];
+    const P2 yz = YZl[ec];
+    const T yq_f = YZl[q].x;
+    const int dx = q - v;
+    const double r = Rl[dx];
+    const double dxd = (double)dx;
+    const double num = (((double)yq_f - (double)yz.x) - b * dxd) + a * (double)__mul24(dx, q + v);
+    const double den = twoa * dxd;
+    double q1;
+    if (EXACT) {
+      q1 = num / den;
+    } else {
+      const double q0 = num * r;
+      const double rem = __builtin_fma(-q0, den, num);
+      q1 = __builtin_fma(rem, r, q0);
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
+      const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
+      const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
+      suspect = (((lo29 - 0x0FFFFFFFu) <= 2u) | ((ex - 897u) > 252u)) ? 1u : suspect;
+    }
+    const T s = (T)q1;
+    const bool pop = (s <= yz.y) && (e > 0);                              // :162 for the entry this lane holds
+    const unsigned gm = (unsigned)(__ballot(pop) >> gshift) & ((1u << LPL) - 1u);
+    const int p = __builtin_ctz(~gm);                                     // pops before the first failing test: 0..LPL
+    const bool push = p < LPL;
+    const int kn = push ? k - p + 1 : k - LPL;
+    if (push && j == p) {                                                 // :166-169 by the lane whose test failed
+      Vl[kn] = (VT)q;
+      P2 en; en.x = yq_f; en.y = s;
+      YZl[kn] = en;
+    }
+    k = kn;
+    q = push ? q + 1 : q;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  *kout = k;
+  return suspect != 0;
+}
+
 // One block = one wavefront = up to g.lpb lines of one group (lpb chosen per group so that every
 // block of the launch fits the same LDS budget: long lines -> fewer lines per block -> many more
 // blocks, so a whole pass is resident at once and all 4 SIMDs of every CU carry chains).
@@ -188,8 +252,38 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   __syncthreads();
   DT_STAMP(2);
 
-  // ---- build the upper envelope (DistanceTransform.hpp:156-170), one lane per line ----
-  if (lane < nl) {
+  // ---- build the upper envelope (DistanceTransform.hpp:156-170) ----
+  // lanes per line: long lines leave most lanes of the wave without a line (LDS capacity), so 4 or 2 lanes
+  // share a line (dt_envelope_m); short lines fill the wave with one lane per line (dt_envelope).
+  const int lpl = g.lpb <= 16 ? 4 : (g.lpb <= 32 ? 2 : 1);
+  auto coop = [&](auto LPLc) {
+    constexpr int LPL = decltype(LPLc)::value;
+    const int line = lane / LPL, j = lane % LPL;
+    if (line < nl) {
+      const int gi = t.g0 + line;
+      const int mi = gi / g.nlines;
+      const DtMap mp = maps[g.map0 + mi];
+      const double* Rl = R + (mi - m_first) * S;
+      P2* YZl = YZ + line * S;
+      VT* Vl = V + line * S;
+      int k;
+      if constexpr (sizeof(T) == 8) {
+        dt_envelope_m<true, LPL, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, j, lane, &k);
+      } else {
+        const bool sus = dt_envelope_m<false, LPL, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, j, lane, &k);
+        const unsigned gm = (unsigned)(__ballot(sus) >> (lane & ~(LPL - 1))) & ((1u << LPL) - 1u);
+        if (gm) {   // a quotient of this line landed next to a float rounding boundary: redo it with true divisions
+          const T* src = lptr[line];
+          for (int q = j; q < len; q += LPL) YZl[q].x = src[q];
+          dt_envelope_m<true, LPL, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, j, lane, &k);
+        }
+      }
+      if (j == 0) { YZl[k + 1].y = INFINITY; Ksz[line] = k; }
+    }
+  };
+  if (lpl == 4) coop(std::integral_constant<int, 4>());
+  else if (lpl == 2) coop(std::integral_constant<int, 2>());
+  else if (lane < nl) {
     const int gi = t.g0 + lane;
     const int mi = gi / g.nlines;
     const DtMap mp = maps[g.map0 + mi];
