@@ -170,8 +170,10 @@ __device__ __forceinline__ bool dt_envelope_m(typename Pair<T>::type* __restrict
       suspect = (((lo29 - 0x0FFFFFFFu) <= 2u) | ((ex - 897u) > 252u)) ? 1u : suspect;
     }
     const T s = (T)q1;
-    const bool pop = (s <= yz.y) && (e > 0);                              // :162 for the entry this lane holds
-    const unsigned gm = (unsigned)(__ballot(pop) >> gshift) & ((1u << LPL) - 1u);
+    // pop = (s <= z[k-j]) && (k-j > 0), :162 for the entry this lane holds; two ballots of plain compares
+    // ANDed as scalars (a ballot of the && goes through a select and a second compare)
+    const unsigned long long pm = __builtin_amdgcn_ballot_w64(s <= yz.y) & __builtin_amdgcn_ballot_w64(e > 0);
+    const unsigned gm = (unsigned)(pm >> gshift) & ((1u << LPL) - 1u);
     const int p = __builtin_ctz(~gm);                                     // pops before the first failing test: 0..LPL
     const bool push = p < LPL;
     const int kn = push ? k - p + 1 : k - LPL;

@@ -299,6 +299,12 @@ static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (
 static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget, int ts) {
   int lpb = 64;
   while (lpb > 8 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts) > budget) --lpb;
+  // the kernel shares a line between 4 lanes when lpb <= 16 and 2 lanes when lpb <= 32 (dt_envelope_m):
+  // just above those thresholds a few lines fewer per block buy twice the lanes per line
+  static const int snap4 = getenv("PBD_DT_SNAP4") ? atoi(getenv("PBD_DT_SNAP4")) : 24;
+  static const int snap2 = getenv("PBD_DT_SNAP2") ? atoi(getenv("PBD_DT_SNAP2")) : 40;
+  if (lpb > 16 && lpb <= snap4) lpb = 16;
+  else if (lpb > 32 && lpb <= snap2) lpb = 32;
   return lpb;
 }
 static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts) {
@@ -390,7 +396,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   // DT LDS budget: ~36 KB per block (4 blocks per CU) unless the longest line needs more at 8 lines/block
   int maxlen = 1;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
-  size_t dt_base = 24 * 1024;   // 6 one-wave blocks per CU: measured optimum on MI355X (16..53 KB swept)
+  size_t dt_base = 20 * 1024;   // 8 one-wave blocks per CU: measured optimum on MI355X (12..32 KB swept)
   if (const char* e = getenv("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
   size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 8, 2, h->ts));
   if (dt_budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
