@@ -341,14 +341,16 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         int k = lo;
         int vk = Vl[k];
         T yk = YZl[k].x, zn = YZl[k + 1].y;
-        T* dst = (T*)mp.dst + li;
         const int nlines = g.nlines;
+        T* dp = (T*)mp.dst + li + (size_t)q0 * nlines;      // running output pointers: no 64-bit multiply per element
+        int16_t* ppq = pp + (size_t)q0 * pst;
         for (int q = q0; q < q1; ++q) {
           const T fos = (T)os;                   // `z[k+1] < os`: int promoted to T (:174)
           while (zn < fos) { k++; zn = YZl[k + 1].y; vk = Vl[k]; yk = YZl[k].x; }
           const int d = os - vk;
-          dst[(size_t)q * nlines] = (T)(a * (double)(d * d) + b * (double)d + (double)yk);
-          pp[(size_t)q * pst] = (int16_t)vk;
+          *dp = (T)(a * (double)__mul24(d, d) + b * (double)d + (double)yk);   // |d| < 2^15
+          *ppq = (int16_t)vk;
+          dp += nlines; ppq += pst;
           os++;
         }
       }
