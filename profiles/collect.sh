@@ -15,7 +15,7 @@ B="python $REPO/bench.py"
 $B --steps 300 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 $B --steps 100 --inflight 1 --no-cpu-baseline > "$OUT/bench_n1_inflight1.json" 2>> "$OUT/bench_n1.err"
 $B --steps 50 --dtype f64 > "$OUT/bench_n1_f64.json" 2>> "$OUT/bench_n1.err"
-# per-kernel durations: sequential (undisturbed) and default (3 frames in flight)
+# per-kernel durations: sequential (undisturbed) and default (4 frames in flight)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_seq" -o run -- $B --steps 20 --warmup 3 --inflight 1 --no-cpu-baseline > "$OUT/stats_seq.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $B --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_f64" -o run -- $B --steps 10 --warmup 2 --inflight 1 --dtype f64 --no-cpu-baseline > "$OUT/stats_f64.log" 2>&1

@@ -57,7 +57,7 @@ md = [f"# {tag}: rocprofv3 summaries (MI355X, gfx950).  Collected by `profiles/c
 for d, title in (("stats_seq", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --inflight 1 --no-cpu-baseline\n"
                   "(sequential frames: per-kernel durations undisturbed)"),
                  ("stats", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline\n"
-                  "(default: 3 frames in flight on 3 streams; kernels of different frames overlap)"),
+                  "(default: 4 frames in flight on 4 streams, 8 hardware queues; kernels of different frames overlap)"),
                  ("stats_f64", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --inflight 1 --dtype f64 --no-cpu-baseline\n"
                   "(PartsBasedDetector<double>, sequential)")):
     t, path = stats_table(d)
