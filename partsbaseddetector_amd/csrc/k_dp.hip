@@ -220,10 +220,9 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     pstr[lane] = nat ? 1 : g.nlines;
   }
   // reciprocal tables: one IEEE division per (map, dx), spread over the 64 lanes
-  for (int e = lane; e < nmb * len; e += 64) {
-    const int ms = e / len, dx = e - ms * len;
+  for (int ms = 0; ms < nmb; ++ms) {
     const double a = maps[g.map0 + m_first + ms].a;
-    R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
+    for (int dx = lane; dx < len; dx += 64) R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
   }
   __syncthreads();
   DT_STAMP(1);
@@ -233,20 +232,23 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   {
     const int CH = (len + 63) >> 6;          // 64-element chunks per line
     const int nch = nl * CH;
+    // chunk -> (line, chunk of line) by a reciprocal multiply: an integer division per load and per store
+    // costs more VALU time than the loads take (c * CH < 2^20 here: c < 64 * CH, CH <= 512)
+    const unsigned inv = (1u << 20) / (unsigned)CH + 1u;
     for (int c0 = 0; c0 < nch; c0 += 16) {
       T r[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int c = min(c0 + j, nch - 1);
-        const int i = c / CH;
+        const int i = (int)(((unsigned)c * inv) >> 20);
         const int q = min((c - i * CH) * 64 + lane, len - 1);
         r[j] = lptr[i][q];
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int c = c0 + j;
-        const int i = min(c, nch - 1) / CH;
-        const int q = (min(c, nch - 1) - i * CH) * 64 + lane;
+        const int c = c0 + j, cc = min(c, nch - 1);
+        const int i = (int)(((unsigned)cc * inv) >> 20);
+        const int q = (cc - i * CH) * 64 + lane;
         if (c < nch && q < len) YZ[i * S + q].x = r[j];
       }
     }
