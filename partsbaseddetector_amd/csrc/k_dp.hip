@@ -411,7 +411,6 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
   const int H = J.H, W = J.W, L = J.L;
   const unsigned HW = (unsigned)H * W;
   if (cell >= HW) return;
-  const int m_ = cell / W, n_ = cell - m_ * W;
   constexpr int ML = 8;            // parent mixtures handled with all their gathers in flight at once
   if (L <= ML) {
     T acc[ML];
@@ -441,24 +440,10 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
           }
         }
       }
-      int ix[ML], iy[ML];
-#pragma unroll
-      for (int m = 0; m < ML; ++m)                               // first-level gathers, all in flight
-        ix[m] = (m < L) ? (correct_ptr ? (int)C.iy[(size_t)bi[m] * HW + cell] : (int)C.ix[(size_t)bi[m] * HW + cell]) : 0;
-#pragma unroll
-      for (int m = 0; m < ML; ++m) {                             // second-level gathers
-        if (m < L) {
-          if (!correct_ptr) iy[m] = C.iy[(size_t)bi[m] * HW + (size_t)m_ * W + ix[m]];   // Iy'(m,n) = Iy(m, Ix(m,n))
-          else { iy[m] = ix[m]; ix[m] = C.ix[(size_t)bi[m] * HW + (size_t)iy[m] * W + n_]; }  // true arg-max
-        }
-      }
 #pragma unroll
       for (int m = 0; m < ML; ++m) {
         if (m < L) {
-          const size_t o = (size_t)m * HW + cell;
-          C.ox[o] = (int16_t)ix[m];
-          C.oy[o] = (int16_t)iy[m];
-          C.ok[o] = (uint8_t)bi[m];
+          C.ok[(size_t)m * HW + cell] = (uint8_t)bi[m];          // Ik (:150); Ix / Iy are composed at back-tracking time
           acc[m] = acc[m] + v[m];                                // parent.score += maxv (:156), child order kept
         }
       }
@@ -483,18 +468,7 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
           if (wv > v) { bi = mm; v = wv; }
         }
       }
-      int ix = C.ix[(size_t)bi * HW + cell];
-      int iy;
-      if (!correct_ptr) {
-        iy = C.iy[(size_t)bi * HW + (size_t)m_ * W + ix];
-      } else {
-        iy = C.iy[(size_t)bi * HW + cell];
-        ix = C.ix[(size_t)bi * HW + (size_t)iy * W + n_];
-      }
-      const size_t o = (size_t)m * HW + cell;
-      C.ox[o] = (int16_t)ix;
-      C.oy[o] = (int16_t)iy;
-      C.ok[o] = (uint8_t)bi;
+      C.ok[(size_t)m * HW + cell] = (uint8_t)bi;
       acc = acc + v;
     }
     ((T*)J.par_out[m])[cell] = acc;
@@ -555,15 +529,27 @@ void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double th
 }
 
 // ---------------------------------------------------------------------------
-// backtrack: one lane per candidate; record = head | boxes[max_parts][4] | locs[max_parts][3]
+// backtrack (argmin, :219-245): one 64-lane block per candidate, one lane per part, depth by depth — a part's
+// location needs only its parent's, so the 26-part skeleton takes 9 dependent steps instead of 25.
+// The composed pointer planes Ix/Iy of the reference are not materialised by the DP: for the winning
+// child mixture mm = Ik(parent location) the lane reads the DT's own pointer planes of (part, mm),
+//   reference composition (DistanceTransform.hpp:233-244):  x = Ix(py, px),  y = Iy(py, x)
+//   dt_correct_ptr:                                         y = Iy(py, px),  x = Ix(y, px)
+// record = head | boxes[max_parts][4] | locs[max_parts][3]
 // ---------------------------------------------------------------------------
+#define BT_MAXP 256   // parts per component held in LDS
 template <typename T>
 __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count, const CandRec* __restrict__ rec,
                                                   int capacity, const BackLevel* __restrict__ back, int ncomp,
                                                   const int* __restrict__ parent, const int* __restrict__ plane0,
                                                   const int* __restrict__ nparts, int max_parts, int kh,
-                                                  char* __restrict__ out, size_t out_stride) {
-  const int idx = blockIdx.x * 64 + threadIdx.x;
+                                                  char* __restrict__ out, size_t out_stride,
+                                                  const int* __restrict__ flat, const int* __restrict__ depth, int max_depth,
+                                                  int nflat, const unsigned long long* __restrict__ scr_base,
+                                                  const int16_t* __restrict__ ixs, const int16_t* __restrict__ iys,
+                                                  int correct_ptr) {
+  __shared__ int lx[BT_MAXP], ly[BT_MAXP], lm[BT_MAXP];
+  const int idx = blockIdx.x, lane = threadIdx.x;
   const int n = min(*count, capacity);
   if (idx >= n) return;
   const CandRec r = rec[idx];
@@ -574,39 +560,53 @@ __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count,
   int32_t* boxes = (int32_t*)(o + sizeof(pbd_candidate_head));
   int32_t* locs = boxes + (size_t)max_parts * 4;
   const int np = nparts[r.comp];
-  head->score = (float)((const T*)B.rootv)[(size_t)r.y * B.W + r.x];   // Candidate::addPart(Rect, float), Candidate.hpp:72
-  head->component = r.comp;
-  head->level = r.level;
-  head->nparts = np;
+  if (lane == 0) {
+    head->score = (float)((const T*)B.rootv)[(size_t)r.y * B.W + r.x];   // Candidate::addPart(Rect, float), Candidate.hpp:72
+    head->component = r.comp;
+    head->level = r.level;
+    head->nparts = np;
+    lx[0] = r.x; ly[0] = r.y; lm[0] = B.rooti[(size_t)r.y * B.W + r.x];
+  }
+  __syncthreads();
+  for (int d = 1; d <= max_depth; ++d) {
+    for (int p = lane; p < np; p += 64) {
+      if (depth[r.comp * max_parts + p] != d) continue;
+      const int par = parent[r.comp * max_parts + p];
+      const int px = lx[par], py = ly[par], pm = lm[par];
+      const size_t off = (size_t)py * B.W + px;
+      const int mm = B.pk[(size_t)(plane0[r.comp * max_parts + p] + pm) * HW + off];           // Ik
+      const size_t so = (size_t)scr_base[(size_t)r.level * nflat + flat[r.comp * max_parts + p]] + (size_t)mm * HW;
+      int x, y;
+      if (!correct_ptr) { x = ixs[so + off]; y = iys[so + (size_t)py * B.W + x]; }
+      else { y = iys[so + off]; x = ixs[so + (size_t)y * B.W + px]; }
+      lx[p] = x; ly[p] = y; lm[p] = mm;
+    }
+    __syncthreads();
+  }
   const T scale = B.scale;                             // `T scale = scales[n]` (:198): Point * T rounds with cvRound
   const int sz = t_round((T)kh * scale);               // Point(xsize,ysize)*scale
-  for (int p = 0; p < np; ++p) {
-    int x, y, m;
-    if (p == 0) {
-      x = r.x; y = r.y; m = B.rooti[(size_t)r.y * B.W + r.x];
-    } else {
-      const int par = parent[r.comp * max_parts + p];
-      const int px = locs[par * 3], py = locs[par * 3 + 1], pm = locs[par * 3 + 2];
-      const size_t off = (size_t)(plane0[r.comp * max_parts + p] + pm) * HW + (size_t)py * B.W + px;
-      x = B.px[off]; y = B.py[off]; m = B.pk[off];
+  for (int p = lane; p < max_parts; p += 64) {
+    if (p < np) {
+      const int x = lx[p], y = ly[p];
+      locs[p * 3] = x; locs[p * 3 + 1] = y; locs[p * 3 + 2] = lm[p];
+      const int x1 = t_round((T)(x - 1) * scale), y1 = t_round((T)(y - 1) * scale);
+      const int x2 = x1 + sz - 1, y2 = y1 + sz - 1;
+      boxes[p * 4] = min(x1, x2); boxes[p * 4 + 1] = min(y1, y2);
+      boxes[p * 4 + 2] = max(x1, x2) - min(x1, x2); boxes[p * 4 + 3] = max(y1, y2) - min(y1, y2);
+    } else {                                           // components with fewer parts: zero padding
+      for (int k = 0; k < 4; ++k) boxes[p * 4 + k] = 0;
+      for (int k = 0; k < 3; ++k) locs[p * 3 + k] = 0;
     }
-    locs[p * 3] = x; locs[p * 3 + 1] = y; locs[p * 3 + 2] = m;
-    const int x1 = t_round((T)(x - 1) * scale), y1 = t_round((T)(y - 1) * scale);
-    const int x2 = x1 + sz - 1, y2 = y1 + sz - 1;
-    boxes[p * 4] = min(x1, x2); boxes[p * 4 + 1] = min(y1, y2);
-    boxes[p * 4 + 2] = max(x1, x2) - min(x1, x2); boxes[p * 4 + 3] = max(y1, y2) - min(y1, y2);
-  }
-  for (int p = np; p < max_parts; ++p) {  // components with fewer parts: zero padding
-    for (int k = 0; k < 4; ++k) boxes[p * 4 + k] = 0;
-    for (int k = 0; k < 3; ++k) locs[p * 3 + k] = 0;
   }
 }
 
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh, char* out,
-                      size_t out_stride, int ts, hipStream_t s) {
-  if (ts == 8) hipLaunchKernelGGL(k_backtrack<double>, dim3((capacity + 63) / 64), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride);
-  else hipLaunchKernelGGL(k_backtrack<float>, dim3((capacity + 63) / 64), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride);
+                      size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,
+                      const unsigned long long* scr_base, const int16_t* ix, const int16_t* iy, int correct_ptr,
+                      hipStream_t s) {
+  if (ts == 8) hipLaunchKernelGGL(k_backtrack<double>, dim3(capacity), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr);
+  else hipLaunchKernelGGL(k_backtrack<float>, dim3(capacity), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr);
 }
 
 // ---------------------------------------------------------------------------

@@ -101,6 +101,7 @@ static int ingest_model(pbd_handle* h, const pbd_model_desc* m) {
   for (int c = 0; c < nc; ++c) {
     const int p0 = h->part_offset[c], cnp = h->part_offset[c + 1] - p0;
     if (cnp <= 0) return fail(h, PBD_ERR_ARG, "model: empty component");
+    if (cnp > 256) return fail(h, PBD_ERR_UNSUPPORTED, "model: more than 256 parts in a component");   // BT_MAXP (k_backtrack)
     h->max_parts = std::max(h->max_parts, cnp);
     h->comp_plane0[c] = plane_next;
     std::map<int, int> slot_of;   // filter id -> slot (ncscores is indexed by filter id, DynamicProgram.cpp:93)
@@ -237,15 +238,23 @@ static int upload_model(pbd_handle* h) {
   HIPCHK(h, hipMalloc(&h->d_biasw, bw.size() * sizeof(float)));
   HIPCHK(h, hipMemcpy(h->d_biasw, bw.data(), bw.size() * sizeof(float), hipMemcpyHostToDevice));
   const int nc = m.ncomponents, mp = h->max_parts;
-  std::vector<int> par(nc * mp, 0), pl0(nc * mp, 0), npv(nc, 0);
+  std::vector<int> par(nc * mp, 0), pl0(nc * mp, 0), npv(nc, 0), flt(nc * mp, 0), dep(nc * mp, 0);
+  h->max_depth = 0;
   for (int c = 0; c < nc; ++c) {
     const int p0 = h->part_offset[c], cnp = h->part_offset[c + 1] - p0;
     npv[c] = cnp;
     for (int p = 0; p < cnp; ++p) {
       par[c * mp + p] = h->parts[p0 + p].parent;
       pl0[c * mp + p] = (p > 0) ? h->parts[p0 + p].plane0 - h->comp_plane0[c] : 0;
+      flt[c * mp + p] = p0 + p;
+      dep[c * mp + p] = (p > 0) ? dep[c * mp + h->parts[p0 + p].parent] + 1 : 0;   // parents precede children (validated)
+      h->max_depth = std::max(h->max_depth, dep[c * mp + p]);
     }
   }
+  HIPCHK(h, hipMalloc(&h->d_flat, flt.size() * sizeof(int)));
+  HIPCHK(h, hipMalloc(&h->d_depth, dep.size() * sizeof(int)));
+  HIPCHK(h, hipMemcpy(h->d_flat, flt.data(), flt.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_depth, dep.data(), dep.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(h, hipMalloc(&h->d_parent, par.size() * sizeof(int)));
   HIPCHK(h, hipMalloc(&h->d_plane0, pl0.size() * sizeof(int)));
   HIPCHK(h, hipMalloc(&h->d_nparts, npv.size() * sizeof(int)));
@@ -347,8 +356,6 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   if ((rc = dev_alloc(h, &h->d_feat, cells * PBD_FLEN * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_resp, cells * m.nfilters * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_acc, cells * h->nslots * ts))) return rc;
-  if ((rc = dev_alloc(h, &h->d_px, cells * std::max(h->nplanes, 1)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_py, cells * std::max(h->nplanes, 1)))) return rc;
   if ((rc = dev_alloc(h, &h->d_pk, cells * std::max(h->nplanes, 1)))) return rc;
   if ((rc = dev_alloc(h, &h->d_rootv, cells * m.ncomponents * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_rooti, cells * m.ncomponents))) return rc;
@@ -523,9 +530,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
             if (h->part_offset[P.comp] + P.parent != pf) continue;
             ReduceChild& C = J.ch[J.nch++];
             const size_t so = scr_of(fp, l, 0);
-            C.sdt = h->d_dt_sdt + so * ts; C.ix = h->d_dt_ixT + so; C.iy = h->d_dt_iy + so;
-            const size_t po = L.cell_off * h->nplanes + (size_t)P.plane0 * HW;
-            C.ox = h->d_px + po; C.oy = h->d_py + po; C.ok = h->d_pk + po;
+            C.sdt = h->d_dt_sdt + so * ts;
+            C.ok = h->d_pk + L.cell_off * h->nplanes + (size_t)P.plane0 * HW;
             C.K = P.K;
             for (int mm = 0; mm < P.K; ++mm) C.bias_off[mm] = P.biasid[mm];
           }
@@ -560,7 +566,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     for (int c = 0; c < m.ncomponents; ++c) {
       BackLevel& B = bl[(size_t)l * m.ncomponents + c];
       const size_t po = L.cell_off * h->nplanes + (size_t)h->comp_plane0[c] * HW;
-      B.px = h->d_px + po; B.py = h->d_py + po; B.pk = h->d_pk + po;
+      B.pk = h->d_pk + po;
       B.rootv = h->d_rootv + (L.cell_off * m.ncomponents + (size_t)c * HW) * ts;
       B.rooti = h->d_rooti + L.cell_off * m.ncomponents + (size_t)c * HW;
       B.H = L.ch; B.W = L.cw; B.scale = L.scale;
@@ -582,6 +588,12 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   h->root_cells = rcells;
   if ((rc = dev_upload(h, &h->d_rootjobs, rj))) return rc;
   if ((rc = dev_upload(h, &h->d_back, bl))) return rc;
+  // where the DT pointer planes of (level, part) live: back-tracking composes Ix / Iy from them on the fly
+  h->scr_base.assign((size_t)n * h->parts.size(), 0);
+  for (int l = 0; l < n; ++l)
+    for (size_t fp = 0; fp < h->parts.size(); ++fp)
+      if (h->parts[fp].p > 0 && h->lv[l].active) h->scr_base[(size_t)l * h->parts.size() + fp] = scr_of((int)fp, l, 0);
+  if ((rc = dev_upload(h, &h->d_scr_base, h->scr_base))) return rc;
   h->fw = w; h->fh = hgt; h->fcn = cn;
   return PBD_OK;
 }
@@ -674,7 +686,9 @@ static const int kFirstCopy = 192;  // records fetched together with the count
 
 static int run_argmin_enqueue(pbd_handle* h) {
   launch_backtrack(h->d_cand_count, h->d_cand_rec, h->opt.max_candidates, h->d_back, h->md.ncomponents, h->d_parent,
-                   h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, h->d_cand_out, h->cand_stride, h->ts, h->stream);
+                   h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, h->d_cand_out, h->cand_stride, h->ts, h->d_flat,
+                   h->d_depth, h->max_depth, (int)h->parts.size(), h->d_scr_base, h->d_dt_ixT, h->d_dt_iy,
+                   h->opt.dt_correct_ptr, h->stream);
   HIPCHK(h, hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   const int first = std::min(kFirstCopy, h->opt.max_candidates);
   HIPCHK(h, hipMemcpyAsync(h->h_cand_out, h->d_cand_out, h->cand_stride * first, hipMemcpyDeviceToHost, h->stream));
@@ -797,6 +811,7 @@ int pbd_destroy(pbd_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   free_frame(h);
   hipFree(h->d_wT); hipFree(h->d_biasw); hipFree(h->d_parent); hipFree(h->d_plane0); hipFree(h->d_nparts);
+  hipFree(h->d_flat); hipFree(h->d_depth);
   hipFree(h->d_cand_count); hipFree(h->d_cand_rec); hipFree(h->d_cand_out);
   if (h->h_cand_out) hipHostFree(h->h_cand_out);
   if (h->h_cand_count) hipHostFree(h->h_cand_count);
@@ -1014,13 +1029,27 @@ int pbd_get_dp_pointers(pbd_handle* h, int level, int component, int part, int p
   const Level& L = h->lv[level];
   const size_t HW = (size_t)L.cw * L.ch;
   const size_t po = L.cell_off * h->nplanes + (size_t)(P.plane0 + parent_mix) * HW;
-  std::vector<int16_t> a(HW), b(HW);
+  if (!L.active) return fail(h, PBD_ERR_STATE, "level is not processed by this handle");
+  // Ik is stored; Ix / Iy (reducePickIndex of the composed DT pointers, src/DynamicProgram.cpp:144-149) are
+  // composed here from the DT pointer planes of the winning mixture, exactly as k_backtrack does per candidate
   std::vector<uint8_t> c(HW);
+  std::vector<int16_t> X((size_t)P.K * HW), Y((size_t)P.K * HW);
+  const size_t so = (size_t)h->scr_base[(size_t)level * h->parts.size() + (p0 + part)];
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(a.data(), h->d_px + po, HW * 2, hipMemcpyDeviceToHost));
-  HIPCHK(h, hipMemcpy(b.data(), h->d_py + po, HW * 2, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(c.data(), h->d_pk + po, HW, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < HW; ++i) { if (ix) ix[i] = a[i]; if (iy) iy[i] = b[i]; if (ik) ik[i] = c[i]; }
+  HIPCHK(h, hipMemcpy(X.data(), h->d_dt_ixT + so, X.size() * 2, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(Y.data(), h->d_dt_iy + so, Y.size() * 2, hipMemcpyDeviceToHost));
+  const int W = L.cw;
+  for (size_t i = 0; i < HW; ++i) {
+    const size_t mo = (size_t)c[i] * HW;
+    const int m_ = (int)(i / W), n_ = (int)(i - (size_t)m_ * W);
+    int x, y;
+    if (!h->opt.dt_correct_ptr) { x = X[mo + i]; y = Y[mo + (size_t)m_ * W + x]; }
+    else { y = Y[mo + i]; x = X[mo + (size_t)y * W + n_]; }
+    if (ix) ix[i] = x;
+    if (iy) iy[i] = y;
+    if (ik) ik[i] = c[i];
+  }
   return PBD_OK;
 }
 static int get_root_(pbd_handle* h, int level, int component, void* rootv, int32_t* rooti, int ts) {
@@ -1085,7 +1114,7 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   ReduceJob J{};
   J.H = rows; J.W = cols; J.L = 1; J.nch = 1;
   J.par_in[0] = d_zero; J.par_out[0] = d_out;
-  J.ch[0].sdt = d_sdt; J.ch[0].ix = d_ixT; J.ch[0].iy = d_iy; J.ch[0].ox = d_ox; J.ch[0].oy = d_oy; J.ch[0].ok = d_ok;
+  J.ch[0].sdt = d_sdt; J.ch[0].ok = d_ok;
   J.ch[0].K = 1;
   J.ch[0].bias_off[0] = (int)h->biasw.size();  // the trailing 0.0f
   HIPCHK(h, hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, h->stream));
@@ -1101,10 +1130,17 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   launch_reduce(d_job, d_rblk, (int)rblk.size(), h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_out, HW * ts, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(hx.data(), d_ox, HW * 2, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(hy.data(), d_oy, HW * 2, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(hx.data(), d_ixT, HW * 2, hipMemcpyDeviceToHost, h->stream));   // the passes' own pointers
+  HIPCHK(h, hipMemcpyAsync(hy.data(), d_iy, HW * 2, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  for (size_t i = 0; i < HW; ++i) { if (ix) ix[i] = hx[i]; if (iy) iy[i] = hy[i]; }
+  for (size_t i = 0; i < HW; ++i) {   // pointer composition of compute() (:233-244), or the true arg-max one
+    const int m_ = (int)(i / cols), n_ = (int)(i - (size_t)m_ * cols);
+    int x, y;
+    if (!h->opt.dt_correct_ptr) { x = hx[i]; y = hy[(size_t)m_ * cols + x]; }
+    else { y = hy[i]; x = hx[(size_t)y * cols + n_]; }
+    if (ix) ix[i] = x;
+    if (iy) iy[i] = y;
+  }
   hipFree(d_in); hipFree(d_tmp); hipFree(d_sdt); hipFree(d_zero); hipFree(d_out); hipFree(d_ixT); hipFree(d_iy);
   hipFree(d_ox); hipFree(d_oy); hipFree(d_ok); hipFree(d_rblk); hipFree(d_maps); hipFree(d_groups); hipFree(d_tasks); hipFree(d_job);
   return PBD_OK;

@@ -67,9 +67,9 @@ struct DtTask { int group, g0; };
 #define PBD_MAX_CH 8   // children of one parent folded into one reduce job
 struct ReduceChild {     // one child part's distance-transformed mixtures
   const void* sdt;       // T [K][H][W] distance-transformed child scores
-  const int16_t* ix;     // [K][H][W] x pointers (row-major)
-  const int16_t* iy;     // [K][H][W] y pointers
-  int16_t* ox; int16_t* oy; uint8_t* ok;  // output pointer planes of this child, [L][H][W]
+  uint8_t* ok;           // output: best child mixture per parent mixture, [L][H][W].  The x / y pointers of the
+                         // winning mixture are NOT materialised: the DT pointer planes stay in HBM for the frame and
+                         // the few back-tracked candidates compose them on the fly (k_backtrack)
   int K, pad;
   int bias_off[PBD_MAX_MIX];  // biasw index of bias(mm)[0] for each child mixture mm
 };
@@ -88,7 +88,7 @@ struct RootJob {
   unsigned cell0;
 };
 struct BackLevel {   // per (level, comp) info for backtracking
-  const int16_t* px; const int16_t* py; const uint8_t* pk; // plane 0 of this comp at this level
+  const uint8_t* pk;   // best-mixture plane 0 of this comp at this level
   const void* rootv; const int* rooti;   // rootv: T
   int H, W; float scale;
 };
@@ -138,7 +138,12 @@ struct pbd_handle {
   uint8_t* d_img = nullptr; size_t img_cap = 0;
   uint8_t* d_pyr = nullptr;
   char* d_feat = nullptr; char* d_resp = nullptr; char* d_acc = nullptr;   // T data, addressed in bytes (elements * ts)
-  int16_t* d_px = nullptr; int16_t* d_py = nullptr; uint8_t* d_pk = nullptr;
+  uint8_t* d_pk = nullptr;
+  unsigned long long* d_scr_base = nullptr;   // [nlevels][nflat parts] element offset of mixture 0's DT planes (ix / iy / sdt)
+  std::vector<unsigned long long> scr_base;   // host copy (pbd_get_dp_pointers)
+  int* d_flat = nullptr;     // [ncomp][max_parts] flat part index
+  int* d_depth = nullptr;    // [ncomp][max_parts] depth of each part in its tree (root = 0)
+  int max_depth = 0;
   char* d_rootv = nullptr; int* d_rooti = nullptr;
   char* d_dt_tmpT = nullptr; char* d_dt_sdt = nullptr; int16_t* d_dt_ixT = nullptr; int16_t* d_dt_iy = nullptr;
   size_t dt_cap_elems = 0;
@@ -215,7 +220,9 @@ void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double th
                  int capacity, int ts, hipStream_t s);
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
-                      char* out, size_t out_stride, int ts, hipStream_t s);
+                      char* out, size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,
+                      const unsigned long long* scr_base, const int16_t* ix, const int16_t* iy, int correct_ptr,
+                      hipStream_t s);
 void dt_debug_read(unsigned long long* out);
 void launch_dt_wave(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, hipStream_t s);
 size_t dtw_lds_bytes(int len);
