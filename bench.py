@@ -90,7 +90,8 @@ def main():
     model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).to(dev), W, H, dtype=dtype)
 
     S = max(1, args.inflight)
-    handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=4096, dtype=dtype) for _ in range(S)]
+    cap = 4096 if W * H <= 640 * 480 else 32768      # the 99.9th-percentile threshold scales the count with the area
+    handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=cap, dtype=dtype) for _ in range(S)]
     for hd in handles:
         hd.set_profiling(True)
 
@@ -99,13 +100,13 @@ def main():
         for i in range(nsteps):
             hd = handles[i % S]
             if len(pending) == S:
-                out = pending.pop(0).collect()
+                out = pending.pop(0).collect(cap)
                 if collect_out is not None:
                     collect_out.append(out)
             hd.enqueue_dev(frames[i % nimg].data_ptr(), W, H, 3)
             pending.append(hd)
         for hd in pending:
-            out = hd.collect()
+            out = hd.collect(cap)
             if collect_out is not None:
                 collect_out.append(out)
 
@@ -144,7 +145,7 @@ def main():
     nseq = 20
     stage_acc = {}
     for i in range(nseq):
-        hd.detect_dev(frames[i % nimg].data_ptr(), W, H, 3)
+        hd.detect_dev(frames[i % nimg].data_ptr(), W, H, 3, capacity=cap)
         for k, v in hd.stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v / nseq
     dp_ms_seq = hd.dp_timer()[0]

@@ -125,7 +125,7 @@ __device__ __forceinline__ bool dt_envelope(typename Pair<T>::type* __restrict__
   return suspect != 0;
 }
 
-// Cooperative envelope scan: LPL (2 or 4) adjacent lanes share one line.  Lane j of the group holds stack
+// Cooperative envelope scan: LPL (2, 4, 8 or 16) adjacent lanes share one line.  Lane j of the group holds stack
 // entry k-j and evaluates the intersection of ITS entry with the current element q — exactly the value the
 // reference computes when its pop loop reaches that entry (`s = f(v[k], q, ...)` after j pops, :161-165).
 // pop_j = (s_j <= z[k-j]) && (k-j > 0); the reference pops while that holds, so the number of pops is
@@ -259,7 +259,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   // ---- build the upper envelope (DistanceTransform.hpp:156-170) ----
   // lanes per line: long lines leave most lanes of the wave without a line (LDS capacity), so 4 or 2 lanes
   // share a line (dt_envelope_m); short lines fill the wave with one lane per line (dt_envelope).
-  const int lpl = g.lpb <= 16 ? 4 : (g.lpb <= 32 ? 2 : 1);
+  const int lpl = g.lpb <= 4 ? 16 : g.lpb <= 8 ? 8 : g.lpb <= 16 ? 4 : (g.lpb <= 32 ? 2 : 1);
   auto coop = [&](auto LPLc) {
     constexpr int LPL = decltype(LPLc)::value;
     const int line = lane / LPL, j = lane % LPL;
@@ -285,7 +285,9 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       if (j == 0) { YZl[k + 1].y = INFINITY; Ksz[line] = k; }
     }
   };
-  if (lpl == 4) coop(std::integral_constant<int, 4>());
+  if (lpl == 16) coop(std::integral_constant<int, 16>());
+  else if (lpl == 8) coop(std::integral_constant<int, 8>());
+  else if (lpl == 4) coop(std::integral_constant<int, 4>());
   else if (lpl == 2) coop(std::integral_constant<int, 2>());
   else if (lane < nl) {
     const int gi = t.g0 + lane;

@@ -300,14 +300,14 @@ static void free_frame(pbd_handle* h) {
 }
 
 // DT block geometry under an LDS budget.  stride = len+1 rounded up to even (keeps the double
-// table and the float arrays 8-byte aligned); lpb = lines per block (any value 8..64: the scan runs
+// table and the float arrays 8-byte aligned); lpb = lines per block (any value 4..64: the scan runs
 // one lane per line and is VALU-issue bound, so lanes per wave = throughput);
 // nmb = maps a block of lpb consecutive lines can touch.
 static int dt_stride_for(int len) { return (len + 2) & ~1; }
 static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (lpb + nlines - 2) / nlines + 1); }
 static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget, int ts) {
   int lpb = 64;
-  while (lpb > 8 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts) > budget) --lpb;
+  while (lpb > 4 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts) > budget) --lpb;
   // the kernel shares a line between 4 lanes when lpb <= 16 and 2 lanes when lpb <= 32 (dt_envelope_m):
   // just above those thresholds a few lines fewer per block buy twice the lanes per line
   static const int snap4 = getenv("PBD_DT_SNAP4") ? atoi(getenv("PBD_DT_SNAP4")) : 24;
@@ -405,7 +405,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
   size_t dt_base = 20 * 1024;   // 8 one-wave blocks per CU: measured optimum on MI355X (12..32 KB swept)
   if (const char* e = getenv("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
-  size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 8, 2, h->ts));
+  size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 4, 2, h->ts));
   if (dt_budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
   h->dt_lds = dt_budget;
   std::vector<DtMap> maps;
@@ -1095,7 +1095,7 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
   size_t dt_base = 40 * 1024;
   if (const char* e = getenv("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
-  const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 8, 1, tsz));
+  const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 4, 1, tsz));
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
   DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz), dt_group(1, 1, cols, rows, budget, tsz)};
   std::vector<DtTask> tasks;
