@@ -496,6 +496,7 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[m][r] = (T)0;
   const T* abase = ft + ((4 * wave) * TW + ai) * CS + ak;   // M-tile m adds m*TW*CS
+  const int mvalid = __builtin_amdgcn_readfirstlane(min(max(H - (t.y0 + 4 * wave), 0), 4));   // M-tiles (= cell rows) of this wave inside the level
 
 #pragma unroll 1
   for (int half = 0; half < NHALF; ++half) {
@@ -545,7 +546,8 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
 #pragma unroll
       for (int u = 0; u < KS; ++u) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m] = MM::mma(a[m * TW * CS + 4 * u], bw[u], acc[m]);
+        for (int m = 0; m < 4; ++m)
+          if (m < mvalid) acc[m] = MM::mma(a[m * TW * CS + 4 * u], bw[u], acc[m]);   // wave-uniform: rows past the level's last row do no MFMA work
       }
     };
     auto tap_pair = [&](int tap) {
