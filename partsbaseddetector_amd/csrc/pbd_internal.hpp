@@ -7,8 +7,8 @@
 //   feat     f32  HOG: level l at feat_off[l], [ch][cw][32]      (cell-major)
 //   resp     f32  pdf: level l at resp_off[l], [nfilters][ch][cw] (plane-major)
 //   acc      f32  accumulated part scores: level l at acc_off[l], [nslots][ch][cw]
-//   ptrx/y   i16  DP back pointers: level l at ptr_off[l], [nplanes][ch][cw]
-//   ptrk     u8   DP best child mixture, same indexing
+//   ptrk     u8   DP best child mixture Ik: level l at cell_off[l]*nplanes, [nplanes][ch][cw]
+//                 (Ix / Iy are composed at back-tracking time from the DT pointer planes dt_ixT / dt_iy)
 //   rootv/i  f32/i32  level l at root_off[l], [ncomp][ch][cw]
 //   dt_*          per-round scratch of the distance transform
 //   cand          device candidate list (count + records)
