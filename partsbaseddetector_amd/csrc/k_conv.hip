@@ -601,8 +601,9 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
   launch_conv_mfma16_t<double, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
 }
 
-// float instantiations of the same kernel: nhalf 1 = whole 32-channel tile in LDS (default fp32 filter bank),
-// 2 / 3 = two channel halves at 5 / 3 waves per SIMD (probe variants).  Tried and dropped: a persistent
+// float instantiations of the same kernel: nhalf 3 = two channel halves, 3+ waves per SIMD (default fp32 filter
+// bank: 0.39 ms and the best throughput with other frames' kernels co-resident), 2 = halves at 5 waves per SIMD
+// (8 spilled registers), 1 = whole 32-channel tile in LDS (0.42 ms).  Tried and dropped: a persistent
 // variant keeping the tile resident across a chunk of n-tiles with a register-direct epilogue (0.49 ms vs
 // 0.44 ms, and long-running workgroups hurt the overlap with other frames' kernels); capping the kernel at
 // two workgroups per CU to leave LDS and wave slots to co-running DT kernels (716 vs 751 frames/s); staging

@@ -632,9 +632,10 @@ static int run_pdf(pbd_handle* h) {
   if (h->conv_mode == PBD_CONV_MFMA)
     if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT, (double*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
     else {
-      // default: 16x16x4 MFMA, whole tile in LDS (k_conv_mfma16<float, 1>); PBD_MFMA_VARIANT=0 selects the
-      // older 32x32x2 kernel, 2/3 the channel-half variants (A/B knob)
-      static const int variant = getenv("PBD_MFMA_VARIANT") ? atoi(getenv("PBD_MFMA_VARIANT")) : 1;
+      // default: 16x16x4 MFMA, tile staged in two channel halves (k_conv_mfma16<float, 2>: 27 KB of LDS per
+      // workgroup, so DT blocks of other frames co-reside on the CU); PBD_MFMA_VARIANT=0 selects the older
+      // 32x32x2 kernel, 1 the whole-tile variant, 2 the halves at 5 waves/SIMD (A/B knob)
+      static const int variant = getenv("PBD_MFMA_VARIANT") ? atoi(getenv("PBD_MFMA_VARIANT")) : 3;
       if (variant && m.kh == 5 && m.kw == 5)
         launch_conv_mfma16_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT, (float*)h->d_resp, m.nfilters, h->nfpad, variant, h->stream);
       else
