@@ -617,5 +617,6 @@ void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* l
   if (ntiles <= 0) return;
   if (nhalf == 2) launch_conv_mfma16_t<float, 2, 5>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 3) launch_conv_mfma16_t<float, 2, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
+  else if (nhalf == 4) launch_conv_mfma16_t<float, 4, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else launch_conv_mfma16_t<float, 1, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
 }
