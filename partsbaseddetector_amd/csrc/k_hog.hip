@@ -40,13 +40,16 @@ __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int cn, int t
   L.RT = L.PT + L.MG + 1;
   size_t o = 0;
   L.mag_off = o; o += (size_t)ts * L.PT * L.PT;
-  L.hist_off = o; o += (size_t)ts * L.NB * L.NB * PBD_NORIENT;
+  // the staged source pixels (raw) are dead once (|g|, bin) are computed and the histograms are not live
+  // before: they share one region (one barrier more) — 20 KB less LDS per workgroup, which leaves room for
+  // other kernels' workgroups on the CU
+  const size_t hist_bytes = (size_t)ts * L.NB * L.NB * PBD_NORIENT, raw_bytes = (size_t)L.RT * L.RT * cn;
+  L.hist_off = o; L.raw_off = o;
+  o += ((hist_bytes > raw_bytes ? hist_bytes : raw_bytes) + 7) & ~(size_t)7;
   L.norm_off = o; o += (size_t)ts * L.NB * L.NB;
   L.ninv_off = o; o += (size_t)ts * (tc + 1) * (tc + 1);
   L.tab_off = o; o += ((size_t)ts * 2 + sizeof(int)) * 2 * L.PT;  // w0,w1,ip for y and x
   L.bin_off = o; o += L.PT * L.PT;
-  o = (o + 3) & ~(size_t)3;
-  L.raw_off = o; o += (size_t)L.RT * L.RT * cn;
   L.total = (o + 15) & ~(size_t)15;
   return L;
 }
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(HOG_NT) void k_hog(const HogTile* __restrict__ tile
     mag[i] = m;
     bin[i] = (uint8_t)b;
   }
-  for (int i = tid; i < NB * NB * PBD_NORIENT; i += HOG_NT) hist[i] = (T)0;
+  __syncthreads();                                       // every thread is done with the staged pixels ...
+  for (int i = tid; i < NB * NB * PBD_NORIENT; i += HOG_NT) hist[i] = (T)0;   // ... whose LDS the histograms take over
   __syncthreads();
   HOG_STAMP(2);
 
