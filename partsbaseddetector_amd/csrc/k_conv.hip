@@ -611,7 +611,9 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
 // 0.44 ms, and long-running workgroups hurt the overlap with other frames' kernels); capping the kernel at
 // two workgroups per CU to leave LDS and wave slots to co-running DT kernels (716 vs 751 frames/s); staging
 // once for 2 or 5 n-tiles with a register-direct epilogue (one unaligned 16-byte store per M-tile and lane:
-// 0.48-0.52 ms vs 0.43 ms — the LDS-transposed epilogue writes whole 64-byte row segments and is faster).
+// 0.48-0.52 ms vs 0.43 ms — the LDS-transposed epilogue writes whole 64-byte row segments and is faster);
+// double-buffered staging (next channel group prefetched into registers across the K loop, second LDS buffer):
+// 0.51-0.71 ms vs 0.39 ms.
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                             const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s) {
   if (ntiles <= 0) return;
