@@ -54,6 +54,10 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
                     help="instantiation: f32 = PartsBasedDetector<float> (BASELINE.json metric), f64 = <double> "
                          "(SURVEY 8f-3: the ROS node / ecto cell instantiation; exact VALU filter bank)")
+    ap.add_argument("--shard", choices=["frames", "levels"], default="frames",
+                    help="N>1: 'frames' = every rank its own frames (weak scaling, the BASELINE metric); 'levels' = all "
+                         "ranks work on the SAME frames, each on an LPT-balanced set of pyramid levels (strong scaling, "
+                         "BASELINE configs[3]: use with --width 1920 --height 1080)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU-side smoke runs)")
     args = ap.parse_args()
@@ -85,7 +89,8 @@ def main():
     dtype = np.float64 if args.dtype == "f64" else np.float32
     # distinct frames per rank and per step slot (32 seeds as in configs[2]); resident in HBM
     nimg = 8
-    frames = [torch.from_numpy(make_image(rank * nimg + i, W, H)).to(dev) for i in range(nimg)]
+    by_levels = args.shard == "levels" and world > 1
+    frames = [torch.from_numpy(make_image((0 if by_levels else rank * nimg) + i, W, H)).to(dev) for i in range(nimg)]
     torch.cuda.synchronize()
     model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).to(dev), W, H, dtype=dtype)
 
@@ -94,6 +99,12 @@ def main():
     handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=cap, dtype=dtype) for _ in range(S)]
     for hd in handles:
         hd.set_profiling(True)
+    if by_levels:   # SURVEY 8e / configs[3]: one frame, levels spread over the ranks by greedy LPT on the cell counts
+        from partsbaseddetector_amd.parallel import shard_levels_lpt
+        g = handles[0].geometry(W, H)
+        my_levels = shard_levels_lpt((g["cell_w"].astype(np.int64) * g["cell_h"]).tolist(), world)[rank]
+        for hd in handles:
+            hd.set_levels(my_levels)
 
     def run(nsteps, collect_out=None):
         pending = []
@@ -155,7 +166,7 @@ def main():
         stage = stage_acc
         dp_ms = dp_ms_seq
         ms_per_step = dt / args.steps * 1e3
-        value = args.steps * world / dt
+        value = args.steps * (1 if by_levels else world) / dt
         # roofline of the stage the north_star prices: the DP/distance-transform pass (HBM-bound).
         # achieved = algorithmic bytes of one frame's pass (B_dp) / its GPU time measured
         # with HIP events on the handle's stream.
@@ -178,15 +189,15 @@ def main():
                     "peak": peak, "unit": "TFLOP/s", "frac": round(pdf_tf / peak, 5), "traffic": None,
                     "launch_ms": round(float(stage["pdf"]), 4), "algorithmic_flops": work["F_pdf"]}
         line = {
-            "metric": "detect() frames/sec, 640x480, 26-part person model",
+            "metric": f"detect() frames/sec, {W}x{H}, 26-part person model",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong" if by_levels else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"person 26 parts x {args.mixtures} mixtures ({len(model.filtersw)} 5x5x32 filters), "
                                    f"{W}x{H} BGR, full pyramid ({hd.geometry(W, H)['nlevels']} levels), "
                                    f"threshold = 99.9th pct of root scores",
                        "frames_per_step_per_gpu": 1, "inflight": S, "conv": args.conv,
-                       "candidates_last_frame": int(ncand_all), "parallelism": f"frames x{world}"},
+                       "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}")},
             "roofline": roof,
             "roofline_dt": {"bound": "hbm", "achieved": round(dp_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(dp_gbs / 8000.0, 5), "ms": round(float(dp_ms), 4)},
