@@ -1084,15 +1084,11 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipSetDevice(h->opt.device));
   const size_t HW = (size_t)rows * cols;
   const size_t ts = (size_t)tsz;
-  char *d_in, *d_tmp, *d_sdt, *d_zero, *d_out;
-  int16_t *d_ixT, *d_iy, *d_ox, *d_oy;
-  uint8_t* d_ok;
+  char *d_in, *d_tmp, *d_sdt;
+  int16_t *d_ixT, *d_iy;
   HIPCHK(h, hipMalloc(&d_in, HW * ts)); HIPCHK(h, hipMalloc(&d_tmp, HW * ts)); HIPCHK(h, hipMalloc(&d_sdt, HW * ts));
-  HIPCHK(h, hipMalloc(&d_zero, HW * ts)); HIPCHK(h, hipMalloc(&d_out, HW * ts));
   HIPCHK(h, hipMalloc(&d_ixT, HW * 2)); HIPCHK(h, hipMalloc(&d_iy, HW * 2));
-  HIPCHK(h, hipMalloc(&d_ox, HW * 2)); HIPCHK(h, hipMalloc(&d_oy, HW * 2)); HIPCHK(h, hipMalloc(&d_ok, HW));
   HIPCHK(h, hipMemcpyAsync(d_in, in, HW * ts, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemsetAsync(d_zero, 0, HW * ts, h->stream));
   DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
   size_t dt_base = 40 * 1024;
   if (const char* e = getenv("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
@@ -1105,32 +1101,20 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   for (int g0 = 0; g0 < rows; g0 += (use_wave_x ? 16 : groups[0].lpb)) tasks.push_back(DtTask{0, g0});
   const int nx = (int)tasks.size();
   for (int g0 = 0; g0 < cols; g0 += (use_wave_y ? 16 : groups[1].lpb)) tasks.push_back(DtTask{1, g0});
-  DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks; ReduceJob* d_job; ReduceBlock* d_rblk;
-  std::vector<ReduceBlock> rblk;
-  for (unsigned c0 = 0; c0 < (unsigned)HW; c0 += 256) rblk.push_back(ReduceBlock{0, c0});
-  HIPCHK(h, hipMalloc(&d_rblk, sizeof(ReduceBlock) * rblk.size()));
-  HIPCHK(h, hipMemcpyAsync(d_rblk, rblk.data(), sizeof(ReduceBlock) * rblk.size(), hipMemcpyHostToDevice, h->stream));
+  DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks;
   HIPCHK(h, hipMalloc(&d_maps, sizeof(maps))); HIPCHK(h, hipMalloc(&d_groups, sizeof(groups)));
-  HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size())); HIPCHK(h, hipMalloc(&d_job, sizeof(ReduceJob)));
-  ReduceJob J{};
-  J.H = rows; J.W = cols; J.L = 1; J.nch = 1;
-  J.par_in[0] = d_zero; J.par_out[0] = d_out;
-  J.ch[0].sdt = d_sdt; J.ch[0].ok = d_ok;
-  J.ch[0].K = 1;
-  J.ch[0].bias_off[0] = (int)h->biasw.size();  // the trailing 0.0f
+  HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size()));
   HIPCHK(h, hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_groups, groups, sizeof(groups), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(d_job, &J, sizeof(J), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
   if (use_wave_x) launch_dt_wave(d_tasks, nx, d_groups, d_maps, dtw_lds_bytes(cols), h->stream);
   else launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, tsz, h->stream);
   if (getenv("PBD_DEBUG_SKIP_Y")) {}   // probe: leave the x pass as the last DT launch (its stamps are then readable)
   else if (use_wave_y) launch_dt_wave(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, dtw_lds_bytes(rows), h->stream);
   else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, tsz, h->stream);
-  launch_reduce(d_job, d_rblk, (int)rblk.size(), h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
-  HIPCHK(h, hipMemcpyAsync(out, d_out, HW * ts, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out, d_sdt, HW * ts, hipMemcpyDeviceToHost, h->stream));   // the y pass's scores, untouched
   HIPCHK(h, hipMemcpyAsync(hx.data(), d_ixT, HW * 2, hipMemcpyDeviceToHost, h->stream));   // the passes' own pointers
   HIPCHK(h, hipMemcpyAsync(hy.data(), d_iy, HW * 2, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1142,8 +1126,8 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
     if (ix) ix[i] = x;
     if (iy) iy[i] = y;
   }
-  hipFree(d_in); hipFree(d_tmp); hipFree(d_sdt); hipFree(d_zero); hipFree(d_out); hipFree(d_ixT); hipFree(d_iy);
-  hipFree(d_ox); hipFree(d_oy); hipFree(d_ok); hipFree(d_rblk); hipFree(d_maps); hipFree(d_groups); hipFree(d_tasks); hipFree(d_job);
+  hipFree(d_in); hipFree(d_tmp); hipFree(d_sdt); hipFree(d_ixT); hipFree(d_iy);
+  hipFree(d_maps); hipFree(d_groups); hipFree(d_tasks);
   return PBD_OK;
 }
 int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, double bx, double ay, double by, int osx,

@@ -558,3 +558,32 @@ def test_detect_both_dt_kernels_agree_with_oracle(gpu_required, orc):
         h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dt_mode=mode)
         assert_candidates_equal(h.detect(im), ref)
         h.close()
+
+
+def test_dt2d_random_sweep_all_lane_sharing_modes(small_handle, orc):
+    """Randomised sweep over map shapes that exercise every lanes-per-line mode of k_dt_pass (1, 2, 4, 8, 16 lanes
+    per line: lines of ~10 .. 1500 elements), curvatures, offsets and value statistics (smooth, noisy, integer
+    plateaus with exact-midpoint intersections -> the exact redo path), always bit-exact against the oracle."""
+    rng = np.random.default_rng(2026)
+    shapes = [(3, 1500), (1500, 2), (5, 700), (9, 300), (40, 200), (200, 40), (33, 120), (120, 33), (64, 90),
+              (17, 60), (60, 17), (25, 45), (45, 25), (12, 30), (30, 12), (7, 10)]
+    for i, (r, c) in enumerate(shapes * 2):
+        kind = i % 4
+        if kind == 0:
+            a = rng.normal(0, 1.5, (r, c))
+        elif kind == 1:
+            a = np.round(rng.normal(0, 2, (r, c)))                      # ties / plateaus
+        elif kind == 2:
+            yy, xx = np.mgrid[0:r, 0:c]
+            a = np.sin(xx / 7.0) * np.cos(yy / 5.0) + 0.05 * rng.normal(size=(r, c))   # smooth: deep pops
+        else:
+            a = rng.uniform(-1e-3, 1e-3, (r, c)) + (rng.random((r, c)) < 0.02) * 5.0   # sparse peaks
+        a = a.astype(np.float32)
+        ax, ay = -float(rng.choice([1.0, 0.5, 0.05, 0.01, 0.003])), -float(rng.choice([1.0, 0.25, 0.02, 0.007]))
+        bx, by = float(rng.uniform(-0.05, 0.05)), float(rng.choice([0.0, 0.01, -0.02]))
+        osx, osy = int(rng.integers(-4, 5)), int(rng.integers(-4, 5))
+        got = small_handle.dt2d(a, ax, bx, ay, by, osx, osy)
+        ref = orc.dt2d(a, ax, bx, ay, by, osx, osy)
+        np.testing.assert_array_equal(got[0].view(np.uint32), ref[0].view(np.uint32), err_msg=f"case {i} {r}x{c}")
+        np.testing.assert_array_equal(got[1], ref[1], err_msg=f"case {i} ix")
+        np.testing.assert_array_equal(got[2], ref[2], err_msg=f"case {i} iy")

@@ -282,3 +282,17 @@ def test_cpp_host_demo_double_matches_oracle(gpu_required, orc, tmp_path):
             assert np.float32(float(tok[0])) == h["score"] and int(tok[2]) == h["level"]
             got = np.array([[int(v) for v in t.split(",")] for t in tok[3:]])
             np.testing.assert_array_equal(got, b[: len(got)])
+
+
+def test_dt2d_f64_random_sweep_all_lane_sharing_modes(h64, orc):
+    rng = np.random.default_rng(2027)
+    shapes = [(3, 1200), (1200, 2), (9, 300), (40, 200), (200, 40), (33, 120), (64, 90), (17, 60), (25, 45), (12, 30), (7, 10)]
+    for i, (r, c) in enumerate(shapes * 2):
+        a = rng.normal(0, 1.5, (r, c)) if i % 2 == 0 else np.round(rng.normal(0, 2, (r, c)))
+        ax, ay = -float(rng.choice([1.0, 0.5, 0.05, 0.01, 0.003])), -float(rng.choice([1.0, 0.25, 0.02, 0.007]))
+        bx, by = float(rng.uniform(-0.05, 0.05)), float(rng.choice([0.0, 0.01, -0.02]))
+        osx, osy = int(rng.integers(-4, 5)), int(rng.integers(-4, 5))
+        got = h64.dt2d(a, ax, bx, ay, by, osx, osy)
+        ref = orc.dt2d(a, ax, bx, ay, by, osx, osy, dtype=F64)
+        np.testing.assert_array_equal(_bits(got[0]), _bits(ref[0]), err_msg=f"case {i} {r}x{c}")
+        np.testing.assert_array_equal(got[1], ref[1]); np.testing.assert_array_equal(got[2], ref[2])
