@@ -587,3 +587,27 @@ def test_dt2d_random_sweep_all_lane_sharing_modes(small_handle, orc):
         np.testing.assert_array_equal(got[0].view(np.uint32), ref[0].view(np.uint32), err_msg=f"case {i} {r}x{c}")
         np.testing.assert_array_equal(got[1], ref[1], err_msg=f"case {i} ix")
         np.testing.assert_array_equal(got[2], ref[2], err_msg=f"case {i} iy")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_detect_random_models_and_sizes(gpu_required, orc, dtype):
+    """End-to-end sweep: random trees (chains, stars, mixed), mixture counts, image sizes (odd, tiny, wide), gray and
+    colour, both instantiations — candidates, part locations and boxes bit-identical to the oracle."""
+    rng = np.random.default_rng(99)
+    trees = [[-1, 0, 1, 2, 3, 4], [-1, 0, 0, 0, 0, 0, 0], [-1, 0, 1, 1, 0, 4, 4, 2, 7, 7], [-1, 0], [-1, 0, 1, 0, 3, 0, 5, 6, 6]]
+    sizes = [(97, 83, 3), (203, 61, 3), (64, 200, 1), (131, 130, 3), (88, 88, 1)]
+    for i, (par, (w, h, cn)) in enumerate(zip(trees, sizes)):
+        K = int(rng.integers(1, 5))
+        m = make_tree_model(par, K, seed=100 + i)
+        im = make_image(50 + i, w, h, cn=cn)
+        m.thresh = -1e30
+        fr = orc.detect(m, im, capacity=1, keep=True, dtype=dtype)[4]
+        vals = np.concatenate([fr.root(l)[0].ravel() for l in range(fr.nlevels)])
+        fr.free()
+        m.thresh = float(np.float32(np.percentile(vals, 98.5)))
+        ref = orc.detect(m, im, dtype=dtype)[:3]
+        hd = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dtype=dtype)
+        got = hd.detect(im)
+        hd.close()
+        assert len(ref[0]) > 0
+        assert_candidates_equal(got, ref)
