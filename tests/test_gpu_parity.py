@@ -611,3 +611,25 @@ def test_detect_random_models_and_sizes(gpu_required, orc, dtype):
         hd.close()
         assert len(ref[0]) > 0
         assert_candidates_equal(got, ref)
+
+
+def test_hog_resize_pyrdown_random_sizes(gpu_required, orc):
+    """Random image sizes (incl. the smallest the stages accept, odd sizes, single rows of cells), gray and colour,
+    sbin 4 and 8, float and double HOG — bit-exact integer pyramid and HOG."""
+    rng = np.random.default_rng(7)
+    hs = {(sb, dt): capi.Handle(make_tree_model([-1, 0], 1, seed=1, sbin=sb), conv_mode=capi.PBD_CONV_EXACT, dtype=dt)
+          for sb in (4, 8) for dt in (np.float32, np.float64)}
+    sizes = [(3, 3), (4, 9), (13, 12), (12, 40), (41, 12), (25, 25)] + [(int(rng.integers(16, 400)), int(rng.integers(16, 300))) for _ in range(14)]
+    for i, (w, h) in enumerate(sizes):
+        cn = 3 if i % 3 else 1
+        im = make_image(200 + i, w, h, cn=cn)
+        for (sb, dt), hd in hs.items():
+            got, ref = hd.hog(im), orc.hog(im, sb, dtype=dt)
+            assert got.shape == ref.shape, (w, h, sb)
+            np.testing.assert_array_equal(got.view(np.uint8), ref.view(np.uint8), err_msg=f"hog {w}x{h} cn{cn} sbin{sb} {dt}")
+        h32 = hs[(4, np.float32)]
+        ow, oh = max(1, int(w / 1.3)), max(1, int(h / 1.3))
+        np.testing.assert_array_equal(h32.resize(im, ow, oh), orc.resize(im, ow, oh), err_msg=f"resize {w}x{h}")
+        np.testing.assert_array_equal(h32.pyrdown(im), orc.pyrdown(im), err_msg=f"pyrdown {w}x{h}")
+    for hd in hs.values():
+        hd.close()
