@@ -633,3 +633,22 @@ def test_hog_resize_pyrdown_random_sizes(gpu_required, orc):
         np.testing.assert_array_equal(h32.pyrdown(im), orc.pyrdown(im), err_msg=f"pyrdown {w}x{h}")
     for hd in hs.values():
         hd.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-12)])
+def test_pdf_mfma_all_levels_random_sizes(gpu_required, orc, dtype, tol):
+    """MFMA filter bank on every level of several pyramids (level sizes from 1x1 cells up, partial tiles on both
+    edges, rows past the last row skipped, a partial last n-tile: 37 filters) against the oracle's tap-ordered sums."""
+    m = make_tree_model([-1] + [0] * 36, 1, seed=77)          # 37 filters: 2 full 16-filter n-tiles + 5
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA, dtype=dtype)
+    for i, (w, hh) in enumerate([(70, 50), (131, 97), (260, 200), (83, 300)]):
+        h.pyramid(make_image(300 + i, w, hh))
+        g = h._geo
+        h.pdf()
+        for l in range(g["nlevels"]):
+            if g["cell_w"][l] == 0 or g["cell_h"][l] == 0:
+                continue
+            ref = orc.pdf_level(h.level_features(l), m.filtersw, dtype=dtype)
+            for n in (0, 15, 16, 31, 32, 36):
+                assert np.abs(h.level_response(l, n) - ref[n]).max() < tol, (w, hh, l, n)
+    h.close()
