@@ -344,13 +344,17 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         }
         int k = lo;
         int vk = Vl[k];
-        T yk = YZl[k].x, zn = YZl[k + 1].y;
+        T yk = YZl[k].x;
+        // the piece after the current one is kept in registers (its y and z are one LDS word), so stepping to it
+        // costs no LDS round trip on the spot: the read of the piece after THAT overlaps this output's arithmetic
+        P2 nyz = YZl[k + 1];                     // (y[k+1], z[k+1]); z[K+1] = +inf ends the walk, slots up to K+2 exist
+        int nv = Vl[k + 1];
         const int nlines = g.nlines;
         T* dp = (T*)mp.dst + li + (size_t)q0 * nlines;      // running output pointers: no 64-bit multiply per element
         int16_t* ppq = pp + (size_t)q0 * pst;
         for (int q = q0; q < q1; ++q) {
           const T fos = (T)os;                   // `z[k+1] < os`: int promoted to T (:174)
-          while (zn < fos) { k++; zn = YZl[k + 1].y; vk = Vl[k]; yk = YZl[k].x; }
+          while (nyz.y < fos) { k++; vk = nv; yk = nyz.x; nyz = YZl[k + 1]; nv = Vl[k + 1]; }
           const int d = os - vk;
           *dp = (T)(a * (double)__mul24(d, d) + b * (double)d + (double)yk);   // |d| < 2^15
           *ppq = (int16_t)vk;
