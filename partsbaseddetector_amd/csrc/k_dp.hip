@@ -226,7 +226,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   }
   __syncthreads();
   DT_STAMP(1);
-  // coalesced load of the nl lines.  Batches of 16 independent loads are issued before the first
+  // coalesced load of the nl lines.  Batches of LB independent loads are issued before the first
   // wait (addresses are clamped instead of predicated: a predicated load makes hipcc branch and
   // wait per element, which serialises one full memory round trip per 256 B).
   {
@@ -235,17 +235,18 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     // chunk -> (line, chunk of line) by a reciprocal multiply: an integer division per load and per store
     // costs more VALU time than the loads take (c * CH < 2^20 here: c < 64 * CH, CH <= 512)
     const unsigned inv = (1u << 20) / (unsigned)CH + 1u;
-    for (int c0 = 0; c0 < nch; c0 += 16) {
-      T r[16];
+    constexpr int LB = 36;                   // loads in flight per lane (one round trip covers a whole 11-12 line block)
+    for (int c0 = 0; c0 < nch; c0 += LB) {
+      T r[LB];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < LB; ++j) {
         const int c = min(c0 + j, nch - 1);
         const int i = (int)(((unsigned)c * inv) >> 20);
         const int q = min((c - i * CH) * 64 + lane, len - 1);
         r[j] = lptr[i][q];
       }
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < LB; ++j) {
         const int c = c0 + j, cc = min(c, nch - 1);
         const int i = (int)(((unsigned)cc * inv) >> 20);
         const int q = (cc - i * CH) * 64 + lane;
