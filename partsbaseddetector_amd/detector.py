@@ -42,6 +42,17 @@ class Candidate:
     def score(self) -> float:
         return float(self.confidence[0]) if len(self.confidence) else float("-inf")
 
+    def setScore(self, confidence: float) -> None:
+        """Candidate::setScore (:76)."""
+        if len(self.confidence) == 0:
+            self.confidence = np.zeros(1, np.float32)
+        self.confidence[0] = np.float32(confidence)
+
+    def resize(self, factor: float) -> None:
+        """Candidate::resize (:82-89): `int *= float` — float product truncated toward zero, per field."""
+        f = np.float32(factor)
+        self.parts = np.trunc(self.parts.astype(np.float32) * f).astype(self.parts.dtype)
+
     def boundingBox(self):
         x, y, w, h = [int(v) for v in self.parts[0]]
         for q in self.parts:

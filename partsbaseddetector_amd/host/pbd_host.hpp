@@ -88,8 +88,15 @@ class Candidate {
   const vectorf& confidence() const { return confidence_; }
   void addPart(Rect r, float c) { parts_.push_back(r); confidence_.push_back(c); }
   float score() const { return confidence_.empty() ? -std::numeric_limits<float>::infinity() : confidence_[0]; }
+  void setScore(float c) { if (confidence_.empty()) confidence_.resize(1); confidence_[0] = c; }   // :76
   void setComponent(int c) { component_ = c; }
   int component() const { return component_; }
+  void resize(const float factor) {      // :82-89: `int *= float` — converted to float, multiplied, truncated back
+    for (Rect& r : parts_) {
+      r.height = (int)((float)r.height * factor); r.width = (int)((float)r.width * factor);
+      r.y = (int)((float)r.y * factor); r.x = (int)((float)r.x * factor);
+    }
+  }
   Rect boundingBox() const {             // union of the part rects (:103-109)
     Rect h = parts_[0];
     for (const Rect& q : parts_) {

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from partsbaseddetector_amd import capi, parallel
+from partsbaseddetector_amd.detector import Candidate
 from partsbaseddetector_amd.model import make_image, make_person_model, make_tree_model
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -85,6 +86,18 @@ def test_candidate_class_mirrors_reference():
     assert len(kept) == 1 and round(kept[0].score(), 1) == 0.9
 
 
+def test_candidate_resize_and_setscore():
+    """Candidate::resize / setScore (include/Candidate.hpp:76,82-89): integer fields times a float, truncated."""
+    c = Candidate(np.array([[10, -7, 21, 5], [3, 4, 9, 9]], np.int32), np.array([1.5, 0.0], np.float32), 0)
+    c.resize(0.5)
+    np.testing.assert_array_equal(c.parts, [[5, -3, 10, 2], [1, 2, 4, 4]])   # -3.5 -> -3: toward zero
+    c.setScore(2.25)
+    assert c.score() == 2.25
+    e = Candidate(np.zeros((0, 4), np.int32), np.zeros(0, np.float32), 0)
+    e.setScore(-1.0)
+    assert e.score() == -1.0
+
+
 def test_level_and_frame_sharding(orc):
     g = orc.geometry(1920, 1080, 4, 10)
     cells = (g["cell_w"].astype(np.int64) * g["cell_h"]).tolist()
@@ -124,6 +137,7 @@ import numpy as np
 import torch.distributed as dist
 sys.path.insert(0, {root!r})
 from partsbaseddetector_amd import capi, parallel
+from partsbaseddetector_amd.detector import Candidate
 from partsbaseddetector_amd.model import make_image, make_tree_model
 from oracle import orc
 dist.init_process_group("gloo")
