@@ -21,9 +21,14 @@
 #include "pbd_internal.hpp"
 
 // debug: per-phase wall-clock stamps (100 MHz) of one workgroup of the last k_conv_mfma launch
+#ifdef PBD_PROBES
 __device__ unsigned long long pbd_conv_dbg[8];
 #define CONV_STAMP(i) do { if (blockIdx.x == 300 && blockIdx.y == 2 && threadIdx.x == 0) pbd_conv_dbg[i] = wall_clock64(); } while (0)
 void conv_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_conv_dbg), sizeof(unsigned long long) * 8); }
+#else
+#define CONV_STAMP(i) do { } while (0)
+void conv_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i] = 0; }
+#endif
 
 #define CT 16        // spatial tile side (cells)
 #define CSTR 33      // LDS floats per cell (32 + 1 pad: conflict-free across x)
@@ -297,8 +302,8 @@ static void launch_conv_exact_t(const ConvTile* tiles, int ntiles, const LevelDe
     if (kh == 5 && kw == 5) {
       constexpr int GPW = 4;
       const size_t ldsh = sizeof(double) * (CT + 4) * (CT + 4) * CSTRH;
-      static bool cfg64 = false;
-      if (!cfg64) { hipFuncSetAttribute((const void*)k_conv_exact_f64<5, 5, GPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh); cfg64 = true; }
+      static LdsOptIn optin64;
+      optin64.ensure((const void*)k_conv_exact_f64<5, 5, GPW>, ldsh);
       const int groups = (nf + NFG - 1) / NFG;
       dim3 grid(ntiles, (groups + GPW - 1) / GPW);
       hipLaunchKernelGGL((k_conv_exact_f64<5, 5, GPW>), grid, dim3(256), ldsh, s, tiles, levels, feat, wT, resp, nf, nfpad);
@@ -306,14 +311,15 @@ static void launch_conv_exact_t(const ConvTile* tiles, int ntiles, const LevelDe
     }
   }
   if (kh == 5 && kw == 5) {
-    static bool cfg = false;   // one per instantiation
-    if (!cfg) { hipFuncSetAttribute((const void*)k_conv_exact<T, 5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+    static LdsOptIn optin;   // one per instantiation
+    optin.ensure((const void*)k_conv_exact<T, 5, 5>, lds);
     const int groups = (nf + NFG - 1) / NFG;
     const int gpw = 4;
     dim3 grid(ntiles, (groups + gpw - 1) / gpw);
     hipLaunchKernelGGL((k_conv_exact<T, 5, 5>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, gpw);
   } else {
-    hipFuncSetAttribute((const void*)k_conv_exact_generic<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsOptIn opting;
+    opting.ensure((const void*)k_conv_exact_generic<T>, lds);
     dim3 grid(ntiles, nf < 16 ? nf : 16);
     hipLaunchKernelGGL(k_conv_exact_generic<T>, grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, kh, kw);
   }
@@ -436,8 +442,8 @@ void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels,
   if (ntiles <= 0) return;
   if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, 4, nf, nfpad, kh, kw, s); return; }
   const size_t lds = sizeof(float) * (CT + 4) * (CT + 4) * CSTR;
-  static bool cfg = false;
-  if (!cfg) { hipFuncSetAttribute((const void*)k_conv_mfma<5, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+  static LdsOptIn optin;
+  optin.ensure((const void*)k_conv_mfma<5, 5>, lds);
   dim3 grid(ntiles, (nf + 31) / 32);
   hipLaunchKernelGGL((k_conv_mfma<5, 5>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
 }
@@ -588,8 +594,8 @@ template <typename T, int NHALF, int WPE>
 static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
                                  const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
   const size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + 1), sizeof(T) * 4 * 16 * 65);
-  static bool cfg = false;   // one per instantiation
-  if (!cfg) { hipFuncSetAttribute((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+  static LdsOptIn optin;   // one per instantiation
+  optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE>, lds);
   dim3 grid(ntiles, (nf + 15) / 16);
   hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
 }
@@ -599,7 +605,7 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
   if (ntiles <= 0) return;
   if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, 8, nf, nfpad, kh, kw, s); return; }
   // four 8-channel passes (27 KB of LDS per workgroup) measured 7 % faster than two 16-channel halves (54 KB)
-  static const int q = getenv("PBD_MFMA64_QUARTERS") ? atoi(getenv("PBD_MFMA64_QUARTERS")) : 1;   // probe knob
+  static const int q = PBD_PROBE_ENV("PBD_MFMA64_QUARTERS") ? atoi(PBD_PROBE_ENV("PBD_MFMA64_QUARTERS")) : 1;   // probe-build knob
   if (q) launch_conv_mfma16_t<double, 4, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else launch_conv_mfma16_t<double, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
 }

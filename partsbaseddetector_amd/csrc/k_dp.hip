@@ -27,9 +27,14 @@
 #include "pbd_internal.hpp"
 
 // debug: per-phase timestamps (100 MHz wall clock) of block 0 of the last k_dt_pass launch
+#ifdef PBD_PROBES
 __device__ unsigned long long pbd_dt_dbg[8];
 #define DT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pbd_dt_dbg[i] = wall_clock64(); } while (0)
 void dt_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_dt_dbg), sizeof(unsigned long long) * 8); }
+#else
+#define DT_STAMP(i) do { } while (0)
+void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i] = 0; }
+#endif
 
 // LDS per block: 64 line pointers + 64 stack sizes + per line {(Y, Z) : float2[S]; V : u8[S] (S <= 256) or
 // u16[S]} + per map touched by the block a table of exact reciprocals 1/(2a*dx), dx < len (double[S]).
@@ -383,11 +388,8 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
 template <typename T>
 static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,
                              hipStream_t s) {
-  static size_t configured = 0;   // one per instantiation
-  if (lds > configured) {
-    hipFuncSetAttribute((const void*)k_dt_pass<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = lds;
-  }
+  static LdsOptIn optin;   // one per instantiation, per-device state inside
+  optin.ensure((const void*)k_dt_pass<T>, lds);
   hipLaunchKernelGGL(k_dt_pass<T>, dim3(ntasks), dim3(64), lds, s, tasks, groups, maps);
 }
 // ts = sizeof(T): DistanceTransform<float> / DistanceTransform<double>

@@ -328,11 +328,8 @@ __global__ __launch_bounds__(256) void k_dt_wave(const DtTask* __restrict__ task
 
 void launch_dt_wave(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, hipStream_t s) {
   if (ntasks <= 0) return;
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipFuncSetAttribute((const void*)k_dt_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = lds;
-  }
+  static LdsOptIn optin;
+  optin.ensure((const void*)k_dt_wave, lds);
   hipLaunchKernelGGL(k_dt_wave, dim3(ntasks), dim3(256), lds, s, tasks, groups, maps);
 }
 

@@ -20,9 +20,14 @@
 #include "pbd_internal.hpp"
 
 // debug: per-phase wall-clock stamps (100 MHz) of block 0 of the last k_hog launch
+#ifdef PBD_PROBES
 __device__ unsigned long long pbd_hog_dbg[8];
 #define HOG_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pbd_hog_dbg[i] = wall_clock64(); } while (0)
 void hog_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_hog_dbg), sizeof(unsigned long long) * 8); }
+#else
+#define HOG_STAMP(i) do { } while (0)
+void hog_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i] = 0; }
+#endif
 
 struct HogLds {
   int PT;        // pixel window side
@@ -262,11 +267,8 @@ static void launch_hog_t(const HogTile* tiles, int ntiles, const LevelDev* level
                          int cn, int sbin, int tc, hipStream_t s) {
   const size_t lds = hog_lds_bytes(sbin, tc, (int)sizeof(T));
   auto go = [&](auto kern) {
-    static size_t configured = 0;  // one per instantiation
-    if (lds > configured) {
-      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      configured = lds;
-    }
+    static LdsOptIn optin;  // one per instantiation (the lambda is instantiated per kernel), per-device state inside
+    optin.ensure((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(HOG_NT), lds, s, tiles, levels, pyr, feat, cn, sbin, tc);
   };
   if (sbin == 4 && tc == 16) go(k_hog<T, 4, 16>);

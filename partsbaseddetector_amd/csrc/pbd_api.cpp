@@ -27,6 +27,20 @@ static int fail(pbd_handle* h, int code, const std::string& msg) {
   return code;
 }
 
+// Kernel launches return nothing: a launch the runtime rejected (wrong current device, a dynamic-LDS request over
+// the opt-in, a bad grid) would otherwise leave the previous frame's buffers in place and detect() would return
+// stale candidates with PBD_OK.  Checked after every stage.
+#define LAUNCHCHK(h, what)                                                               \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess) {                                                              \
+      (h)->err = std::string(what) + ": kernel launch failed: " + hipGetErrorString(e_); \
+      return PBD_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+// every ABI entry that launches or copies runs on the handle's device, whatever the caller's current device is
+#define ON_DEVICE(h) HIPCHK(h, hipSetDevice((h)->opt.device))
+
 // ---------------------------------------------------------------------------
 // pyramid geometry — HOGFeatures<T>::pyramid, src/HOGFeatures.cpp:98-127,174-175
 // ---------------------------------------------------------------------------
@@ -74,9 +88,16 @@ static int ingest_model(pbd_handle* h, const pbd_model_desc* m) {
   if (m->nfilters <= 0 || m->kh <= 0 || m->kw <= 0 || m->kh > 9 || m->kw > 9 || m->sbin <= 0 || m->interval <= 0 ||
       m->interval > 16 || m->ncomponents <= 0)
     return fail(h, PBD_ERR_ARG, "model: bad sizes");
+  if (m->ndefs < 0 || m->nbias <= 0) return fail(h, PBD_ERR_ARG, "model: ndefs >= 0 and nbias > 0 required");
   const int nc = m->ncomponents;
+  if (m->part_offset[0] != 0) return fail(h, PBD_ERR_ARG, "model: part_offset[0] must be 0");
+  for (int c = 0; c < nc; ++c)
+    if (m->part_offset[c + 1] <= m->part_offset[c]) return fail(h, PBD_ERR_ARG, "model: part_offset must be strictly increasing");
   h->part_offset.assign(m->part_offset, m->part_offset + nc + 1);
   const int np = h->part_offset[nc];
+  if (m->mix_offset[0] != 0) return fail(h, PBD_ERR_ARG, "model: mix_offset[0] must be 0");
+  for (int fp = 0; fp < np; ++fp)
+    if (m->mix_offset[fp + 1] <= m->mix_offset[fp]) return fail(h, PBD_ERR_ARG, "model: mix_offset must be strictly increasing");
   h->parentid.assign(m->parentid, m->parentid + np);
   h->mix_offset.assign(m->mix_offset, m->mix_offset + np + 1);
   const int nm = h->mix_offset[np];
@@ -310,8 +331,8 @@ static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget, int ts) 
   while (lpb > 4 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts) > budget) --lpb;
   // the kernel shares a line between 4 lanes when lpb <= 16 and 2 lanes when lpb <= 32 (dt_envelope_m):
   // just above those thresholds a few lines fewer per block buy twice the lanes per line
-  static const int snap4 = getenv("PBD_DT_SNAP4") ? atoi(getenv("PBD_DT_SNAP4")) : 24;
-  static const int snap2 = getenv("PBD_DT_SNAP2") ? atoi(getenv("PBD_DT_SNAP2")) : 40;
+  static const int snap4 = PBD_PROBE_ENV("PBD_DT_SNAP4") ? atoi(PBD_PROBE_ENV("PBD_DT_SNAP4")) : 24;   // probe-build knobs
+  static const int snap2 = PBD_PROBE_ENV("PBD_DT_SNAP2") ? atoi(PBD_PROBE_ENV("PBD_DT_SNAP2")) : 40;
   if (lpb > 16 && lpb <= snap4) lpb = 16;
   else if (lpb > 32 && lpb <= snap2) lpb = 32;
   return lpb;
@@ -404,7 +425,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   int maxlen = 1;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
   size_t dt_base = 20 * 1024;   // 8 one-wave blocks per CU: measured optimum on MI355X (12..32 KB swept)
-  if (const char* e = getenv("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
   size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 4, 2, h->ts));
   if (dt_budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
   h->dt_lds = dt_budget;
@@ -490,7 +511,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       add_tasks(gx, gxi, xt, xwt);
       add_tasks(gy, gyi, yt, ywt);
     }
-    if (const char* e = getenv("PBD_DEBUG_DUP")) {   // scaling probe: every DT block issued n times (identical outputs)
+    if (const char* e = PBD_PROBE_ENV("PBD_DEBUG_DUP")) {   // scaling probe: every DT block issued n times (identical outputs)
       const int ndup = atoi(e);
       const std::vector<DtTask> x0 = xt, y0 = yt;
       for (int i = 1; i < ndup; ++i) { xt.insert(xt.end(), x0.begin(), x0.end()); yt.insert(yt.end(), y0.begin(), y0.end()); }
@@ -617,12 +638,14 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
     }
     launch_pyrdown(pa, h->d_pyr, h->stream);
   }
+  LAUNCHCHK(h, "image pyramid");
   h->have_pyr = true;
   return PBD_OK;
 }
 
 static int run_hog(pbd_handle* h) {
   launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->stream);
+  LAUNCHCHK(h, "HOG");
   h->have_feat = true;
   return PBD_OK;
 }
@@ -635,7 +658,7 @@ static int run_pdf(pbd_handle* h) {
       // default: 16x16x4 MFMA, tile staged in two channel halves (k_conv_mfma16<float, 2>: 27 KB of LDS per
       // workgroup, so DT blocks of other frames co-reside on the CU); PBD_MFMA_VARIANT=0 selects the older
       // 32x32x2 kernel, 1 the whole-tile variant, 2 the halves at 5 waves/SIMD (A/B knob)
-      static const int variant = getenv("PBD_MFMA_VARIANT") ? atoi(getenv("PBD_MFMA_VARIANT")) : 3;
+      static const int variant = PBD_PROBE_ENV("PBD_MFMA_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_MFMA_VARIANT")) : 3;
       if (variant && m.kh == 5 && m.kw == 5)
         launch_conv_mfma16_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT, (float*)h->d_resp, m.nfilters, h->nfpad, variant, h->stream);
       else
@@ -643,6 +666,7 @@ static int run_pdf(pbd_handle* h) {
     }
   else
     launch_conv_exact(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat, h->d_wT, h->d_resp, h->ts, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
+  LAUNCHCHK(h, "filter bank");
   h->have_resp = true;
   return PBD_OK;
 }
@@ -679,6 +703,7 @@ static int run_dp_min(pbd_handle* h) {
   launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
               h->opt.max_candidates, h->ts, h->stream);
   if (h->dp_timer_on) hipEventRecord(h->ev_dp1, h->stream);
+  LAUNCHCHK(h, "DP min");
   h->have_dp = true;
   return PBD_OK;
 }
@@ -690,6 +715,7 @@ static int run_argmin_enqueue(pbd_handle* h) {
                    h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, h->d_cand_out, h->cand_stride, h->ts, h->d_flat,
                    h->d_depth, h->max_depth, (int)h->parts.size(), h->d_scr_base, h->d_dt_ixT, h->d_dt_iy,
                    h->opt.dt_correct_ptr, h->stream);
+  LAUNCHCHK(h, "argmin");
   HIPCHK(h, hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   const int first = std::min(kFirstCopy, h->opt.max_candidates);
   HIPCHK(h, hipMemcpyAsync(h->h_cand_out, h->d_cand_out, h->cand_stride * first, hipMemcpyDeviceToHost, h->stream));
@@ -868,6 +894,7 @@ int pbd_detect_enqueue_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, i
 
 int pbd_detect_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
   if (!h) return PBD_ERR_ARG;
+  ON_DEVICE(h);
   int rc = collect(h, heads, boxes, locs, capacity, count);
   read_stage_times(h);
   return rc;
@@ -945,6 +972,7 @@ int pbd_get_level_image(pbd_handle* h, int level, uint8_t* out) {
   CHECK_LEVEL(h, level);
   if (!h->have_pyr) return fail(h, PBD_ERR_STATE, "pyramid not computed");
   const Level& L = h->lv[level];
+  ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_pyr + L.img_off, (size_t)L.iw * L.ih * h->fcn, hipMemcpyDeviceToHost));
   return PBD_OK;
@@ -959,6 +987,8 @@ static int get_level_features_(pbd_handle* h, int level, void* out, int ts) {
   CHECK_SCALAR(h, ts);
   if (!h->have_feat) return fail(h, PBD_ERR_STATE, "features not computed");
   const Level& L = h->lv[level];
+  if (!L.active) return fail(h, PBD_ERR_STATE, "level is not processed by this handle (pbd_set_levels / level_begin..level_end)");
+  ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_feat + L.cell_off * PBD_FLEN * ts, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyDeviceToHost));
   return PBD_OK;
@@ -967,6 +997,7 @@ static int set_level_features_(pbd_handle* h, int level, const void* in, int ts)
   CHECK_LEVEL(h, level);
   CHECK_SCALAR(h, ts);
   const Level& L = h->lv[level];
+  ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->d_feat + L.cell_off * PBD_FLEN * ts, in, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyHostToDevice));
   h->have_feat = true;
@@ -979,6 +1010,7 @@ int pbd_set_level_features_f64(pbd_handle* h, int level, const double* in) { ret
 int pbd_pdf(pbd_handle* h) {
   if (!h) return PBD_ERR_ARG;
   if (!h->have_feat) return fail(h, PBD_ERR_STATE, "pdf() before pyramid()");
+  ON_DEVICE(h);
   int rc = run_pdf(h);
   if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -990,7 +1022,9 @@ static int get_level_response_(pbd_handle* h, int level, int filter, void* out, 
   if (!h->have_resp) return fail(h, PBD_ERR_STATE, "responses not computed");
   if (filter < 0 || filter >= h->md.nfilters) return fail(h, PBD_ERR_ARG, "filter out of range");
   const Level& L = h->lv[level];
+  if (!L.active) return fail(h, PBD_ERR_STATE, "level is not processed by this handle (pbd_set_levels / level_begin..level_end)");
   const size_t HW = (size_t)L.cw * L.ch;
+  ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_resp + (L.cell_off * h->md.nfilters + filter * HW) * ts, HW * ts, hipMemcpyDeviceToHost));
   return PBD_OK;
@@ -1001,6 +1035,7 @@ static int set_level_response_(pbd_handle* h, int level, int filter, const void*
   if (filter < 0 || filter >= h->md.nfilters) return fail(h, PBD_ERR_ARG, "filter out of range");
   const Level& L = h->lv[level];
   const size_t HW = (size_t)L.cw * L.ch;
+  ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->d_resp + (L.cell_off * h->md.nfilters + filter * HW) * ts, in, HW * ts, hipMemcpyHostToDevice));
   h->have_resp = true;
@@ -1013,6 +1048,7 @@ int pbd_set_level_response_f64(pbd_handle* h, int level, int filter, const doubl
 int pbd_dp_min(pbd_handle* h) {
   if (!h) return PBD_ERR_ARG;
   if (!h->have_resp) return fail(h, PBD_ERR_STATE, "min() before pdf()");
+  ON_DEVICE(h);
   int rc = run_dp_min(h);
   if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1036,6 +1072,7 @@ int pbd_get_dp_pointers(pbd_handle* h, int level, int component, int part, int p
   std::vector<uint8_t> c(HW);
   std::vector<int16_t> X((size_t)P.K * HW), Y((size_t)P.K * HW);
   const size_t so = (size_t)h->scr_base[(size_t)level * h->parts.size() + (p0 + part)];
+  ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(c.data(), h->d_pk + po, HW, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(X.data(), h->d_dt_ixT + so, X.size() * 2, hipMemcpyDeviceToHost));
@@ -1059,7 +1096,9 @@ static int get_root_(pbd_handle* h, int level, int component, void* rootv, int32
   if (!h->have_dp) return fail(h, PBD_ERR_STATE, "min() not run");
   if (component < 0 || component >= h->md.ncomponents) return fail(h, PBD_ERR_ARG, "component out of range");
   const Level& L = h->lv[level];
+  if (!L.active) return fail(h, PBD_ERR_STATE, "level is not processed by this handle (pbd_set_levels / level_begin..level_end)");
   const size_t HW = (size_t)L.cw * L.ch;
+  ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (rootv) HIPCHK(h, hipMemcpy(rootv, h->d_rootv + (L.cell_off * h->md.ncomponents + component * HW) * ts, HW * ts, hipMemcpyDeviceToHost));
   if (rooti) HIPCHK(h, hipMemcpy(rooti, h->d_rooti + L.cell_off * h->md.ncomponents + component * HW, HW * 4, hipMemcpyDeviceToHost));
@@ -1070,6 +1109,7 @@ int pbd_get_root_f64(pbd_handle* h, int level, int component, double* rootv, int
 int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
   if (!h) return PBD_ERR_ARG;
   if (!h->have_dp) return fail(h, PBD_ERR_STATE, "argmin() before min()");
+  ON_DEVICE(h);
   int rc = run_argmin_enqueue(h);
   if (rc) return rc;
   return collect(h, heads, boxes, locs, capacity, count);
@@ -1091,7 +1131,7 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMemcpyAsync(d_in, in, HW * ts, hipMemcpyHostToDevice, h->stream));
   DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
   size_t dt_base = 40 * 1024;
-  if (const char* e = getenv("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
   const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 4, 1, tsz));
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
   DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz), dt_group(1, 1, cols, rows, budget, tsz)};
@@ -1110,7 +1150,7 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
   if (use_wave_x) launch_dt_wave(d_tasks, nx, d_groups, d_maps, dtw_lds_bytes(cols), h->stream);
   else launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, tsz, h->stream);
-  if (getenv("PBD_DEBUG_SKIP_Y")) {}   // probe: leave the x pass as the last DT launch (its stamps are then readable)
+  if (PBD_PROBE_ENV("PBD_DEBUG_SKIP_Y")) { hipMemsetAsync(d_sdt, 0, HW * ts, h->stream); hipMemsetAsync(d_iy, 0, HW * 2, h->stream); }   // probe build: leave the x pass as the last DT launch (its stamps are then readable)
   else if (use_wave_y) launch_dt_wave(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, dtw_lds_bytes(rows), h->stream);
   else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, tsz, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
@@ -1314,9 +1354,14 @@ int pbd_get_work(const pbd_handle* h, double work[6]) {
   work[5] = C * dtmaps;
   return PBD_OK;
 }
-int pbd_debug_dt_stamps(unsigned long long* out) { dt_debug_read(out); return PBD_OK; }
-int pbd_debug_hog_stamps(unsigned long long* out) { hog_debug_read(out); return PBD_OK; }
-int pbd_debug_conv_stamps(unsigned long long* out) { conv_debug_read(out); return PBD_OK; }
+#ifdef PBD_PROBES
+#define PROBE_RC PBD_OK
+#else
+#define PROBE_RC PBD_ERR_UNSUPPORTED   /* stamps exist only in libpbd_hip_probes.so (make probes) */
+#endif
+int pbd_debug_dt_stamps(unsigned long long* out) { if (!out) return PBD_ERR_ARG; dt_debug_read(out); return PROBE_RC; }
+int pbd_debug_hog_stamps(unsigned long long* out) { if (!out) return PBD_ERR_ARG; hog_debug_read(out); return PROBE_RC; }
+int pbd_debug_conv_stamps(unsigned long long* out) { if (!out) return PBD_ERR_ARG; conv_debug_read(out); return PROBE_RC; }
 int pbd_debug_dtw_stats(unsigned long long* out, int reset) { dtw_stats_read(out, reset); return PBD_OK; }
 
 int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes) {

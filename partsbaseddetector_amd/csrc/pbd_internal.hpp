@@ -197,6 +197,35 @@ __device__ __forceinline__ int t_round(float v) { return __float2int_rn(v); }   
 __device__ __forceinline__ int t_round(double v) { return __double2int_rn(v); }
 #endif
 
+// ---- dynamic-LDS opt-in --------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that drives several
+// GPUs (pbd_group, or handles created with different pbd_options.device) must set it on each of them.  One
+// instance per kernel instantiation; remembers the largest size every device has been given.
+#include <mutex>
+struct LdsOptIn {
+  std::mutex mu;
+  size_t cfg[64] = {};
+  hipError_t ensure(const void* fn, size_t lds) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    std::lock_guard<std::mutex> g(mu);
+    if (lds <= cfg[d] && cfg[d]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) cfg[d] = lds;
+    return e;
+  }
+};
+
+// ---- probes ----------------------------------------------------------------------
+// Per-phase wall-clock stamps and the environment tuning knobs are compiled only into the probe build
+// (make probes -> libpbd_hip_probes.so, -DPBD_PROBES), which tests/tools_*.py load; the product library carries
+// neither (the pbd_debug_* entry points then return PBD_ERR_UNSUPPORTED).
+#ifdef PBD_PROBES
+#define PBD_PROBE_ENV(name) getenv(name)
+#else
+#define PBD_PROBE_ENV(name) ((const char*)nullptr)
+#endif
+
 // ---- kernel launchers (k_*.hip) ----------------------------------------------
 void launch_resize(const ResizeArgs& a, const uint8_t* src, uint8_t* pyr, hipStream_t s);
 void launch_pyrdown(const PyrDownArgs& a, uint8_t* pyr, hipStream_t s);

@@ -652,3 +652,135 @@ def test_pdf_mfma_all_levels_random_sizes(gpu_required, orc, dtype, tol):
             for n in (0, 15, 16, 31, 32, 36):
                 assert np.abs(h.level_response(l, n) - ref[n]).max() < tol, (w, hh, l, n)
     h.close()
+
+
+# ---------------------------------------------------------------- the timed configuration, classified
+def _classified_compare(orc, model, im, hd, got, ref, fr, dtype=np.float32, tol=1e-4):
+    """MFMA filter bank vs the oracle on one frame.  Root scores within `tol`; candidates on one side only sit on the
+    threshold; every common candidate whose part locations differ is CLASSIFIED:
+      * DP-consistent: the oracle's DP (tests/dp_ref.py over orc.dt2d) run on the GPU's own responses back-tracks to
+        exactly the GPU's locations — the distance transform / reduce / back-tracking are bit-exact, so the flip
+        comes from the <= 2e-5 response perturbation alone;
+      * near-tie: at the first diverging part, the two alternatives are within `tie` of each other in the ORACLE's
+        numbers, tie = max(1e-5, 4 * max|resp_gpu - resp_oracle| * parts in the subtree) — each of the subtree's
+        parts can move either alternative by the perturbation.
+    Anything else is a bug.  Returns (common, flips, ties, bugs, worst margin)."""
+    from tests import dp_ref
+    h, w = im.shape[:2]
+    hd._geo = hd.geometry(w, h)
+    key = lambda r, i: (int(r[0][i]["level"]), int(r[0][i]["component"]), int(r[2][i][0][0]), int(r[2][i][0][1]))
+    rk = {key(ref, i): i for i in range(len(ref[0]))}
+    gk = {key(got, i): i for i in range(len(got[0]))}
+    for k in set(rk) ^ set(gk):
+        s = ref[0][rk[k]]["score"] if k in rk else got[0][gk[k]]["score"]
+        assert abs(float(s) - model.thresh) < tol, ("candidate on one side only, not on the threshold", k, float(s))
+    common = sorted(set(rk) & set(gk))
+    flips, ties, bugs, worst = 0, 0, [], 0.0
+    omaps, gmaps, dmax = {}, {}, {}
+    nf = len(model.filtersw)
+    for k in common:
+        i, j = rk[k], gk[k]
+        assert abs(float(ref[0][i]["score"]) - float(got[0][j]["score"])) < tol
+        if np.array_equal(ref[2][i], got[2][j]):
+            np.testing.assert_array_equal(ref[1][i], got[1][j])
+            continue
+        flips += 1
+        l, c = k[0], k[1]
+        if l not in omaps:
+            ro = fr.resp(l)
+            rg = np.stack([hd.level_response(l, n) for n in range(nf)])
+            dmax[l] = float(np.abs(ro.astype(np.float64) - rg).max())
+            omaps[l] = {cc: None for cc in range(model.ncomponents)}
+            gmaps[l] = {cc: None for cc in range(model.ncomponents)}
+            omaps[l]["resp"], gmaps[l]["resp"] = ro, rg
+        if omaps[l][c] is None:
+            omaps[l][c] = dp_ref.level_maps(orc, model, c, omaps[l]["resp"], dtype=dtype)
+            gmaps[l][c] = dp_ref.level_maps(orc, model, c, gmaps[l]["resp"], dtype=dtype)
+        np_ = model.nparts(c)
+        replay = dp_ref.backtrack(model, c, gmaps[l][c], k[2], k[3])
+        consistent = np.array_equal(replay, got[2][j][:np_])
+        p, kind, margin, sub = dp_ref.divergence_margin(model, c, omaps[l][c], ref[2][i][:np_], got[2][j][:np_])
+        tie = max(1e-5, 4.0 * dmax[l] * sub)
+        worst = max(worst, margin)
+        if consistent and margin < tie:
+            ties += 1
+        else:
+            bugs.append((k, p, kind, margin, tie, consistent))
+    return len(common), flips, ties, bugs, worst
+
+
+def test_detect_person_timed_configuration_classified(gpu_required, orc):
+    """The configuration bench.py times (BASELINE configs[1]): 26 parts x 6 mixtures, 640x480, PBD_CONV_AUTO ->
+    k_conv_mfma16<float>, against orc.detect (src/PartsBasedDetector.cpp:69-95) with every mismatch classified."""
+    m = make_person_model()
+    for seed in (0, 3):
+        im = make_image(seed, 640, 480)
+        m.thresh = thresh_from_oracle(orc, m, im, 99.9)
+        rh, rb, rl, _, fr = orc.detect(m, im, keep=True)
+        hd = capi.Handle(m)                                  # PBD_CONV_AUTO, as in bench.py
+        got = hd.detect(im)
+        n, flips, ties, bugs, worst = _classified_compare(orc, m, im, hd, got, (rh, rb, rl), fr)
+        hd.close(); fr.free()
+        print(f"person 26x6 640x480 seed {seed}: {len(rh)} reference candidates, {n} common, {flips} with different part "
+              f"locations ({100.0 * flips / max(n, 1):.2f} %), {ties} near-ties (worst margin {worst:.2e}), {len(bugs)} bugs")
+        assert len(rh) > 50 and n >= 0.95 * len(rh)
+        assert not bugs, bugs
+
+
+@pytest.mark.parametrize("K", [8, 12])
+def test_config5_large_mixture_640x480_vs_oracle(gpu_required, orc, K):
+    """BASELINE configs[4]: large-mixture person model (26 x 8 = 208 and 26 x 12 = 312 filters) at 640x480 against the
+    oracle: the exact filter bank bit for bit, the MFMA filter bank (what PBD_CONV_AUTO selects) classified."""
+    m = make_person_model(K=K)
+    im = make_image(1, 640, 480)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.9)
+    rh, rb, rl, _, fr = orc.detect(m, im, keep=True)
+    assert len(rh) > 50
+    he = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    assert_candidates_equal(he.detect(im), (rh, rb, rl))
+    he.close()
+    hm = capi.Handle(m)                                      # AUTO -> MFMA for N x K this size
+    got = hm.detect(im)
+    n, flips, ties, bugs, worst = _classified_compare(orc, m, im, hm, got, (rh, rb, rl), fr)
+    hm.close(); fr.free()
+    print(f"person 26x{K} ({26 * K} filters) 640x480: {len(rh)} reference candidates, {n} common, {flips} flips, {ties} near-ties "
+          f"(worst margin {worst:.2e}), {len(bugs)} bugs")
+    assert n >= 0.95 * len(rh) and not bugs, bugs
+
+
+def test_person_1080p_levels_vs_oracle(gpu_required, orc):
+    """BASELINE configs[3] geometry (1920x1080, 58 levels, DT lines of 478 / 268 elements): candidates of a level set
+    that includes level 0 (pbd_set_levels, the level-sharded multi-GPU path) equal the oracle's candidates of
+    those levels bit for bit (exact filter bank), with a real threshold."""
+    m = make_person_model(K=2)                               # 52 filters: keeps the CPU oracle at a few seconds
+    im = make_image(0, 1920, 1080)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.97)
+    rh, rb, rl = orc.detect(m, im, capacity=32768)[:3]
+    levels = [0, 7, 13, 30, 57]
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, max_candidates=32768)
+    g = h.geometry(1920, 1080)
+    assert g["nlevels"] == 58 and g["cell_w"][0] == 478 and g["cell_h"][0] == 268
+    h.set_levels(levels)
+    got = h.detect(im, capacity=32768)
+    h.close()
+    sel = np.isin(rh["level"], levels)
+    assert sel.sum() > 30 and (rh["level"][sel] == 0).sum() > 10
+    assert_candidates_equal(got, (rh[sel], rb[sel], rl[sel]))
+
+
+def test_person_1080p_full_mfma_scores(gpu_required, orc):
+    """Same geometry, full 26 x 6 model, every level, default (MFMA) filter bank: the root score maps of levels 0 and
+    20 are within 1e-4 of the oracle's everywhere (DT / DP on 478-element lines against the oracle, end to end)."""
+    m = make_person_model()
+    m.thresh = 3.0e38
+    im = make_image(0, 1920, 1080)
+    fr = orc.detect(m, im, capacity=1, keep=True)[4]
+    h = capi.Handle(m, max_candidates=32768)
+    heads, _, _ = h.detect(im)
+    assert len(heads) == 0
+    h._geo = h.geometry(1920, 1080)
+    for l in (0, 20, 57):
+        rv, _ = h.root(l, 0)
+        ov, _ = fr.root(l)
+        assert np.abs(rv - ov[0]).max() < 1e-4, l
+    h.close(); fr.free()

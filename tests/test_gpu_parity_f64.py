@@ -296,3 +296,21 @@ def test_dt2d_f64_random_sweep_all_lane_sharing_modes(h64, orc):
         ref = orc.dt2d(a, ax, bx, ay, by, osx, osy, dtype=F64)
         np.testing.assert_array_equal(_bits(got[0]), _bits(ref[0]), err_msg=f"case {i} {r}x{c}")
         np.testing.assert_array_equal(got[1], ref[1]); np.testing.assert_array_equal(got[2], ref[2])
+
+
+def test_detect_f64_mfma_person_K6_matches_oracle(gpu_required, orc):
+    """Full 26 x 6 person model at 640x480 on the double instantiation with the fp64 MFMA filter bank (what
+    PBD_CONV_AUTO selects): candidates, part locations and boxes against orc.detect<double>; differences classified
+    like the float case (tests/test_gpu_parity.py::_classified_compare) — with |delta resp| ~1e-13 flips need an
+    (essentially exact) tie."""
+    from tests.test_gpu_parity import _classified_compare
+    m = make_person_model()
+    im = make_image(0, 640, 480)
+    m.thresh = _thresh64(orc, m, im, 99.9)
+    rh, rb, rl, _, fr = orc.detect(m, im, keep=True, dtype=F64)
+    hd = capi.Handle(m, dtype=F64)
+    got = hd.detect(im)
+    n, flips, ties, bugs, worst = _classified_compare(orc, m, im, hd, got, (rh, rb, rl), fr, dtype=F64, tol=1e-6)
+    hd.close(); fr.free()
+    print(f"person 26x6 640x480 double: {len(rh)} reference candidates, {n} common, {flips} flips, {len(bugs)} bugs")
+    assert len(rh) > 50 and n >= len(rh) - 2 and not bugs, bugs

@@ -293,3 +293,34 @@ def test_f64_and_f32_instantiations_track_each_other(orc):
     for l in (0, f32.nlevels - 1):
         assert np.abs(f64.root(l)[0] - f32.root(l)[0]).max() < 1e-4
     f32.free(); f64.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_dp_ref_matches_oracle(orc, dtype):
+    """tests/dp_ref.py (numpy message passing over orc.dt2d, used to classify MFMA location flips) reproduces the
+    oracle's DP bit for bit: root scores / mixtures, and the back-tracked part locations of detect()."""
+    from tests import dp_ref
+    from tests.util import thresh_from_oracle
+    for m, (w, h) in ((make_tree_model([-1, 0, 1, 1, 0, 4, 4, 2], 3, seed=9), (120, 90)),
+                      (make_tree_model([-1, 0, 0, 1], 1, seed=10), (90, 70))):
+        im = make_image(6, w, h)
+        m.thresh = thresh_from_oracle(orc, m, im, 99.0) if dtype == np.float32 else -1e30
+        if dtype == np.float64:
+            fr = orc.detect(m, im, capacity=1, keep=True, dtype=dtype)[4]
+            vals = np.concatenate([fr.root(l)[0].ravel() for l in range(fr.nlevels)])
+            fr.free()
+            m.thresh = float(np.float32(np.percentile(vals, 99.0)))
+        heads, boxes, locs, _, fr = orc.detect(m, im, keep=True, dtype=dtype)
+        assert len(heads) > 3
+        cache = {}
+        for hd, lc in zip(heads, locs):
+            l = int(hd["level"])
+            if l not in cache:
+                cache[l] = dp_ref.level_maps(orc, m, 0, fr.resp(l), dtype=dtype)
+                rv, ri = fr.root(l)
+                np.testing.assert_array_equal(cache[l]["rootv"].view(np.uint8), rv[0].view(np.uint8))
+                np.testing.assert_array_equal(cache[l]["rooti"], ri[0])
+            got = dp_ref.backtrack(m, 0, cache[l], int(lc[0][0]), int(lc[0][1]))
+            np.testing.assert_array_equal(got, lc[: m.nparts(0)])
+            assert dp_ref.divergence_margin(m, 0, cache[l], lc, lc) is None
+        fr.free()
