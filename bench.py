@@ -4,12 +4,23 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one PartsBasedDetector::detect() pass per GPU over one 640x480 synthetic frame that is
-already resident in HBM (full pyramid: 46 levels; HOG -> filter bank -> DP min -> argmin; the
-candidates are copied back to the host every step).  Frames are independent, so ranks shard frames
-with no data-path collective ("weak" scaling: one frame per rank per step); the only collective is
-the RCCL all_gather of the fixed-capacity candidate buffers after the timed loop has produced them
-(SURVEY §8e).  Prints ONE JSON line on rank 0.
+One "step" = one PartsBasedDetector::detect() pass per GPU over one 640x480 synthetic frame (full pyramid: 46
+levels; HOG -> filter bank -> DP min -> argmin; the candidates are copied back to the host every step).
+
+Protocol:
+  * setup (untimed, independent of --warmup): every handle and the clocks are pre-warmed for a fixed wall time;
+  * W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides, max over ranks;
+  * `value` = frames/s with the input frames ALREADY RESIDENT IN HBM when the timed region starts (the contract
+    of this tier); the same K steps are then repeated handing over PINNED HOST images, so that every step
+    contains its H2D copy (pbd_detect_enqueue_u8): reported beside it as `value_incl_h2d`;
+  * per-frame wall time of the timed loop (completion-to-completion): median / p10 / p90;
+  * a strictly sequential leg (one frame in flight, pbd_detect_u8-equivalent: H2D + kernels + D2H per call) gives
+    the latency figures and the per-stage GPU times behind `roofline` (HIP events on the handle's stream);
+  * `cpu_baseline`: the oracle (reference-structured OpenMP restatement) on the box's host cores — 2 warm-ups +
+    median of 5 frames on all cores, and a one-thread leg on a bounded sample.
+Frames are independent, so ranks shard frames with no data-path collective ("weak" scaling: one frame per rank
+per step); the only collective is the RCCL all_gather of the candidate buffers.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -26,6 +37,8 @@ sys.path.insert(0, ROOT)
 # 4 queues 727 frames/s, 8 queues 865 (3 in flight: 825 / 832).  Must be set before the HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+PREWARM_S = 1.5       # fixed wall time every rank spends running frames before --warmup / the timed region
+
 
 def pick_threshold(capi, model, d_img, w, h, q=99.9, dtype=np.float32):
     """99.9-th percentile of the root scores of the seed frame, computed with the
@@ -37,6 +50,31 @@ def pick_threshold(capi, model, d_img, w, h, q=99.9, dtype=np.float32):
     vals = np.concatenate([hd.root(l, 0)[0].ravel() for l in range(hd._geo["nlevels"])])
     hd.close()
     return float(np.float32(np.percentile(vals, q)))
+
+
+def pct(a, q):
+    return round(float(np.percentile(np.asarray(a, np.float64), q)), 4)
+
+
+def cpu_info():
+    """(model string, physical cores, hardware threads) of the host."""
+    model, cores, phys, core = "unknown", set(), None, None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                cores.add((phys, core)); phys = core = None
+    except OSError:
+        pass
+    nthreads = os.cpu_count() or 1
+    return model, (len(cores) or nthreads), nthreads
 
 
 def main():
@@ -53,12 +91,13 @@ def main():
     ap.add_argument("--mixtures", type=int, default=6)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
                     help="instantiation: f32 = PartsBasedDetector<float> (BASELINE.json metric), f64 = <double> "
-                         "(SURVEY 8f-3: the ROS node / ecto cell instantiation; exact VALU filter bank)")
+                         "(SURVEY 8f-3: the ROS node / ecto cell instantiation)")
     ap.add_argument("--shard", choices=["frames", "levels"], default="frames",
                     help="N>1: 'frames' = every rank its own frames (weak scaling, the BASELINE metric); 'levels' = all "
                          "ranks work on the SAME frames, each on an LPT-balanced set of pyramid levels (strong scaling, "
                          "BASELINE configs[3]: use with --width 1920 --height 1080)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU-side smoke runs)")
     args = ap.parse_args()
 
@@ -87,18 +126,18 @@ def main():
     model = make_person_model(K=args.mixtures)
     conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA}[args.conv]
     dtype = np.float64 if args.dtype == "f64" else np.float32
-    # distinct frames per rank and per step slot (32 seeds as in configs[2]); resident in HBM
+    # distinct frames per rank and per step slot (32 seeds as in configs[2]); resident in HBM and, for the
+    # H2D-inclusive leg, in pinned host memory
     nimg = 8
     by_levels = args.shard == "levels" and world > 1
-    frames = [torch.from_numpy(make_image((0 if by_levels else rank * nimg) + i, W, H)).to(dev) for i in range(nimg)]
+    host_frames = [torch.from_numpy(make_image((0 if by_levels else rank * nimg) + i, W, H)).pin_memory() for i in range(nimg)]
+    frames = [t.to(dev) for t in host_frames]
     torch.cuda.synchronize()
     model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).to(dev), W, H, dtype=dtype)
 
     S = max(1, args.inflight)
     cap = 4096 if W * H <= 640 * 480 else 32768      # the 99.9th-percentile threshold scales the count with the area
     handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=cap, dtype=dtype) for _ in range(S)]
-    for hd in handles:
-        hd.set_profiling(True)
     if by_levels:   # SURVEY 8e / configs[3]: one frame, levels spread over the ranks by greedy LPT on the cell counts
         from partsbaseddetector_amd.parallel import shard_levels_lpt
         g = handles[0].geometry(W, H)
@@ -106,70 +145,103 @@ def main():
         for hd in handles:
             hd.set_levels(my_levels)
 
-    def run(nsteps, collect_out=None):
+    def run(nsteps, collect_out=None, stamps=None, host=False):
+        """S frames in flight; host=True hands over pinned host images (H2D inside every step)."""
         pending = []
         for i in range(nsteps):
             hd = handles[i % S]
             if len(pending) == S:
                 out = pending.pop(0).collect(cap)
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
                 if collect_out is not None:
                     collect_out.append(out)
-            hd.enqueue_dev(frames[i % nimg].data_ptr(), W, H, 3)
+            if host:
+                hd.enqueue_host_ptr(host_frames[i % nimg].data_ptr(), W, H, 3)
+            else:
+                hd.enqueue_dev(frames[i % nimg].data_ptr(), W, H, 3)
             pending.append(hd)
         for hd in pending:
             out = hd.collect(cap)
+            if stamps is not None:
+                stamps.append(time.perf_counter())
             if collect_out is not None:
                 collect_out.append(out)
 
+    def timed(nsteps, host):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs, stamps = [], [t0]
+        run(nsteps, outs, stamps, host=host)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64)
+            if cdev is not None:
+                tmax = tmax.to(cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, outs, np.diff(np.asarray(stamps)) * 1e3
+
+    # ---- setup: pre-warm every handle (plan, LDS opt-ins, pinned buffers) and the clocks for a fixed wall time ----
+    prewarm_frames = 0
+    if not args.no_prewarm:
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < PREWARM_S or prewarm_frames < 4 * S:
+            run(2 * S, host=(prewarm_frames // (2 * S)) % 2 == 1)
+            prewarm_frames += 2 * S
     run(args.warmup)
     for hd in handles:
         hd.dp_timer(reset=True)
-    torch.cuda.synchronize()
+
+    # ---- the timed region: exactly K steps, frames resident in HBM ----
+    dt, outs, per_frame_ms = timed(args.steps, host=False)
+    # ---- the same K steps handing over pinned host images: H2D inside every step ----
+    dt_h2d, outs_h2d, per_frame_ms_h2d = timed(args.steps, host=True)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = []
-    run(args.steps, outs)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64)
-        if cdev is not None:
-            tmax = tmax.to(cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
         # the one collective of the path: candidates of the last frame of every rank -> rank 0
-        gathered = gather_candidates(outs[-1], handles[0].max_parts, capacity=1024, device=cdev)
+        gathered = gather_candidates(outs[-1], handles[0].max_parts, capacity=cap, device=cdev)
         ncand_all = sum(len(g[0]) for g in gathered)
     else:
         ncand_all = len(outs[-1][0])
 
-    # per-launch durations for the roofline: frames overlap when inflight > 1, which stretches every
-    # kernel's span, so a short SEQUENTIAL leg (one frame in flight on one handle) is timed after the
-    # throughput loop, with the same HIP events on the handle's stream.
+    # ---- sequential leg: one frame in flight on one handle, host image in, candidates out (pbd_detect_u8 semantics) ----
     hd = handles[0]
+    hd.set_profiling(True)
     hd.dp_timer(reset=True)
-    nseq = 20
-    stage_acc = {}
-    for i in range(nseq):
-        hd.detect_dev(frames[i % nimg].data_ptr(), W, H, 3, capacity=cap)
+    nseq = 30
+    stage_acc, seq_ms = {}, []
+    for i in range(nseq + 3):
+        t1 = time.perf_counter()
+        hd.enqueue_host_ptr(host_frames[i % nimg].data_ptr(), W, H, 3)
+        hd.collect(cap)
+        t2 = time.perf_counter()
+        if i < 3:
+            hd.dp_timer(reset=True)
+            continue
+        seq_ms.append((t2 - t1) * 1e3)
         for k, v in hd.stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v / nseq
     dp_ms_seq = hd.dp_timer()[0]
+    hd.set_profiling(False)
 
     if rank == 0:
         work = hd.work()
         stage = stage_acc
         dp_ms = dp_ms_seq
+        per_rank = 1 if by_levels else world
         ms_per_step = dt / args.steps * 1e3
-        value = args.steps * (1 if by_levels else world) / dt
-        # roofline of the stage the north_star prices: the DP/distance-transform pass (HBM-bound).
+        value = args.steps * per_rank / dt
+        value_h2d = args.steps * per_rank / dt_h2d
+        # roofline of the stage the north_star prices: the DP/distance-transform pass (HBM-bound by bytes).
         # achieved = algorithmic bytes of one frame's pass (SURVEY §8d: B_dp) / its GPU time measured
-        # with HIP events on the handle's stream.
+        # with HIP events on the handle's stream in the sequential leg.
         dp_gbs = work["B_dp"] / (dp_ms * 1e-3) / 1e9
         pdf_tf = work["F_pdf"] / (stage["pdf"] * 1e-3) / 1e12 if stage["pdf"] > 0 else 0.0
         traffic = None
@@ -177,7 +249,7 @@ def main():
         if os.path.exists(tpath) and (W, H, args.mixtures, args.dtype) == (640, 480, 6, "f32"):
             traffic = json.load(open(tpath))["hbm_bytes_per_frame_corrected"]
         if stage["dp_min"] >= stage["pdf"]:
-            roof = {"kernel": "dp_min stage = 18 x k_dt_pass + 9 x k_reduce + k_root per frame", "bound": "hbm",
+            roof = {"kernel": "dp_min stage (distance-transform passes + mixture reduce + root) per frame", "bound": "hbm",
                     "achieved": round(dp_gbs, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(dp_gbs / 8000.0, 5),
                     "traffic": traffic, "launch_ms": round(float(dp_ms), 4), "algorithmic_bytes": work["B_dp"],
                     "timing": f"HIP events around the stage, mean of {nseq} sequential frames after the timed loop"}
@@ -196,8 +268,18 @@ def main():
             "config": {"workload": f"person 26 parts x {args.mixtures} mixtures ({len(model.filtersw)} 5x5x32 filters), "
                                    f"{W}x{H} BGR, full pyramid ({hd.geometry(W, H)['nlevels']} levels), "
                                    f"threshold = 99.9th pct of root scores",
-                       "frames_per_step_per_gpu": 1, "inflight": S, "conv": args.conv,
+                       "frames_per_step_per_gpu": 1, "inflight": S, "conv": args.conv, "input": "frames resident in HBM",
+                       "prewarm_s": 0.0 if args.no_prewarm else PREWARM_S, "prewarm_frames": prewarm_frames,
                        "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}")},
+            "frame_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),
+                         "what": "completion-to-completion wall time per frame in the timed loop (rank 0)"},
+            "value_incl_h2d": round(value_h2d, 3),
+            "incl_h2d": {"value": round(value_h2d, 3), "unit": "frames/s", "ms_per_step": round(dt_h2d / args.steps * 1e3, 4),
+                         "frame_ms": {"median": pct(per_frame_ms_h2d, 50), "p10": pct(per_frame_ms_h2d, 10), "p90": pct(per_frame_ms_h2d, 90)},
+                         "what": "the same K steps with every frame handed over as a pinned host image (pbd_detect_enqueue_u8: "
+                                 "H2D + kernels + D2H of the candidates per step)"},
+            "sequential": {"latency_ms": {"median": pct(seq_ms, 50), "p10": pct(seq_ms, 10), "p90": pct(seq_ms, 90)},
+                           "frames": nseq, "what": "one frame in flight: host image in, candidates out, wall time per call"},
             "roofline": roof,
             "roofline_dt": {"bound": "hbm", "achieved": round(dp_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(dp_gbs / 8000.0, 5), "ms": round(float(dp_ms), 4)},
@@ -206,16 +288,33 @@ def main():
             "stage_ms_sequential": {k: round(v, 4) for k, v in stage.items()},
         }
         if not args.no_cpu_baseline:
-            # bounded CPU sample: the oracle (reference-structured OpenMP restatement) on ONE frame
+            # bounded CPU sample: the oracle (reference-structured OpenMP restatement), same model and image size.
             from oracle import orc
-            im = make_image(0, W, H)
+            ims = [make_image(i, W, H) for i in range(3)]
+            cpu_name, ncores, nhw = cpu_info()
+            orc.set_num_threads(ncores)                # one thread per physical core (SMT siblings only slow it down)
+            times, stage_ms = [], None
+            for i in range(2 + 5):                     # 2 warm-ups + 5 timed frames, median
+                t = time.perf_counter()
+                _, _, _, ms = orc.detect(model, ims[i % 3], dtype=dtype)[:4]
+                if i >= 2:
+                    times.append(time.perf_counter() - t)
+                    stage_ms = ms
+            med = float(np.median(times))
+            # one-thread leg (OMP_NUM_THREADS=1 equivalent) on a bounded sample: ONE frame, same model and size
+            orc.set_num_threads(1)
             t = time.perf_counter()
-            _, _, _, ms = orc.detect(model, im, dtype=dtype)[:4]
-            cdt = time.perf_counter() - t
-            line["cpu_baseline"] = {"value": round(1.0 / cdt, 4), "unit": "frames/s", "cores": orc.num_threads(),
-                                    "kind": "port", "sample": "1 frame 640x480, same model, oracle/pbd_oracle.c "
-                                    "(OpenMP at the reference's five loops)",
-                                    "stage_ms": [round(x, 1) for x in ms]}
+            orc.detect(model, ims[0], dtype=dtype)
+            t1 = time.perf_counter() - t
+            orc.set_num_threads(ncores)
+            line["cpu_baseline"] = {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": ncores, "threads": ncores,
+                                    "hw_threads": nhw, "kind": "port", "cpu": cpu_name,
+                                    "sample": f"median of 5 frames {W}x{H} after 2 warm-ups, same model, oracle/pbd_oracle.c "
+                                              f"(OpenMP at the reference's five loops), one thread on each of the {ncores} physical cores",
+                                    "frame_s": {"median": round(med, 4), "min": round(min(times), 4), "max": round(max(times), 4)},
+                                    "stage_ms": [round(x, 1) for x in stage_ms],
+                                    "single_thread": {"value": round(1.0 / t1, 4), "unit": "frames/s", "threads": 1,
+                                                      "sample": f"1 frame {W}x{H}, same model (OMP_NUM_THREADS=1 equivalent)"}}
         print(json.dumps(line), flush=True)
     for hd in handles:
         hd.close()

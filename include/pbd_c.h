@@ -36,7 +36,8 @@ enum {
   PBD_ERR_UNSUPPORTED = 2, /* CV_StsUnsupportedFormat, src/HOGFeatures.cpp:141 */
   PBD_ERR_CAPACITY = 3,    /* output array too small; *count = needed          */
   PBD_ERR_HIP = 4,         /* HIP runtime failure (see pbd_last_error)         */
-  PBD_ERR_STATE = 5        /* stage called before its producer stage           */
+  PBD_ERR_STATE = 5,       /* stage called before its producer stage           */
+  PBD_ERR_RCCL = 6         /* RCCL failure in a pbd_group gather (see pbd_group_last_error) */
 };
 
 /* ---- model: POD mirror of include/Model.hpp:49-122 ------------------------
@@ -147,6 +148,12 @@ int pbd_set_stream(pbd_handle* h, void* hip_stream);
 int pbd_detect_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride,
                   pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
                   int capacity, int* count);
+/* Input depth.  The reference dispatches features<uint8_t|uint16_t|float|double> on im.depth()
+ * (src/HOGFeatures.cpp:136-146); its three callers (src/demo.cpp:90, ros/Node.cpp:183,
+ * cells/detect.cpp:224) all pass CV_8U BGR.  This library takes 8-bit images only, BY DESIGN: for the other
+ * depths cv::resize / cv::pyrDown use different (float / wider fixed-point) arithmetic that no reference
+ * test or fixture pins, so a restatement could not be checked against anything; pass 16U/32F/64F images
+ * through convertTo(CV_8U) first, or expect PBD_ERR_UNSUPPORTED from the adaptors in INTEGRATION.md.       */
 /* same, image already resident in device memory (tightly packed or strided)  */
 int pbd_detect_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, int cn, int stride,
                       pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
@@ -157,6 +164,43 @@ int pbd_detect_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, int cn, i
 int pbd_detect_enqueue_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, int cn, int stride);
 int pbd_detect_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
                        int capacity, int* count);
+/* asynchronous pbd_detect_u8: the H2D copy of the host image is enqueued on the handle's stream in
+ * front of the kernels (truly asynchronous when `im` is pinned: hipHostMalloc / hipHostRegister; a pageable
+ * image is staged by the runtime).  `im` must stay valid until pbd_detect_collect returns.               */
+int pbd_detect_enqueue_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride);
+
+/* ---- one process, several GPUs (SURVEY 8b "Threading", 8e) ------------------
+ * The reference's hosts are single processes (src/demo.cpp:85-103, ros/Node.cpp:183, cells/detect.cpp:224).
+ * A pbd_group owns one handle per listed device (a device may be listed more than once: several frames in
+ * flight on it) and drives them from the calling thread; frames and pyramid levels never interact
+ * (src/DynamicProgram.cpp:83-87), so there is no data-path collective, only the gather of the members'
+ * candidate buffers:
+ *   PBD_GATHER_RCCL  ncclAllGather over the members' devices (RCCL over xGMI; librccl is loaded at run time) of a
+ *                    fixed-size block {count, first records}, then ONE D2H on member 0; members holding more
+ *                    records than the block hand the remainder over directly;
+ *   PBD_GATHER_HOST  one small D2H per member + concatenation on the host (same result; used when librccl is
+ *                    missing or a device is listed twice — RCCL wants distinct devices);
+ *   PBD_GATHER_AUTO  RCCL when possible, else host.
+ * Results are identical to running the frames one after the other on a single handle.                      */
+enum { PBD_GATHER_AUTO = 0, PBD_GATHER_HOST = 1, PBD_GATHER_RCCL = 2 };
+typedef struct pbd_group pbd_group;
+/* opt->device is ignored (devices[] decides); every other option applies to all members                     */
+int pbd_group_create(const pbd_model_desc* model, const pbd_options* opt, const int32_t* devices, int ndevices,
+                     int gather_mode, pbd_group** out);
+int pbd_group_destroy(pbd_group* g);
+const char* pbd_group_last_error(const pbd_group* g);
+int pbd_group_size(const pbd_group* g);
+int pbd_group_gather_mode(const pbd_group* g);          /* PBD_GATHER_HOST or PBD_GATHER_RCCL actually in use   */
+pbd_handle* pbd_group_member(pbd_group* g, int i);     /* borrowed: stage entry points, pbd_get_stage_ms, ...   */
+/* BASELINE configs[2]: a batch of same-sized frames, frame f on member f % size, all members busy at once.
+ * Frame f's candidates land at heads[f*capacity], boxes[f*capacity*max_parts*4], locs[f*capacity*max_parts*3]
+ * (boxes / locs may be NULL), counts[f] = number found; PBD_ERR_CAPACITY if any frame exceeds `capacity`.   */
+int pbd_group_detect_batch_u8(pbd_group* g, const uint8_t* const* ims, int nframes, int w, int hgt, int cn, int stride,
+                              pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* counts);
+/* BASELINE configs[3]: ONE frame, its pyramid levels spread over the members by greedy LPT on the cell counts
+ * (every member rebuilds the cheap image pyramid); output in the order a single handle produces.            */
+int pbd_group_detect_u8(pbd_group* g, const uint8_t* im, int w, int hgt, int cn, int stride,
+                        pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count);
 
 /* ---- stage entry points (parity testing; same kernels as detect) ----------
  * IFeatures::nscales/scales (include/IFeatures.hpp:54-63) + pyramid geometry
@@ -234,7 +278,11 @@ int pbd_get_work(const pbd_handle* h, double work[6]);
 /* average GPU ms of the DP-min kernels alone over frames since the last reset
  * (HIP events on the handle's stream around the DP stage)                    */
 int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes);
-/* debug: 100 MHz wall-clock stamps of block 0 of the last distance-transform launch at its six
+/* The pbd_debug_* entry points below report something only in the probe build of the library
+ * (make -C partsbaseddetector_amd/csrc probes -> libpbd_hip_probes.so, -DPBD_PROBES: per-phase stamps inside
+ * the kernels + environment tuning knobs); the product library compiles neither and returns
+ * PBD_ERR_UNSUPPORTED.
+ * debug: 100 MHz wall-clock stamps of block 0 of the last distance-transform launch at its six
  * phase boundaries (setup, line load, envelope scan, read-out, pointer store, end)            */
 int pbd_debug_dt_stamps(unsigned long long out[8]);
 /* same for the HOG kernel: tile staging, gradient, histogram, energy+normalisers, features */

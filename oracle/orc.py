@@ -241,3 +241,8 @@ def nms_map(src, sz):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n: int):
+    """omp_set_num_threads for the timed CPU baseline legs (all cores / one thread)."""
+    lib().orc_set_num_threads(int(n))

@@ -374,3 +374,12 @@ ORC_API int orc_num_threads(void) {
   return 1;
 #endif
 }
+
+/* bench.py's cpu_baseline legs: all host cores, and one thread (OMP_NUM_THREADS=1 equivalent) */
+ORC_API void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

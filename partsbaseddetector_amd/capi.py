@@ -14,9 +14,12 @@ import numpy as np
 from .model import pbd_model_desc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpbd_hip.so")
+# PBD_LIBRARY: load another build of the same ABI (tests/tools_*.py point it at libpbd_hip_probes.so, the
+# `make probes` build with per-phase stamps and environment tuning knobs compiled in)
+LIB_PATH = os.environ.get("PBD_LIBRARY") or os.path.join(_HERE, "libpbd_hip.so")
 
-PBD_OK, PBD_ERR_ARG, PBD_ERR_UNSUPPORTED, PBD_ERR_CAPACITY, PBD_ERR_HIP, PBD_ERR_STATE = range(6)
+PBD_OK, PBD_ERR_ARG, PBD_ERR_UNSUPPORTED, PBD_ERR_CAPACITY, PBD_ERR_HIP, PBD_ERR_STATE, PBD_ERR_RCCL = range(7)
+PBD_GATHER_AUTO, PBD_GATHER_HOST, PBD_GATHER_RCCL = 0, 1, 2
 PBD_CONV_AUTO, PBD_CONV_EXACT, PBD_CONV_MFMA = 0, 1, 2
 PBD_SCALAR_F32, PBD_SCALAR_F64 = 0, 1
 
@@ -30,6 +33,8 @@ EXPORTS = [
     "pbd_set_levels", "pbd_get_level_features_f64", "pbd_set_level_features_f64", "pbd_get_level_response_f64",
     "pbd_set_level_response_f64", "pbd_get_root_f64", "pbd_dt2d_f64", "pbd_hog_u8_f64",
     "pbd_candidates_sort", "pbd_candidates_nms", "pbd_get_stage_ms", "pbd_set_profiling",
+    "pbd_detect_enqueue_u8", "pbd_group_create", "pbd_group_destroy", "pbd_group_last_error", "pbd_group_size",
+    "pbd_group_gather_mode", "pbd_group_member", "pbd_group_detect_batch_u8", "pbd_group_detect_u8",
     "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps", "pbd_debug_dtw_stats",
 ]
 
@@ -65,6 +70,10 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
         L.pbd_last_error.restype = C.c_char_p
         L.pbd_last_error.argtypes = [C.c_void_p]
+        L.pbd_group_last_error.restype = C.c_char_p
+        L.pbd_group_last_error.argtypes = [C.c_void_p]
+        L.pbd_group_member.restype = C.c_void_p
+        L.pbd_group_member.argtypes = [C.c_void_p, C.c_int]
         for name in EXPORTS:
             getattr(L, name)  # every declared symbol must be exported
         _lib = L
@@ -151,6 +160,19 @@ class Handle:
 
     def enqueue_dev(self, dptr: int, w, hgt, cn, stride=None):
         self._chk(self.L.pbd_detect_enqueue_dev_u8(self.h, C.c_void_p(dptr), w, hgt, cn, stride or w * cn))
+
+    def enqueue(self, im: np.ndarray):
+        """pbd_detect_enqueue_u8: asynchronous H2D of a host image (pinned for true asynchrony) + all kernels.
+        The array must stay alive until collect()."""
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        assert im.dtype == np.uint8 and im.flags["C_CONTIGUOUS"]
+        self._inflight_im = im
+        self._chk(self.L.pbd_detect_enqueue_u8(self.h, C.c_void_p(im.ctypes.data), w, hgt, cn, w * cn))
+
+    def enqueue_host_ptr(self, ptr: int, w, hgt, cn, stride=None):
+        """same from a raw host pointer (e.g. a torch pinned tensor's data_ptr())."""
+        self._chk(self.L.pbd_detect_enqueue_u8(self.h, C.c_void_p(ptr), w, hgt, cn, stride or w * cn))
 
     def collect(self, capacity=4096):
         heads, boxes, locs = self._bufs(capacity)
@@ -306,6 +328,75 @@ class Handle:
         ms, n = C.c_double(0), C.c_int(0)
         self._chk(self.L.pbd_dp_timer(self.h, int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class Group:
+    """pbd_group: one process driving several GPUs (include/pbd_c.h).  devices may repeat an ordinal."""
+
+    def __init__(self, model, devices, gather=PBD_GATHER_AUTO, conv_mode=PBD_CONV_AUTO, max_candidates=4096,
+                 dtype=np.float32):
+        self.L = lib()
+        self.model = model
+        self.desc = model.to_desc()
+        f64 = np.dtype(dtype) == np.dtype(np.float64)
+        opt = pbd_options(0, conv_mode, max_candidates, 0, 0, 0, PBD_SCALAR_F64 if f64 else PBD_SCALAR_F32,
+                          (C.c_int32 * 2)(0, 0))
+        dv = np.ascontiguousarray(list(devices), np.int32)
+        self.g = C.c_void_p()
+        rc = self.L.pbd_group_create(C.byref(self.desc), C.byref(opt), _p(dv, C.c_int32), len(dv), gather, C.byref(self.g))
+        if rc != PBD_OK:
+            msg = self.L.pbd_group_last_error(self.g).decode() if self.g else "allocation failed"
+            if self.g:
+                self.L.pbd_group_destroy(self.g)
+            self.g = None
+            raise PbdError(rc, msg)
+        self.size = self.L.pbd_group_size(self.g)
+        self.gather_mode = self.L.pbd_group_gather_mode(self.g)
+        self.max_parts = self.L.pbd_max_parts(C.c_void_p(self.L.pbd_group_member(self.g, 0)))
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.pbd_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != PBD_OK:
+            raise PbdError(rc, self.L.pbd_group_last_error(self.g).decode())
+
+    def detect_batch(self, frames, capacity=4096):
+        """frames: list of equal-sized uint8 images -> list of (heads, boxes, locs), frame f on member f % size."""
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        n = len(frames)
+        hgt, w = frames[0].shape[:2]
+        cn = 1 if frames[0].ndim == 2 else frames[0].shape[2]
+        ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        heads = np.zeros(n * capacity, HEAD_DTYPE)
+        boxes = np.zeros((n * capacity, self.max_parts, 4), np.int32)
+        locs = np.zeros((n * capacity, self.max_parts, 3), np.int32)
+        counts = np.zeros(n, np.int32)
+        self._chk(self.L.pbd_group_detect_batch_u8(self.g, ptrs, n, w, hgt, cn, w * cn, heads.ctypes.data_as(C.c_void_p),
+                                                   _p(boxes, C.c_int32), _p(locs, C.c_int32), capacity, _p(counts, C.c_int32)))
+        return [(heads[f * capacity: f * capacity + counts[f]].copy(), boxes[f * capacity: f * capacity + counts[f]].copy(),
+                 locs[f * capacity: f * capacity + counts[f]].copy()) for f in range(n)]
+
+    def detect(self, im, capacity=4096):
+        """one frame, pyramid levels LPT-sharded over the members."""
+        im = np.ascontiguousarray(im, np.uint8)
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        heads = np.zeros(capacity, HEAD_DTYPE)
+        boxes = np.zeros((capacity, self.max_parts, 4), np.int32)
+        locs = np.zeros((capacity, self.max_parts, 3), np.int32)
+        cnt = C.c_int(0)
+        self._chk(self.L.pbd_group_detect_u8(self.g, _p(im, C.c_uint8), w, hgt, cn, w * cn, heads.ctypes.data_as(C.c_void_p),
+                                             _p(boxes, C.c_int32), _p(locs, C.c_int32), capacity, C.byref(cnt)))
+        return heads[:cnt.value].copy(), boxes[:cnt.value].copy(), locs[:cnt.value].copy()
 
 
 def candidates_sort(heads, boxes, locs):

@@ -708,7 +708,7 @@ static int run_dp_min(pbd_handle* h) {
   return PBD_OK;
 }
 
-static const int kFirstCopy = 192;  // records fetched together with the count
+static const int kFirstCopy = PBD_FIRST_COPY;  // records fetched together with the count
 
 static int run_argmin_enqueue(pbd_handle* h) {
   launch_backtrack(h->d_cand_count, h->d_cand_rec, h->opt.max_candidates, h->d_back, h->md.ncomponents, h->d_parent,
@@ -716,22 +716,26 @@ static int run_argmin_enqueue(pbd_handle* h) {
                    h->d_depth, h->max_depth, (int)h->parts.size(), h->d_scr_base, h->d_dt_ixT, h->d_dt_iy,
                    h->opt.dt_correct_ptr, h->stream);
   LAUNCHCHK(h, "argmin");
-  HIPCHK(h, hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   const int first = std::min(kFirstCopy, h->opt.max_candidates);
-  HIPCHK(h, hipMemcpyAsync(h->h_cand_out, h->d_cand_out, h->cand_stride * first, hipMemcpyDeviceToHost, h->stream));
+  if (h->d_gsend) {   // member of an RCCL-gathering pbd_group: pack {count, first records} for the all-gather instead of the D2H
+    HIPCHK(h, hipMemcpyAsync(h->d_gsend, h->d_cand_count, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_gsend + 16, h->d_cand_out, h->cand_stride * first, hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    HIPCHK(h, hipMemcpyAsync(h->h_cand_count, h->d_cand_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_cand_out, h->d_cand_out, h->cand_stride * first, hipMemcpyDeviceToHost, h->stream));
+  }
   h->pending = true;
   return PBD_OK;
 }
 
-static int collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
-  if (!h->pending) return fail(h, PBD_ERR_STATE, "collect without a pending detect");
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+// frame finished on the stream: timers, and the records beyond the first block (rare) fetched into h_cand_out.
+// `found` = the device-side count (h_cand_count[0], or the count a group gather delivered).
+int pbd_i_finish_frame(pbd_handle* h, int found) {
   h->pending = false;
   if (h->dp_timer_on && h->have_dp) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev_dp0, h->ev_dp1) == hipSuccess) { h->dp_ms_sum += ms; h->dp_frames++; }
   }
-  const int found = h->h_cand_count[0];
   const int n = std::min(found, h->opt.max_candidates);
   const int first = std::min(kFirstCopy, h->opt.max_candidates);
   if (n > first) {
@@ -739,14 +743,19 @@ static int collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int
                              h->cand_stride * (n - first), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
-  if (count) *count = found;
   if (found > h->opt.max_candidates) return fail(h, PBD_ERR_CAPACITY, "device candidate capacity exceeded; raise pbd_options.max_candidates");
-  // order like a single-threaded reference run: level, component, row-major root location
-  const int mp = h->max_parts;
+  return PBD_OK;
+}
+
+// Candidate records (cand_stride bytes each, possibly from several handles of one group: recs[i] points at record i)
+// -> the caller's arrays, ordered like a single-threaded reference run: level, component, row-major root location.
+int pbd_i_emit(pbd_handle* h, const std::vector<const char*>& recs, pbd_candidate_head* heads, int32_t* boxes,
+               int32_t* locs, int capacity) {
+  const int mp = h->max_parts, n = (int)recs.size();
   std::vector<int> order(n);
   for (int i = 0; i < n; ++i) order[i] = i;
   auto key = [&](int i, int k) -> int {
-    const char* o = h->h_cand_out + h->cand_stride * i;
+    const char* o = recs[i];
     const pbd_candidate_head* hd = (const pbd_candidate_head*)o;
     const int32_t* lc = (const int32_t*)(o + sizeof(pbd_candidate_head)) + (size_t)mp * 4;
     return k == 0 ? hd->level : k == 1 ? hd->component : k == 2 ? lc[1] : lc[0];
@@ -757,7 +766,7 @@ static int collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int
   });
   if (n > capacity) return fail(h, PBD_ERR_CAPACITY, "output capacity too small");
   for (int i = 0; i < n; ++i) {
-    const char* o = h->h_cand_out + h->cand_stride * order[i];
+    const char* o = recs[order[i]];
     if (heads) heads[i] = *(const pbd_candidate_head*)o;
     const int32_t* b = (const int32_t*)(o + sizeof(pbd_candidate_head));
     if (boxes) memcpy(boxes + (size_t)i * mp * 4, b, sizeof(int32_t) * mp * 4);
@@ -766,6 +775,25 @@ static int collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int
   return PBD_OK;
 }
 
+static int collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
+  if (!h->pending) return fail(h, PBD_ERR_STATE, "collect without a pending detect");
+  if (h->d_gsend) return fail(h, PBD_ERR_STATE, "handle belongs to an RCCL-gathering pbd_group: collect through the group");
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const int found = h->h_cand_count[0];
+  if (count) *count = found;
+  int rc = pbd_i_finish_frame(h, found);
+  if (rc) return rc;
+  std::vector<const char*> recs((size_t)found);
+  for (int i = 0; i < found; ++i) recs[i] = h->h_cand_out + h->cand_stride * i;
+  return pbd_i_emit(h, recs, heads, boxes, locs, capacity);
+}
+int pbd_i_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
+  int rc = collect(h, heads, boxes, locs, capacity, count);
+  return rc;
+}
+
+static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride);
+int pbd_i_enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) { return enqueue_all(h, d_src, stride); }
 static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
   int rc;
   const bool prof = h->profiling;
@@ -907,22 +935,31 @@ int pbd_detect_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, int cn, i
   return pbd_detect_collect(h, heads, boxes, locs, capacity, count);
 }
 
+static int upload_image(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride);
+extern "C++" int pbd_i_upload_image(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride) { return upload_image(h, im, w, hgt, cn, stride); }
 static int upload_image(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride) {
   if (stride < w * cn) return fail(h, PBD_ERR_ARG, "stride < w*cn");
   HIPCHK(h, hipSetDevice(h->opt.device));
   int rc = plan_frame(h, w, hgt, cn);
   if (rc) return rc;
-  HIPCHK(h, hipMemcpy2DAsync(h->d_img, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice, h->stream));
+  // tightly packed rows: one linear copy (a DMA-engine transfer when `im` is pinned); strided rows: a 2-D copy
+  if (stride == w * cn) HIPCHK(h, hipMemcpyAsync(h->d_img, im, (size_t)w * cn * hgt, hipMemcpyHostToDevice, h->stream));
+  else HIPCHK(h, hipMemcpy2DAsync(h->d_img, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice, h->stream));
   return PBD_OK;
+}
+
+int pbd_detect_enqueue_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride) {
+  if (!h || !im) return PBD_ERR_ARG;
+  if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
+  int rc = upload_image(h, im, w, hgt, cn, stride);   // hipMemcpy2DAsync on the handle's stream, in front of the kernels
+  if (rc) return rc;
+  return enqueue_all(h, h->d_img, w * cn);
 }
 
 int pbd_detect_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, pbd_candidate_head* heads,
                   int32_t* boxes, int32_t* locs, int capacity, int* count) {
-  if (!h || !im) return PBD_ERR_ARG;
-  if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
-  int rc = upload_image(h, im, w, hgt, cn, stride);
+  int rc = pbd_detect_enqueue_u8(h, im, w, hgt, cn, stride);
   if (rc) return rc;
-  if ((rc = enqueue_all(h, h->d_img, w * cn))) return rc;
   return pbd_detect_collect(h, heads, boxes, locs, capacity, count);
 }
 

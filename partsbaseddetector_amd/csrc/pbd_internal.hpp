@@ -174,6 +174,7 @@ struct pbd_handle {
   char* d_cand_out = nullptr; char* h_cand_out = nullptr; int* h_cand_count = nullptr;
   size_t cand_stride = 0;
   bool pending = false;
+  char* d_gsend = nullptr;   // set by an RCCL-gathering pbd_group: {count, pad to 16 B, first records} block sent by ncclAllGather
 
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -225,6 +226,15 @@ struct LdsOptIn {
 #else
 #define PBD_PROBE_ENV(name) ((const char*)nullptr)
 #endif
+
+// ---- internals shared with pbd_group.cpp -----------------------------------------
+int pbd_i_upload_image(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride);   // plan + async H2D
+int pbd_i_enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride);                          // all stages + argmin
+int pbd_i_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count);
+int pbd_i_finish_frame(pbd_handle* h, int found);
+int pbd_i_emit(pbd_handle* h, const std::vector<const char*>& recs, pbd_candidate_head* heads, int32_t* boxes,
+               int32_t* locs, int capacity);
+#define PBD_FIRST_COPY 192   // candidate records fetched (or gathered) together with the count
 
 // ---- kernel launchers (k_*.hip) ----------------------------------------------
 void launch_resize(const ResizeArgs& a, const uint8_t* src, uint8_t* pyr, hipStream_t s);

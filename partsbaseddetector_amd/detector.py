@@ -142,7 +142,8 @@ class SpatialConvolutionEngine:
         g = self._h._geo
         if features is not None:
             for l, f in enumerate(features):
-                self._h.set_level_features(l, np.asarray(f, np.float32).reshape(g["cell_h"][l], g["cell_w"][l], 32))
+                # the handle's T (float or double): a double detector must not round injected features to float
+                self._h.set_level_features(l, np.asarray(f, self._h.dtype).reshape(g["cell_h"][l], g["cell_w"][l], 32))
         self._h.pdf()
         nf = len(self._h.model.filtersw)
         return [[self._h.level_response(l, n) for n in range(nf)] for l in range(g["nlevels"])]

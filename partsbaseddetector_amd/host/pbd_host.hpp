@@ -154,6 +154,16 @@ class BinaryModel : public Model {
     const int nf = hd[0], kh = hd[1], kw = hd[2];
     flen_ = hd[3]; norient_ = hd[4]; binsize_ = hd[5]; nscales_ = hd[6];
     const int ndefs = hd[7], nbias = hd[8], ncomp = hd[9];
+    // the header counts size every allocation below: bound them by what the file can actually hold
+    fseek(f, 0, SEEK_END);
+    const long long fsize = ftell(f);
+    fseek(f, 8 + (long)sizeof(hd), SEEK_SET);
+    const long long per_filter = (long long)kh * kw * flen_ * 4;
+    if (nf <= 0 || kh <= 0 || kw <= 0 || kh > 64 || kw > 64 || flen_ <= 0 || flen_ > 1024 || ndefs < 0 || nbias <= 0 || ncomp <= 0 ||
+        (long long)nf * per_filter > fsize || (long long)ndefs * 24 > fsize || (long long)nbias * 4 > fsize || (long long)ncomp * 4 > fsize) {
+      fclose(f);
+      return false;
+    }
     ok = rd(f, &thresh_, 4);
     filtersw_.resize(nf);
     for (int n = 0; n < nf && ok; ++n) { filtersw_[n].create(kh, kw * flen_, PBD_32F); ok = rd(f, filtersw_[n].ptr<float>(), (size_t)kh * kw * flen_ * 4); }
@@ -165,9 +175,11 @@ class BinaryModel : public Model {
     filterid_.resize(ncomp); biasid_.resize(ncomp); defid_.resize(ncomp); parentid_.resize(ncomp);
     for (int c = 0; c < ncomp && ok; ++c) {
       int32_t np; ok = rd(f, &np, 4);
+      if (!ok || np <= 0 || (long long)np * 8 > fsize) { ok = false; break; }
       filterid_[c].resize(np); biasid_[c].resize(np); defid_[c].resize(np); parentid_[c].resize(np);
       for (int p = 0; p < np && ok; ++p) {
         int32_t pk[2]; ok = rd(f, pk, 8);
+        if (!ok || pk[1] <= 0 || (long long)pk[1] * 12 > fsize) { ok = false; break; }
         parentid_[c][p] = pk[0];
         filterid_[c][p].resize(pk[1]); biasid_[c][p].resize(pk[1]); defid_[c][p].resize(pk[1]);
         ok = ok && rd(f, filterid_[c][p].data(), 4 * pk[1]) && rd(f, defid_[c][p].data(), 4 * pk[1]) && rd(f, biasid_[c][p].data(), 4 * pk[1]);

@@ -61,7 +61,10 @@ def shard_levels_lpt(cells: Sequence[int], world: int) -> List[List[int]]:
 def pack_candidates(cands, max_parts: int, capacity: int) -> np.ndarray:
     """(heads, boxes, locs) -> int32 [1 + capacity * (4 + 7*max_parts)] : count, then records."""
     heads, boxes, locs = cands
-    n = min(len(heads), capacity)
+    n = len(heads)
+    if n > capacity:     # the C ABI reports PBD_ERR_CAPACITY for the same condition: never drop detections silently
+        raise OverflowError(f"{n} candidates do not fit the gather capacity {capacity}: pass capacity >= the handle's "
+                            f"max_candidates")
     rec = HEAD_WORDS + 7 * max_parts
     buf = np.zeros(1 + capacity * rec, np.int32)
     buf[0] = n
@@ -89,9 +92,10 @@ def unpack_candidates(buf: np.ndarray, max_parts: int):
     return heads, boxes, locs
 
 
-def gather_candidates(cands, max_parts: int, capacity: int = 1024, device=None):
+def gather_candidates(cands, max_parts: int, capacity: int = 4096, device=None):
     """all_gather of every rank's candidates; returns a list (one entry per rank) of
-    (heads, boxes, locs).  Works with any initialised torch.distributed backend."""
+    (heads, boxes, locs).  Works with any initialised torch.distributed backend.  `capacity` (records per rank in
+    the fixed-size exchange buffer) defaults to the handles' default max_candidates; a rank holding more raises."""
     import torch
     import torch.distributed as dist
 

@@ -784,3 +784,94 @@ def test_person_1080p_full_mfma_scores(gpu_required, orc):
         ov, _ = fr.root(l)
         assert np.abs(rv - ov[0]).max() < 1e-4, l
     h.close(); fr.free()
+
+
+# ---------------------------------------------------------------- pbd_group: one process, several handles / GPUs
+def test_group_batch_two_handles_one_gpu_equals_single_handle(gpu_required, orc):
+    """pbd_group_detect_batch_u8 over two members on the same GPU (host gather: RCCL wants distinct devices) returns,
+    frame by frame, exactly what one handle returns — and what the oracle returns (configs[2] shape: a batch of
+    frames round-robin over the members, odd batch size: the last wave has an idle member)."""
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    frames = [make_image(i, 200, 150) for i in range(5)]
+    m.thresh = thresh_from_oracle(orc, m, frames[0], 99.3)
+    g = capi.Group(m, [0, 0], conv_mode=capi.PBD_CONV_EXACT)
+    assert g.size == 2 and g.gather_mode == capi.PBD_GATHER_HOST
+    outs = g.detect_batch(frames)
+    single = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    for f, got in zip(frames, outs):
+        assert_candidates_equal(got, single.detect(f))
+        assert_candidates_equal(got, orc.detect(m, f)[:3])
+    with pytest.raises(capi.PbdError) as e:          # fixed capacity per frame
+        g.detect_batch(frames[:2], capacity=1)
+    assert e.value.code == capi.PBD_ERR_CAPACITY
+    # level-sharded single frame over the same two members, then batches again (level sets are reset)
+    assert_candidates_equal(g.detect(frames[1]), single.detect(frames[1]))
+    assert_candidates_equal(g.detect_batch(frames[:1])[0], single.detect(frames[0]))
+    single.close(); g.close()
+
+
+def test_group_level_sharding_more_members_than_needed(gpu_required, orc):
+    """pbd_group_detect_u8 with 3 members on one GPU (LPT level sets) == the single-handle frame; 1080p-style
+    use is the same call with 8 devices."""
+    m = make_tree_model([-1, 0, 0], 2, seed=6)
+    im = make_image(3, 320, 240)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.0)
+    g = capi.Group(m, [0, 0, 0], gather=capi.PBD_GATHER_HOST, conv_mode=capi.PBD_CONV_EXACT)
+    assert_candidates_equal(g.detect(im), orc.detect(m, im)[:3])
+    g.close()
+
+
+def test_group_rccl_gather_single_rank(gpu_required, orc):
+    """The RCCL code path (dlopen librccl, ncclCommInitAll, ncclAllGather of the {count, records} block, one D2H)
+    on the one GPU this box has: a communicator of one rank.  More candidates than the gathered block holds
+    (192) exercises the remainder hand-over."""
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    im = make_image(0, 320, 240)
+    g = capi.Group(m, [0], gather=capi.PBD_GATHER_RCCL, conv_mode=capi.PBD_CONV_EXACT)
+    assert g.gather_mode == capi.PBD_GATHER_RCCL
+    for q in (99.5, 97.0):
+        m.thresh = thresh_from_oracle(orc, m, im, q)
+        g2 = capi.Group(m, [0], gather=capi.PBD_GATHER_RCCL, conv_mode=capi.PBD_CONV_EXACT)
+        ref = orc.detect(m, im)[:3]
+        assert (len(ref[0]) > 192) == (q < 99.0)
+        assert_candidates_equal(g2.detect_batch([im, im])[1], ref)
+        assert_candidates_equal(g2.detect(im), ref)
+        g2.close()
+    with pytest.raises(capi.PbdError) as e:          # RCCL wants distinct devices
+        capi.Group(m, [0, 0], gather=capi.PBD_GATHER_RCCL)
+    assert e.value.code == capi.PBD_ERR_RCCL
+    g.close()
+
+
+def test_detect_enqueue_host_image_async(gpu_required, orc):
+    """pbd_detect_enqueue_u8: host image (pinned) -> async H2D + kernels on the handle's stream; two frames in flight."""
+    import torch
+    m = make_tree_model([-1, 0, 0], 2, seed=6)
+    ims = [make_image(3 + i, 200, 150) for i in range(2)]
+    m.thresh = thresh_from_oracle(orc, m, ims[0], 99.0)
+    pinned = [torch.from_numpy(im).pin_memory() for im in ims]
+    hs = [capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT) for _ in range(2)]
+    for h, t in zip(hs, pinned):
+        h.enqueue_host_ptr(t.data_ptr(), 200, 150, 3)
+    for h, im in zip(hs, ims):
+        assert_candidates_equal(h.collect(), orc.detect(m, im)[:3])
+    hs[0].enqueue(ims[1])                              # pageable numpy image: staged by the runtime
+    assert_candidates_equal(hs[0].collect(), orc.detect(m, ims[1])[:3])
+    for h in hs:
+        h.close()
+
+
+def test_inactive_level_getters_refuse(gpu_required):
+    """Levels excluded by pbd_set_levels hold no data: the getters answer PBD_ERR_STATE instead of uninitialised HBM."""
+    m = make_tree_model([-1, 0], 1, seed=2)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    h.set_levels([0, 3])
+    im = make_image(1, 160, 120)
+    h.detect(im)
+    h._geo = h.geometry(160, 120); h._cn = 3
+    h.level_features(0); h.level_response(3, 0); h.root(0, 0)
+    for fn in (lambda: h.level_features(1), lambda: h.level_response(2, 0), lambda: h.root(1, 0)):
+        with pytest.raises(capi.PbdError) as e:
+            fn()
+        assert e.value.code == capi.PBD_ERR_STATE
+    h.close()

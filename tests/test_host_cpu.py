@@ -131,6 +131,16 @@ def test_pack_unpack_roundtrip():
     np.testing.assert_array_equal(out[2], locs)
 
 
+def test_pack_candidates_overflow_raises():
+    """A rank holding more candidates than the exchange buffer must fail loudly (the C ABI reports
+    PBD_ERR_CAPACITY for the same condition), never drop detections in the multi-GPU merge."""
+    heads = np.zeros(5, capi.HEAD_DTYPE)
+    boxes, locs = np.zeros((5, 3, 4), np.int32), np.zeros((5, 3, 3), np.int32)
+    with pytest.raises(OverflowError):
+        parallel.pack_candidates((heads, boxes, locs), 3, 4)
+    assert parallel.pack_candidates((heads, boxes, locs), 3, 5)[0] == 5
+
+
 _WORKER = r"""
 import os, sys
 import numpy as np

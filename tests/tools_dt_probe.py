@@ -1,4 +1,6 @@
 """Ad-hoc probe (not a test): standalone DT on a few map sizes, per-phase timestamps of block 0."""
+import os
+os.environ.setdefault("PBD_LIBRARY", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "partsbaseddetector_amd", "libpbd_hip_probes.so"))  # `make -C partsbaseddetector_amd/csrc probes`
 import ctypes as C
 import sys
 import numpy as np

@@ -1,4 +1,6 @@
 """Ad-hoc probe (not a test): wave-per-line DT on single maps under the kernel tracer."""
+import os
+os.environ.setdefault("PBD_LIBRARY", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "partsbaseddetector_amd", "libpbd_hip_probes.so"))  # `make -C partsbaseddetector_amd/csrc probes`
 import sys
 import numpy as np
 sys.path.insert(0, "/root/repo")

@@ -1,4 +1,6 @@
 """Ad-hoc probe (not a test): host-side cost of one pbd_detect_enqueue_dev_u8 + collect (CPU time per frame)."""
+import os
+os.environ.setdefault("PBD_LIBRARY", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "partsbaseddetector_amd", "libpbd_hip_probes.so"))  # `make -C partsbaseddetector_amd/csrc probes`
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch

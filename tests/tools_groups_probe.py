@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("PBD_LIBRARY", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "partsbaseddetector_amd", "libpbd_hip_probes.so"))  # `make -C partsbaseddetector_amd/csrc probes`
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch

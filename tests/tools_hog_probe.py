@@ -1,4 +1,6 @@
 """Ad-hoc probe (not a test): per-phase timestamps of block 0 of k_hog."""
+import os
+os.environ.setdefault("PBD_LIBRARY", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "partsbaseddetector_amd", "libpbd_hip_probes.so"))  # `make -C partsbaseddetector_amd/csrc probes`
 import ctypes as C
 import sys
 sys.path.insert(0, "/root/repo")
