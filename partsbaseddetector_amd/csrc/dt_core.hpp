@@ -1,0 +1,238 @@
+// dt_core.hpp — exact, segment-parallel emulation of DistanceTransform<T>::computeRow
+// (reference include/DistanceTransform.hpp:151-182, Quadratic::operator() :89-105).
+//
+// The reference builds the upper envelope of one score line with a sequential stack algorithm whose
+// float-rounded intersections decide the result, so the RESULT must be that of the sequential run.  A line is
+// long (level 0 of a 640x480 frame: 158 / 118 elements) and a pass lasts as long as its longest line, so the
+// line is cut into P segments that P lanes scan CONCURRENTLY, each with the reference's own arithmetic and
+// its own (local) stack, and the local results are then stitched into exactly the state the sequential run
+// would have reached.  Shared by k_dp.hip (device) and tests/tools/dt_core_test.cpp (host: the same source run
+// against the reference loop on millions of random and adversarial lines).
+//
+// Representation (per line, in LDS on the device): the stack is a LINKED LIST over the line's elements —
+//   YZ[e].x  y of element e (the input line, never modified)
+//   YZ[e].y  z of e: the intersection computed when e was pushed (`z[k] = s`, :168)
+//   B[e]     the element directly below e on the stack at the time e was pushed (`v[k-1]`)
+// An element on the stack never changes its z or its "below", so the stack at any time is the chain
+// top -> B[top] -> ... -> bottom, and pushing q writes only q's own slots.  9 bytes per element (float).
+//
+// 1. dt_seg_scan: lane p runs the reference's loop (:156-170) on elements [s_p, s_{p+1}) with an empty initial
+//    stack ("local scan"): local z / B for every element of the segment.
+//    While it scans, a popped element's B slot (dead from then on) receives the element that popped it:
+//    B[e] > e marks e as popped and names its "popper".
+// 2. dt_stitch (one lane per line, segments left to right) replays what the GLOBAL run does when it reaches
+//    segment B = [s_p, s_{p+1}) with the stack G left by the segments before it.  Invariant: the part of the
+//    global stack made of B's elements is a suffix [F, ...] of the local stack, and every entry above F has the
+//    same z and the same "below" globally as locally (its predecessor is the same element); only F's z
+//    differs (its predecessor lies in G).  For an element q of B the global run therefore performs exactly
+//    the local run's pop tests as long as those stay above F — nothing to redo — and deviates only when the
+//    local scan of q reached F ("event"): then F is tested with its GLOBAL z:
+//      fail -> q is pushed on F, as in the local run iff that also stopped at F; if the local run popped F the
+//              invariant is lost: the line is flagged and redone sequentially (only near-degenerate
+//              geometry: exact ties / collinear triples);
+//      pass -> F is popped and the pops continue into G with explicit tests; q becomes the new F.
+//    Events need no search: while F is the top of the local stack the next element is the next event; once an
+//    element c sits on F, the next element to reach F is the one that pops c locally — c's popper link.
+//    Events are rare (a new "record" element of the segment) and each costs a few intersections.
+// 3. dt_seg_table: which segments still own entries of the final stack, where the chain enters them, and the z
+//    of their lowest entry — so that a read-out lane finds the entry covering its last output with a table
+//    look-up and a short walk.
+// 4. The read-out (:172-178) runs over q in DESCENDING order, sub-ranges in lockstep (coalesced stores), stepping
+//    down the chain through the "below" links: k(q) = max{k : z[k] < os + q}, the same entry the reference's
+//    ascending `while (z[k+1] < os) k++` reaches because z is strictly increasing along the stack.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#ifdef __HIPCC__
+#define DT_HD __device__ __forceinline__
+#define DT_MUL24(a, b) __mul24((a), (b))
+DT_HD unsigned long long dt_bits(double d) { return (unsigned long long)__double_as_longlong(d); }
+#else
+#define DT_HD static inline
+#define DT_MUL24(a, b) ((a) * (b))
+DT_HD unsigned long long dt_bits(double d) { unsigned long long u; memcpy(&u, &d, 8); return u; }
+#endif
+
+template <typename T> struct alignas(2 * sizeof(T)) DtPair { T x, y; };
+
+// segment p of P over a line of `len` elements: [dt_seg_start(p), dt_seg_start(p + 1))
+DT_HD int dt_seg_start(int p, int P, int len) { return (int)(((long long)p * len) / P); }
+// segments actually used for a line: at least 8 elements each (short lines gain nothing from stitching)
+DT_HD int dt_segments(int lanes_per_line, int len) {
+  int P = len / 8;
+  if (P > lanes_per_line) P = lanes_per_line;
+  return P < 1 ? 1 : P;
+}
+
+// Intersection of the parabolas rooted at x0 = vk < x1 = q (Quadratic::operator()(x0,x1,y0,y1), :98-100),
+// narrowed to T like `T s = f(...)` at :161:
+//   num = ((y1 - y0) - b*(x1-x0)) + a*(x1^2 - x0^2)      (same fp64 operations, same order)
+//   s   = (T)(num / den),  den = (2a)*(x1-x0)
+// EXACT = false (float only): the fp64 division is replaced by ONE multiplication with the correctly rounded
+// reciprocal r = RN(1/den) from the per-map table: q1 = RN(num * r) carries two roundings, so q1 lies within
+// 3 ulp of RN(num/den) and (float)q1 can differ from (float)RN(num/den) only if a float rounding boundary (a
+// double whose low 29 mantissa bits are 0x10000000) lies within 3 ulp of q1 — low 29 bits in
+// 0x0FFFFFFC..0x10000004 are flagged — or the value leaves the normal float range.  A flagged line is redone
+// with EXACT = true (IEEE division), so the result is always bit-identical to the reference's.
+template <bool EXACT, typename T>
+DT_HD T dt_isect(double yk, int vk, double yq, int q, double a, double b, double twoa, double r, unsigned& suspect) {
+  const int dx = q - vk;
+  const double dxd = (double)dx;
+  const double num = ((yq - yk) - b * dxd) + a * (double)DT_MUL24(dx, q + vk);   // x1^2 - x0^2 < 2^31, operands < 2^16
+  const double den = twoa * dxd;
+  double q1;
+  if (EXACT) {
+    q1 = num / den;
+  } else {
+    q1 = num * r;
+    const unsigned long long bits = dt_bits(q1);
+    const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
+    const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
+    suspect = (((lo29 - 0x0FFFFFFCu) <= 8u) | ((ex - 897u) > 252u)) ? 1u : suspect;
+  }
+  return (T)q1;
+}
+
+// Local scan of elements [s0, s1) (:156-170 with an empty initial stack).  The reference's nested loops
+// (for q { while (pop) }) are flattened into a state machine doing exactly one intersection per iteration, so the
+// lanes of a wavefront never wait for the slowest lane's pop count and every line sees the reference's sequence
+// of intersections / `s <= z[k]` tests in order.  Branch-free body: the stack top and the entry below it live in
+// registers; the entry two below (addressed through the top's "below of below" kept in a register), the
+// reciprocal a pop would need and the next line element are loaded at the top of an iteration and consumed at
+// its end; the z store goes unconditionally to q's own slot (dead when the step pops).
+// R[dx] = RN(1 / (2a*dx)) (EXACT = false only).  Returns the sticky "suspect" flag.
+template <bool EXACT, typename T, typename IT>
+DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R, int s0, int s1,
+                       double a, double b) {
+  const double twoa = 2 * a;
+  YZ[s0].y = (T)-INFINITY;                  // z[0] = -inf (:158): the bottom of a stack is never popped (`k > 0`, :162)
+  B[s0] = (IT)s0;
+  if (s1 - s0 < 2) return false;
+  const double r1 = EXACT ? 0.0 : R[1];
+  int vk = s0, nv = s0, nb = s0;            // top, the entry below it, the entry below that (element indices)
+  T zk = (T)-INFINITY, nz = (T)-INFINITY;
+  double yk = (double)YZ[s0].x, ny = yk;
+  double r_top = r1;
+  int q = s0 + 1;
+  T yq_f = YZ[q].x;
+  unsigned suspect = 0;
+  while (q < s1) {
+    // prefetches (addresses known now, values used after the arithmetic below)
+    const DtPair<T> pyz = YZ[nb];
+    const int pb = (int)B[nb];
+    const double r_nxt = EXACT ? 0.0 : R[q - nv];        // reciprocal for the entry below the top (used if this step pops)
+    const T ynext_f = YZ[q + 1 < s1 ? q + 1 : s1 - 1].x;
+    const double yq = (double)yq_f;
+    const T s = dt_isect<EXACT, T>(yk, vk, yq, q, a, b, twoa, r_top, suspect);
+    const bool pop = (s <= zk) && (vk != s0);            // :162
+    // push: B[q] = top (:166-169).  pop: the popped top's slot is dead from now on and records its popper.
+    B[pop ? vk : q] = (IT)(pop ? q : vk);
+    YZ[q].y = s;                                         // dead if this step pops
+    const int vk_o = vk; const double yk_o = yk; const T zk_o = zk; const int nv_o = nv;
+    vk = pop ? nv : q;
+    yk = pop ? ny : yq;
+    zk = pop ? nz : s;
+    r_top = pop ? r_nxt : r1;
+    nv = pop ? nb : vk_o;
+    ny = pop ? (double)pyz.x : yk_o;
+    nz = pop ? pyz.y : zk_o;
+    nb = pop ? pb : nv_o;
+    yq_f = pop ? yq_f : ynext_f;
+    q = pop ? q : q + 1;
+  }
+  return suspect != 0;
+}
+
+// Stitch the local scans of segments 1..P-1 onto segment 0, left to right (see the header comment).  One lane
+// per line; a flattened state machine doing ONE intersection per iteration (lanes of a wavefront stitch
+// different lines: no lane waits in a nested loop for another's trip count).  F[p] receives the lowest element
+// of segment p that the global run left on the stack after segment p (meaningful only while the segment is
+// alive, see dt_seg_table); its z and "below" are patched to the global values.  Returns true if the invariant
+// was lost or a quotient was suspect (the caller redoes the line sequentially).
+template <bool EXACT, typename T, typename IT>
+DT_HD bool dt_stitch(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R, int len, int P,
+                     double a, double b, IT* __restrict__ F, int fstride) {
+  const double twoa = 2 * a;
+  unsigned suspect = 0;
+  bool bad = false;
+  F[0] = (IT)0;
+  if (P < 2) return false;
+  int p = 1, s1 = dt_seg_start(2, P, len);
+  int q = dt_seg_start(1, P, len);          // the global run reaches the segment's first element: top of G = q - 1
+  double yq = (double)YZ[q].x;
+  int e = q - 1;
+  bool testf = false;                        // false: popping in G for q; true: e == F, tested with its global z
+  int f = 0, fb = 0;
+  T zf = (T)0;
+  for (;;) {
+    const DtPair<T> ez = YZ[e];
+    const int eb = (int)B[e];
+    const T s = dt_isect<EXACT, T>((double)ez.x, e, yq, q, a, b, twoa, EXACT ? 0.0 : R[q - e], suspect);
+    const bool pass = (s <= (testf ? zf : ez.y)) && (e != 0);      // :162; only the bottom of the whole stack is protected
+    if (pass) {
+      e = testf ? fb : eb;                   // F popped: continue below it; otherwise one more pop in G
+      testf = false;
+      continue;
+    }
+    int nq;
+    if (!testf) {                            // q is pushed on e: the new F, top of the segment's part of the stack
+      f = q; zf = s; fb = e;
+      nq = q + 1;                            // F is the top: the next element tests it
+    } else {                                 // F survives q: fine iff the local run stopped at F too (q sits on F)
+      if ((int)B[f] == q) bad = true;        // ... but it popped F (F's popper link names q): invariant lost
+      const int pq = (int)B[q];              // q alive at the end of its segment: its "below"; popped: its popper
+      nq = pq > q ? pq : s1;                 // the next element to reach F is the one that pops q
+    }
+    if (nq >= s1) {                          // segment done: patch F to its global z / below
+      YZ[f].y = zf;
+      B[f] = (IT)fb;
+      F[p * fstride] = (IT)f;
+      if (++p >= P) break;
+      q = s1;
+      s1 = dt_seg_start(p + 1, P, len);
+      e = q - 1;
+      testf = false;
+    } else {
+      q = nq;
+      e = f;
+      testf = true;
+    }
+    yq = (double)YZ[q].x;
+  }
+  return bad || suspect != 0;
+}
+
+// After the stitch: which segments still own entries of the final stack, where the chain enters them (ENT[p]:
+// topmost surviving element of segment p, or `dead`) and the z of their lowest entry (ZLO[p] = z of F[p]).  One
+// lane per line, top segment first.
+template <typename T, typename IT>
+DT_HD void dt_seg_table(const DtPair<T>* __restrict__ YZ, const IT* __restrict__ B, int len, int P,
+                        const IT* __restrict__ F, IT* __restrict__ ENT, T* __restrict__ ZLO, int tstride, IT dead) {
+  int e = len - 1;
+  for (int p = P - 1; p >= 0; --p) {
+    if (e >= dt_seg_start(p, P, len)) {
+      const int f = (int)F[p * tstride];
+      ENT[p * tstride] = (IT)e;
+      ZLO[p * tstride] = YZ[f].y;
+      e = (int)B[f];
+    } else {
+      ENT[p * tstride] = dead;
+    }
+  }
+}
+
+// Read-out lane: the stack entry covering output position `osq` (= os + q, compared like `z[k+1] < os`, :174):
+// the topmost entry whose z is < (T)osq.  It lies in the highest surviving segment whose lowest entry qualifies.
+template <typename T, typename IT>
+DT_HD int dt_cover(const DtPair<T>* __restrict__ YZ, const IT* __restrict__ B, int P, const IT* __restrict__ ENT,
+                   const T* __restrict__ ZLO, int tstride, IT dead, int osq) {
+  const T fos = (T)osq;
+  int ps = 0;                                // segment 0 always qualifies: z of the bottom entry is -inf
+  for (int p = 1; p < P; ++p)
+    if (ENT[p * tstride] != dead && ZLO[p * tstride] < fos) ps = p;
+  int e = (int)ENT[ps * tstride];
+  while (!(YZ[e].y < fos)) e = (int)B[e];
+  return e;
+}

@@ -25,195 +25,57 @@
 // k_backtrack argmin (:219-245): one lane per candidate walks the part tree.
 #include <type_traits>
 #include "pbd_internal.hpp"
+#include "dt_core.hpp"
 
 // debug: per-phase timestamps (100 MHz wall clock) of block 0 of the last k_dt_pass launch
 #ifdef PBD_PROBES
 __device__ unsigned long long pbd_dt_dbg[8];
 #define DT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pbd_dt_dbg[i] = wall_clock64(); } while (0)
-void dt_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_dt_dbg), sizeof(unsigned long long) * 8); }
+#define DT_COUNT_REDO() atomicAdd(&pbd_dt_dbg[7], 1ull)
+void dt_debug_read(unsigned long long* out) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_dt_dbg), sizeof(unsigned long long) * 8);
+  const unsigned long long z = 0;
+  hipMemcpyToSymbol(HIP_SYMBOL(pbd_dt_dbg), &z, sizeof(z), 7 * sizeof(unsigned long long));   // [7]: lines redone sequentially since the last read
+}
 #else
 #define DT_STAMP(i) do { } while (0)
+#define DT_COUNT_REDO() do { } while (0)
 void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i] = 0; }
 #endif
 
-// LDS per block: 64 line pointers + 64 stack sizes + per line {(Y, Z) : float2[S]; V : u8[S] (S <= 256) or
-// u16[S]} + per map touched by the block a table of exact reciprocals 1/(2a*dx), dx < len (double[S]).
-// The envelope scan is VALU-issue bound with one lane per line, and the lines resident on a CU are
-// bounded by these bytes: every byte saved per element is more active lanes per wavefront.
-size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts) {   // ts = sizeof(T): (Y, Z) is float2 or double2
-  return (size_t)lpb * stride * (2 * ts + (stride <= 256 ? 1 : 2)) + 64 * (8 + 8 + 4 + 4) + (size_t)nmb * stride * 8 + 16;
-}
-template <typename T> struct Pair;                       // (y, z) of one stack entry: one LDS word pair
-template <> struct Pair<float> { typedef float2 type; };
-template <> struct Pair<double> { typedef double2 type; };
-
-// Envelope scan of one line (DistanceTransform.hpp:156-170), one lane per line.
-//
-// Intersection of the parabolas rooted at x0 < x1 (Quadratic::operator()(x0,x1,y0,y1), :98-100),
-// narrowed to T like `T s = f(...)` at :161:
-//   num = ((y1 - y0) - b*(x1-x0)) + a*(x1^2 - x0^2)      (same fp64 operations, same order)
-//   s   = (float)(num / den),  den = (2a)*(x1-x0)
-// EXACT = false: the fp64 division (14 dependent instructions, four of them quarter rate) is
-// replaced by a multiplication with the exact reciprocal r = RN(1/den) from the per-map table plus
-// one fma residual correction; q1 is within 1 ulp of RN(num/den), so (float)q1 can differ from
-// (float)RN(num/den) only if a float rounding boundary lies within 1 ulp of q1 (low 29 mantissa
-// bits in 0x0FFFFFFF..0x10000001) or the value leaves the normal float range.  Those cases
-// (~1e-8 of all evaluations) set a sticky flag and the whole line is redone with EXACT = true
-// (true IEEE division), so the result is always bit-identical to the reference's.
-//
-// The reference's nested loops (for q { while (pop) }) are flattened into a state machine doing
-// exactly one intersection per iteration: lanes never wait for the slowest lane's pop count and
-// every line sees the reference's sequence of intersections / `s <= z[k]` tests in order.  A
-// single in-order wave exposes every latency and is instruction-issue bound, so the body is
-// branch-free, keeps the stack top and the entry below it in registers, prefetches the entry two
-// below, the reciprocal for a pop and the next line element at the top of the iteration (consumed
-// at its end), stores (y,z) of an entry as one 8-byte LDS word, and issues the push stores
-// unconditionally to slot k+1 (dead when the step pops).  The y of stack entry k overwrites the
-// consumed line element k in place (k <= q).
-template <bool EXACT, typename VT, typename T>
-__device__ __forceinline__ bool dt_envelope(typename Pair<T>::type* __restrict__ YZl, VT* __restrict__ Vl,
-                                            const double* __restrict__ Rl, int len, double a, double b, int* kout) {
-  const double twoa = 2 * a;
-  const double r1 = Rl[1 < len ? 1 : 0];
-  int k = 0, q = 1, vk = 0, nv = 0;
-  T zk = -INFINITY, nz = -INFINITY;
-  double yk = (double)YZl[0].x, ny = 0.0;
-  double r_top = r1;
-  unsigned suspect = 0;             // sticky: a quotient landed next to a float rounding boundary
-  Vl[0] = 0;
-  YZl[0].y = -INFINITY;
-  T yq_f = YZl[min(1, len - 1)].x;
-  while (q < len) {
-    // prefetches (addresses known now, values used after the arithmetic below)
-    const int k2 = max(k - 2, 0);
-    const int pv = Vl[k2];
-    const typename Pair<T>::type pyz = YZl[k2];
-    const double r_nxt = Rl[max(q - nv, 0)];   // reciprocal for the entry below the top (used if this step pops)
-    const T ynext_f = YZl[min(q + 1, len - 1)].x;
-    // intersection with the stack top
-    const int dx = q - vk;
-    const double yq = (double)yq_f;
-    const double dxd = (double)dx;
-    const double num = ((yq - yk) - b * dxd) + a * (double)__mul24(dx, q + vk);   // x1^2 - x0^2 < 2^31, operands < 2^16
-    const double den = twoa * dxd;
-    double q1;
-    if (EXACT) {
-      q1 = num / den;
-    } else {
-      const double q0 = num * r_top;
-      const double rem = __builtin_fma(-q0, den, num);
-      q1 = __builtin_fma(rem, r_top, q0);
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
-      const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
-      const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-      suspect = (((lo29 - 0x0FFFFFFFu) <= 2u) | ((ex - 897u) > 252u)) ? 1u : suspect;   // one v_cndmask
-    }
-    const T s = (T)q1;                          // `T s = f(...)` (:161): narrowed for float, kept for double
-    const bool pop = (s <= zk) && (k > 0);  // :162
-    // push stores (:166-169); slot k+1 is dead if this step pops
-    Vl[k + 1] = (VT)q;
-    { typename Pair<T>::type e; e.x = yq_f; e.y = s; YZl[k + 1] = e; }
-    // state update, selects only
-    const int vk_o = vk; const double yk_o = yk; const T zk_o = zk;
-    k = pop ? k - 1 : k + 1;
-    vk = pop ? nv : q;
-    yk = pop ? ny : yq;
-    zk = pop ? nz : s;
-    r_top = pop ? r_nxt : r1;
-    nv = pop ? pv : vk_o;
-    ny = pop ? (double)pyz.x : yk_o;
-    nz = pop ? pyz.y : zk_o;
-    yq_f = pop ? yq_f : ynext_f;
-    q = pop ? q : q + 1;
-  }
-  *kout = k;
-  return suspect != 0;
+// LDS per block: per-lane descriptors and segment tables (DT_HDR bytes), per map touched by the block a table of
+// exact reciprocals 1/(2a*dx), dx < len (double[S]), and per line {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
+// 9 bytes per line element for float: the lines resident on a CU are bounded by these bytes.
+#define DT_HDR 3072
+size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts) {   // ts = sizeof(T): (y, z) is a float or a double pair
+  return (size_t)lpb * stride * (2 * ts + (stride <= 256 ? 1 : 2)) + DT_HDR + (size_t)nmb * stride * 8 + 16;
 }
 
-// Cooperative envelope scan: LPL (2, 4, 8 or 16) adjacent lanes share one line.  Lane j of the group holds stack
-// entry k-j and evaluates the intersection of ITS entry with the current element q — exactly the value the
-// reference computes when its pop loop reaches that entry (`s = f(v[k], q, ...)` after j pops, :161-165).
-// pop_j = (s_j <= z[k-j]) && (k-j > 0); the reference pops while that holds, so the number of pops is
-// p = index of the first lane whose test fails.  p < LPL: lane p pushes q with its own s at slot k-p+1 and
-// the element is consumed — a push with up to LPL-1 pops costs ONE iteration; p == LPL: all LPL entries pop
-// and the same element meets the next LPL entries.  Same comparisons, same values, same results, about
-// one iteration per element instead of 1.5, and the extra lanes are lanes that LDS capacity leaves idle
-// anyway (a block holds 14-16 lines of 158 elements).  Loop state is just (k, q): entries are re-read
-// from the LDS stack every iteration (a wave's LDS operations are ordered; the fence keeps the compiler
-// from hoisting a lane's read above another lane's push).
-template <bool EXACT, int LPL, typename VT, typename T>
-__device__ __forceinline__ bool dt_envelope_m(typename Pair<T>::type* __restrict__ YZl, VT* __restrict__ Vl,
-                                              const double* __restrict__ Rl, int len, double a, double b, int j,
-                                              int lane, int* kout) {
-  typedef typename Pair<T>::type P2;
-  const double twoa = 2 * a;
-  const int gshift = lane & ~(LPL - 1);
-  int k = 0, q = 1;
-  unsigned suspect = 0;
-  if (j == 0) { Vl[0] = 0; YZl[0].y = -INFINITY; }
-  while (q < len) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int e = k - j, ec = max(e, 0);
-    const int v = Vl[ec];
-    const P2 yz = YZl[ec];
-    const T yq_f = YZl[q].x;
-    const int dx = q - v;
-    const double r = Rl[dx];
-    const double dxd = (double)dx;
-    const double num = (((double)yq_f - (double)yz.x) - b * dxd) + a * (double)__mul24(dx, q + v);
-    const double den = twoa * dxd;
-    double q1;
-    if (EXACT) {
-      q1 = num / den;
-    } else {
-      const double q0 = num * r;
-      const double rem = __builtin_fma(-q0, den, num);
-      q1 = __builtin_fma(rem, r, q0);
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
-      const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
-      const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-      suspect = (((lo29 - 0x0FFFFFFFu) <= 2u) | ((ex - 897u) > 252u)) ? 1u : suspect;
-    }
-    const T s = (T)q1;
-    // pop = (s <= z[k-j]) && (k-j > 0), :162 for the entry this lane holds; two ballots of plain compares
-    // ANDed as scalars (a ballot of the && goes through a select and a second compare)
-    const unsigned long long pm = __builtin_amdgcn_ballot_w64(s <= yz.y) & __builtin_amdgcn_ballot_w64(e > 0);
-    const unsigned gm = (unsigned)(pm >> gshift) & ((1u << LPL) - 1u);
-    const int p = __builtin_ctz(~gm);                                     // pops before the first failing test: 0..LPL
-    const bool push = p < LPL;
-    const int kn = push ? k - p + 1 : k - LPL;
-    if (push && j == p) {                                                 // :166-169 by the lane whose test failed
-      Vl[kn] = (VT)q;
-      P2 en; en.x = yq_f; en.y = s;
-      YZl[kn] = en;
-    }
-    k = kn;
-    q = push ? q + 1 : q;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  *kout = k;
-  return suspect != 0;
-}
-
-// One block = one wavefront = up to g.lpb lines of one group (lpb chosen per group so that every
-// block of the launch fits the same LDS budget: long lines -> fewer lines per block -> many more
-// blocks, so a whole pass is resident at once and all 4 SIMDs of every CU carry chains).
-template <typename T, typename VT>
+// One block = one wavefront = up to g.lpb lines of one group (lpb chosen per group so that every block of the
+// launch fits the same LDS budget: long lines -> fewer lines per block -> many more blocks).  LDS capacity leaves
+// most lanes of a wave without a line of their own, so the 64 / lpb lanes that share a line each scan one SEGMENT of
+// it concurrently and the segments are stitched into the sequential result (dt_core.hpp): lane = p * lpb + line.
+template <typename T, typename IT>
 __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps) {
   const int lane = threadIdx.x;
   const int len = g.len, S = g.stride, lpb = g.lpb;
-  typedef typename Pair<T>::type P2;
-  const T** lptr = (const T**)smem;   // [64] source pointer of each line of this block
-  int16_t** pptr = (int16_t**)(smem + 64 * 8);  // [64] pointer-output base of each line
-  int* pstr = (int*)(smem + 64 * 16);         // [64] pointer-output element stride of each line
-  int* Ksz = (int*)(smem + 64 * 20);          // [64] final stack size of each line
-  double* R = (double*)(smem + 64 * 24);      // [nmb][S] 1/(2a*dx) per map of this block
+  typedef DtPair<T> P2;
+  constexpr bool EX = sizeof(T) == 8;          // DistanceTransform<double>: s is not narrowed, every intersection takes the IEEE division
+  const T** lptr = (const T**)smem;            // [64] source pointer of each line of this block
+  int16_t** pptr = (int16_t**)(smem + 64 * 8); // [64] pointer-output base of each line
+  int* pstr = (int*)(smem + 64 * 16);          // [64] pointer-output element stride of each line
+  int* FLAG = (int*)(smem + 64 * 20);          // [64] per line: redo sequentially (suspect quotient / lost stitch invariant); then: segments in use
+  T* ZLO = (T*)(smem + 64 * 24);               // [64] per lane (p * lpb + line): z of the segment's lowest surviving element
+  IT* FT = (IT*)(smem + 64 * 32);              // [64] per lane: that element
+  IT* ENT = FT + 64;                           // [64] topmost surviving element of the segment (or dead)
+  double* R = (double*)(smem + DT_HDR);        // [nmb][S] 1/(2a*dx) per map of this block
+  const IT dead = (IT)~(IT)0;
   const int total = g.nmaps * g.nlines;
   const int nl = min(lpb, total - t.g0);
   const int m_first = t.g0 / g.nlines, m_last = (t.g0 + nl - 1) / g.nlines;
   const int nmb = m_last - m_first + 1;
-  P2* YZ = (P2*)(R + g.nmb * S);      // [lpb][S] .x: line values, then y of stack entries (in place); .y: z[k]
-  VT* V = (VT*)(YZ + lpb * S);                // [lpb][S] v[k]
+  P2* YZ = (P2*)(R + g.nmb * S);               // [lpb][S] .x: line values (never modified); .y: z of the element when pushed
+  IT* B = (IT*)(YZ + lpb * S);                 // [lpb][S] element below on the stack when pushed; later: element above (read-out)
   if (lane < nl) {
     const int gi = t.g0 + lane;
     const int mi = gi / g.nlines, li = gi - mi * g.nlines;
@@ -223,11 +85,14 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const bool nat = mp0.ptr_natural != 0;
     pptr[lane] = mp0.ptr + (nat ? (size_t)li * len : (size_t)li);
     pstr[lane] = nat ? 1 : g.nlines;
+    FLAG[lane] = 0;
   }
   // reciprocal tables: one IEEE division per (map, dx), spread over the 64 lanes
-  for (int ms = 0; ms < nmb; ++ms) {
-    const double a = maps[g.map0 + m_first + ms].a;
-    for (int dx = lane; dx < len; dx += 64) R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
+  if constexpr (!EX) {
+    for (int ms = 0; ms < nmb; ++ms) {
+      const double a = maps[g.map0 + m_first + ms].a;
+      for (int dx = lane; dx < len; dx += 64) R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
+    }
   }
   __syncthreads();
   DT_STAMP(1);
@@ -262,115 +127,82 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   __syncthreads();
   DT_STAMP(2);
 
-  // ---- build the upper envelope (DistanceTransform.hpp:156-170) ----
-  // lanes per line: long lines leave most lanes of the wave without a line (LDS capacity), so 4 or 2 lanes
-  // share a line (dt_envelope_m); short lines fill the wave with one lane per line (dt_envelope).
-  const int lpl = g.lpb <= 4 ? 16 : g.lpb <= 8 ? 8 : g.lpb <= 16 ? 4 : (g.lpb <= 32 ? 2 : 1);
-  auto coop = [&](auto LPLc) {
-    constexpr int LPL = decltype(LPLc)::value;
-    const int line = lane / LPL, j = lane % LPL;
-    if (line < nl) {
-      const int gi = t.g0 + line;
-      const int mi = gi / g.nlines;
-      const DtMap mp = maps[g.map0 + mi];
-      const double* Rl = R + (mi - m_first) * S;
-      P2* YZl = YZ + line * S;
-      VT* Vl = V + line * S;
-      int k;
-      if constexpr (sizeof(T) == 8) {
-        dt_envelope_m<true, LPL, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, j, lane, &k);
-      } else {
-        const bool sus = dt_envelope_m<false, LPL, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, j, lane, &k);
-        const unsigned gm = (unsigned)(__ballot(sus) >> (lane & ~(LPL - 1))) & ((1u << LPL) - 1u);
-        if (gm) {   // a quotient of this line landed next to a float rounding boundary: redo it with true divisions
-          const T* src = lptr[line];
-          for (int q = j; q < len; q += LPL) YZl[q].x = src[q];
-          dt_envelope_m<true, LPL, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, j, lane, &k);
-        }
-      }
-      if (j == 0) { YZl[k + 1].y = INFINITY; Ksz[line] = k; }
-    }
-  };
-  if (lpl == 16) coop(std::integral_constant<int, 16>());
-  else if (lpl == 8) coop(std::integral_constant<int, 8>());
-  else if (lpl == 4) coop(std::integral_constant<int, 4>());
-  else if (lpl == 2) coop(std::integral_constant<int, 2>());
-  else if (lane < nl) {
-    const int gi = t.g0 + lane;
+  const int nsub = 64 / lpb;                     // lanes per line
+  const int P = dt_segments(nsub, len);          // segments per line
+  const int line = lane % lpb, p = lane / lpb;
+  const bool mine = line < nl && p < nsub;
+  DtMap mp;
+  const double* Rl = R;
+  P2* YZl = YZ + line * S;
+  IT* Bl = B + line * S;
+  if (mine) {
+    const int gi = t.g0 + line;
     const int mi = gi / g.nlines;
-    const DtMap mp = maps[g.map0 + mi];
-    const double* Rl = R + (mi - m_first) * S;
-    P2* YZl = YZ + lane * S;
-    VT* Vl = V + lane * S;
-    int k;
-    if constexpr (sizeof(T) == 8) {
-      // DistanceTransform<double>: s is not narrowed, so every intersection takes the IEEE division
-      dt_envelope<true, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, &k);
-    } else if (dt_envelope<false, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, &k)) {
-      // a quotient landed within 1 ulp of a float rounding boundary: redo this line with true divisions
-      const T* src = lptr[lane];
-      for (int q = 0; q < len; ++q) YZl[q].x = src[q];
-      dt_envelope<true, VT, T>(YZl, Vl, Rl, len, mp.a, mp.b, &k);
-    }
-    YZl[k + 1].y = INFINITY;
-    Ksz[lane] = k;
+    mp = maps[g.map0 + mi];
+    Rl = R + (mi - m_first) * S;
+  }
+  // ---- local scans: the envelope of every segment (DistanceTransform.hpp:156-170 on the segment alone) ----
+  if (mine && p < P) {
+    if (dt_seg_scan<EX, T, IT>(YZl, Bl, Rl, dt_seg_start(p, P, len), dt_seg_start(p + 1, P, len), mp.a, mp.b)) FLAG[line] = 1;
   }
   __syncthreads();
   DT_STAMP(3);
+  // ---- stitch the segments into the sequential result; one lane per line ----
+  if (mine && p == 0) {
+    bool redo = FLAG[line] != 0;
+    if (!redo && P > 1) redo = dt_stitch<EX, T, IT>(YZl, Bl, Rl, len, P, mp.a, mp.b, FT + line, lpb);
+    int Pl = P;
+    if (redo) DT_COUNT_REDO();
+    if (redo) {   // a quotient next to a float rounding boundary, or near-degenerate geometry: the whole line sequentially, IEEE divisions
+      dt_seg_scan<true, T, IT>(YZl, Bl, Rl, 0, len, mp.a, mp.b);
+      Pl = 1;
+    }
+    FT[line] = (IT)0;
+    dt_seg_table<T, IT>(YZl, Bl, len, Pl, FT + line, ENT + line, ZLO + line, lpb, dead);
+    FLAG[line] = Pl;                             // segments the read-out lanes look at
+  }
+  __syncthreads();
+  DT_STAMP(6);
+  DT_STAMP(4);
 
   // ---- read out (:172-178) ----
-  // Output q of a line depends only on the finished stack, so the 64/lpb idle lane groups share a
-  // line: sub-range r of the outputs starts from a binary search for its first stack entry.
-  // Scores go out transposed (lanes of one sub-range = consecutive lines -> coalesced); pointers go
-  // straight to their plane: transposed like the scores in the y pass, natural (2-byte runs per lane,
-  // merged in L2) in the x pass — no LDS staging, that space holds more lines instead.
-  {
-    const int nsub = 64 / lpb;
-    const int line = lane % lpb, sub = lane / lpb;
-    if (line < nl && sub < nsub) {
-      const int gi = t.g0 + line;
-      const int mi = gi / g.nlines, li = gi - mi * g.nlines;
-      const DtMap mp = maps[g.map0 + mi];
-      const double a = mp.a, b = mp.b;
-      const P2* YZl = YZ + line * S;
-      const VT* Vl = V + line * S;
-      int16_t* pp = pptr[line];
-      const int pst = pstr[line];
-      const int K = Ksz[line];
-      const int chunk = (len + nsub - 1) / nsub;
-      const int q0 = sub * chunk, q1 = min(len, q0 + chunk);
-      if (q0 < q1) {
-        int os = mp.os + q0;
-        // first k with !(z[k+1] < os): z is strictly increasing, z[K+1] = +inf
-        int lo = 0, hi = K;
-        const T f0 = (T)os;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (YZl[mid + 1].y < f0) lo = mid + 1; else hi = mid;
-        }
-        int k = lo;
-        int vk = Vl[k];
-        T yk = YZl[k].x;
-        // the piece after the current one is kept in registers (its y and z are one LDS word), so stepping to it
-        // costs no LDS round trip on the spot: the read of the piece after THAT overlaps this output's arithmetic
-        P2 nyz = YZl[k + 1];                     // (y[k+1], z[k+1]); z[K+1] = +inf ends the walk, slots up to K+2 exist
-        int nv = Vl[k + 1];
-        const int nlines = g.nlines;
-        T* dp = (T*)mp.dst + li + (size_t)q0 * nlines;      // running output pointers: no 64-bit multiply per element
-        int16_t* ppq = pp + (size_t)q0 * pst;
-        for (int q = q0; q < q1; ++q) {
-          const T fos = (T)os;                   // `z[k+1] < os`: int promoted to T (:174)
-          while (nyz.y < fos) { k++; vk = nv; yk = nyz.x; nyz = YZl[k + 1]; nv = Vl[k + 1]; }
-          const int d = os - vk;
-          *dp = (T)(a * (double)__mul24(d, d) + b * (double)d + (double)yk);   // |d| < 2^15
-          *ppq = (int16_t)vk;
-          dp += nlines; ppq += pst;
-          os++;
-        }
+  // Output q of a line depends only on the finished stack, so the 64/lpb lanes of a line each take a sub-range of
+  // the outputs, all sub-ranges stepping q in lockstep — downwards, along the "below" links: scores go out
+  // transposed (lanes of one sub-range = consecutive lines -> coalesced); pointers go straight to their plane:
+  // transposed like the scores in the y pass, natural (2-byte runs per lane, merged in L2) in the x pass — no
+  // LDS staging, that space holds more lines.
+  if (mine) {
+    const int gi = t.g0 + line;
+    const int mi = gi / g.nlines, li = gi - mi * g.nlines;
+    const double a = mp.a, b = mp.b;
+    int16_t* pp = pptr[line];
+    const int pst = pstr[line];
+    const int chunk = (len + nsub - 1) / nsub;
+    const int q0 = p * chunk, q1 = min(len, q0 + chunk);
+    if (q0 < q1) {
+      int os = mp.os + q1 - 1;
+      int e = dt_cover<T, IT>(YZl, Bl, FLAG[line], ENT + line, ZLO + line, lpb, dead, os);
+      P2 eyz = YZl[e];
+      // the piece below the current one is kept in registers, so stepping to it costs no LDS round trip on the
+      // spot: the read of the piece below THAT overlaps this output's arithmetic.  The bottom of the stack
+      // (z = -inf, linked to itself) ends every walk.
+      int nx = (int)Bl[e];
+      P2 nyz = YZl[nx];
+      int nnx = (int)Bl[nx];
+      const int nlines = g.nlines;
+      T* dp = (T*)mp.dst + li + (size_t)(q1 - 1) * nlines;      // running output pointers: no 64-bit multiply per element
+      int16_t* ppq = pp + (size_t)(q1 - 1) * pst;
+      for (int q = q1 - 1; q >= q0; --q) {
+        const T fos = (T)os;                   // `z[k+1] < os`: int promoted to T (:174)
+        while (!(eyz.y < fos)) { e = nx; eyz = nyz; nx = nnx; nyz = YZl[nx]; nnx = (int)Bl[nx]; }
+        const int d = os - e;
+        *dp = (T)(a * (double)__mul24(d, d) + b * (double)d + (double)eyz.x);   // |d| < 2^15
+        *ppq = (int16_t)e;
+        dp -= nlines; ppq -= pst;
+        os--;
       }
     }
   }
-  DT_STAMP(4);
   DT_STAMP(5);
 }
 
@@ -381,6 +213,12 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
   DT_STAMP(0);
   const DtTask t = tasks[blockIdx.x];
   const DtGroup g = groups[t.group];
+  // A pass lasts as long as its longest lines (level 0: one residency round of the whole chip), and a block
+  // shares its SIMD with one other block, usually of a smaller level that has slack: the long-line blocks take
+  // the issue slots first (g.prio: 3 for the longest lines of the launch ... 0 for lines under half of that).
+  if (g.prio == 3) __builtin_amdgcn_s_setprio(3);
+  else if (g.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (g.prio == 1) __builtin_amdgcn_s_setprio(1);
   if (g.stride <= 256) dt_block<T, unsigned char>(smem, t, g, maps);    // stack indices < 255 fit a byte
   else dt_block<T, unsigned short>(smem, t, g, maps);
 }

@@ -329,12 +329,11 @@ static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (
 static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget, int ts) {
   int lpb = 64;
   while (lpb > 4 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts) > budget) --lpb;
-  // the kernel shares a line between 4 lanes when lpb <= 16 and 2 lanes when lpb <= 32 (dt_envelope_m):
-  // just above those thresholds a few lines fewer per block buy twice the lanes per line
-  static const int snap4 = PBD_PROBE_ENV("PBD_DT_SNAP4") ? atoi(PBD_PROBE_ENV("PBD_DT_SNAP4")) : 24;   // probe-build knobs
-  static const int snap2 = PBD_PROBE_ENV("PBD_DT_SNAP2") ? atoi(PBD_PROBE_ENV("PBD_DT_SNAP2")) : 40;
-  if (lpb > 16 && lpb <= snap4) lpb = 16;
-  else if (lpb > 32 && lpb <= snap2) lpb = 32;
+  // the 64 / lpb lanes that share a line scan one segment of it each (dt_core.hpp): a pass lasts as long as its
+  // longest line, so take the lane count the budget allows, rounded UP (P = ceil(64 / lpb) segments), and give
+  // the block the lines that fills the wave with (lpb = 64 / P) — a few lines fewer per block, a shorter scan
+  static const int snap = PBD_PROBE_ENV("PBD_DT_SNAP") ? atoi(PBD_PROBE_ENV("PBD_DT_SNAP")) : 1;   // probe-build knob
+  if (snap && lpb < 64) lpb = 64 / ((64 + lpb - 1) / lpb);
   return lpb;
 }
 static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts) {
@@ -568,6 +567,11 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     h->grl[grp].push_back(R);
     if (grp == h->ngroups - 1) slot_init = slot_w;
     }  // groups
+  }
+  {  // issue priority of a group's blocks: by line length relative to the frame's longest line
+    static const int prio_on = PBD_PROBE_ENV("PBD_DT_PRIO") ? atoi(PBD_PROBE_ENV("PBD_DT_PRIO")) : 1;
+    for (DtGroup& g : groups)
+      g.prio = !prio_on ? 0 : (g.len * 8 >= maxlen * 7) ? 3 : (g.len * 4 >= maxlen * 3) ? 2 : (g.len * 2 >= maxlen) ? 1 : 0;
   }
   h->dtw_lds = wave_maxlen ? dtw_lds_bytes(wave_maxlen) : 0;
   if (h->dtw_lds > 160 * 1024 || wave_maxlen > 512) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the wave-per-line distance transform");

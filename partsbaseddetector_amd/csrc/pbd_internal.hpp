@@ -61,7 +61,7 @@ struct DtMap {       // one 1-D pass over one score map
   double a, b;       // Quadratic(a, b)
   int os, ptr_natural;  // ptr_natural: write ptr row-major [line][q] instead of transposed
 };
-struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, nmb, pad; };  // stride: LDS elements per line (even); lpb: lines per block; nmb: max maps a block touches
+struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, nmb, prio; };  // stride: LDS elements per line (even); lpb: lines per block; nmb: max maps a block touches; prio: s_setprio of the group's blocks (long lines first)
 struct DtTask { int group, g0; };
 
 #define PBD_MAX_CH 8   // children of one parent folded into one reduce job

@@ -16,6 +16,7 @@ for (r, c) in [(8, 10), (118, 158), (118, 158), (16, 158), (158, 16), (64, 64)]:
     h.dt2d(a, -0.01, 0.001, -0.02, -0.002, 1, -1)
     st = (C.c_ulonglong * 8)()
     L.pbd_debug_dt_stamps(st)
-    d = [(st[i + 1] - st[i]) / 100.0 for i in range(5)]
-    print(f"{r}x{c} y-pass block0 phases us: setup+rtable {d[0]:.1f} load {d[1]:.1f} envelope {d[2]:.1f} readout {d[3]:.1f} ptrs {d[4]:.1f}", flush=True)
+    us = lambda a, b: (st[b] - st[a]) / 100.0
+    print(f"{r}x{c} y-pass block0 phases us: setup+rtable {us(0, 1):.1f} load {us(1, 2):.1f} segment scans {us(2, 3):.1f} "
+          f"stitch+table {us(3, 6):.1f} phase A {us(6, 4):.1f} read-out {us(4, 5):.1f}; lines redone sequentially: {st[7]}", flush=True)
 h.close()
