@@ -54,12 +54,14 @@ template <> struct Pair<double> { typedef double2 type; };
 //   num = ((y1 - y0) - b*(x1-x0)) + a*(x1^2 - x0^2)      (same fp64 operations, same order)
 //   s   = (float)(num / den),  den = (2a)*(x1-x0)
 // EXACT = false: the fp64 division (14 dependent instructions, four of them quarter rate) is
-// replaced by a multiplication with the exact reciprocal r = RN(1/den) from the per-map table plus
-// one fma residual correction; q1 is within 1 ulp of RN(num/den), so (float)q1 can differ from
-// (float)RN(num/den) only if a float rounding boundary lies within 1 ulp of q1 (low 29 mantissa
-// bits in 0x0FFFFFFF..0x10000001) or the value leaves the normal float range.  Those cases
-// (~1e-8 of all evaluations) set a sticky flag and the whole line is redone with EXACT = true
-// (true IEEE division), so the result is always bit-identical to the reference's.
+// replaced by ONE multiplication with the correctly rounded reciprocal r = RN(1/den) from the per-map
+// table: q1 = RN(num * r) carries two roundings (r, the product), so |q1 - num/den| <= (2u + u^2)|num/den|
+// and q1 lies within 3 ulp of the reference's RN(num/den).  (float)q1 can therefore differ from
+// (float)RN(num/den) only if a float rounding boundary (a double whose low 29 mantissa bits are
+// 0x10000000) lies within 3 ulp of q1 — low 29 bits in 0x0FFFFFFC..0x10000004 are flagged, one ulp of
+// slack — or the value leaves the normal float range.  Those cases (~2e-8 of all evaluations) set a
+// sticky flag and the whole line is redone with EXACT = true (true IEEE division), so the result is
+// always bit-identical to the reference's.
 //
 // The reference's nested loops (for q { while (pop) }) are flattened into a state machine doing
 // exactly one intersection per iteration: lanes never wait for the slowest lane's pop count and
@@ -100,13 +102,11 @@ __device__ __forceinline__ bool dt_envelope(typename Pair<T>::type* __restrict__
     if (EXACT) {
       q1 = num / den;
     } else {
-      const double q0 = num * r_top;
-      const double rem = __builtin_fma(-q0, den, num);
-      q1 = __builtin_fma(rem, r_top, q0);
+      q1 = num * r_top;                 // within 3 ulp of RN(num/den): |r - 1/den| <= u/den, one more rounding
       const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
       const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
       const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-      suspect = (((lo29 - 0x0FFFFFFFu) <= 2u) | ((ex - 897u) > 252u)) ? 1u : suspect;   // one v_cndmask
+      suspect = (((lo29 - 0x0FFFFFFCu) <= 8u) | ((ex - 897u) > 252u)) ? 1u : suspect;   // one v_cndmask
     }
     const T s = (T)q1;                          // `T s = f(...)` (:161): narrowed for float, kept for double
     const bool pop = (s <= zk) && (k > 0);  // :162
@@ -166,13 +166,11 @@ __device__ __forceinline__ bool dt_envelope_m(typename Pair<T>::type* __restrict
     if (EXACT) {
       q1 = num / den;
     } else {
-      const double q0 = num * r;
-      const double rem = __builtin_fma(-q0, den, num);
-      q1 = __builtin_fma(rem, r, q0);
+      q1 = num * r;
       const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
       const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
       const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-      suspect = (((lo29 - 0x0FFFFFFFu) <= 2u) | ((ex - 897u) > 252u)) ? 1u : suspect;
+      suspect = (((lo29 - 0x0FFFFFFCu) <= 8u) | ((ex - 897u) > 252u)) ? 1u : suspect;
     }
     const T s = (T)q1;
     // pop = (s <= z[k-j]) && (k-j > 0), :162 for the entry this lane holds; two ballots of plain compares
