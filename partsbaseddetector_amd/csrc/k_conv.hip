@@ -488,6 +488,15 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   struct alignas(16) V { T e[EPV]; };
   T* ft = (T*)smem;                         // [TH][TW][CS]
   CONV_STAMP(0);
+#ifdef PBD_PROBES
+  {  // probe: issue priority by workgroup index, to pull co-resident workgroups out of phase
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const int mode = nfpad >> 16;
+    const unsigned pr = mode == 1 ? (lin & 3u) : mode == 2 ? ((lin >> 8) & 3u) : mode == 3 ? ((lin >> 3) & 3u) : mode == 4 ? ((lin >> 10) & 3u) : mode == 5 ? (blockIdx.y & 3u) : 0u;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
+  nfpad &= 0xffff;
+#endif
   const ConvTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const int H = lv.ch, W = lv.cw;
@@ -614,7 +623,8 @@ static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelD
   static LdsOptIn optin;   // one per instantiation
   optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>, lds);
   dim3 grid(ntiles, (nf + 16 * NTW - 1) / (16 * NTW));
-  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
+  static const int prio_mode = PBD_PROBE_ENV("PBD_CONV_PRIO") ? atoi(PBD_PROBE_ENV("PBD_CONV_PRIO")) : 0;   // probe build only
+  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16));
 }
 
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,

@@ -875,3 +875,29 @@ def test_inactive_level_getters_refuse(gpu_required):
             fn()
         assert e.value.code == capi.PBD_ERR_STATE
     h.close()
+
+
+def test_graph_replay_equals_eager(gpu_required, orc):
+    """pbd_options.graph: the frame's launches captured once per geometry and replayed — several frames (different
+    images, host and device-resident entry points), a geometry change in between (re-plan, re-capture), all equal to
+    the oracle like the eager path."""
+    import torch
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    ims = [make_image(i, 200, 150) for i in range(4)]
+    m.thresh = thresh_from_oracle(orc, m, ims[0], 99.3)
+    refs = [orc.detect(m, im)[:3] for im in ims]
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, graph=1)
+    for rep in range(2):
+        for im, ref in zip(ims, refs):                 # frame 0 eager, frame 1 captured, then replays
+            assert_candidates_equal(h.detect(im), ref)
+    d_im = torch.from_numpy(ims[2]).cuda()
+    torch.cuda.synchronize()
+    assert_candidates_equal(h.detect_dev(d_im.data_ptr(), 200, 150, 3), refs[2])
+    big = make_image(9, 260, 190)                      # geometry change: the graph is dropped with the plan
+    for _ in range(3):
+        assert_candidates_equal(h.detect(big), orc.detect(m, big)[:3])
+    assert_candidates_equal(h.detect(ims[1]), refs[1])
+    h.set_profiling(True)                              # profiling runs go through the eager path
+    assert_candidates_equal(h.detect(ims[3]), refs[3])
+    assert h.stage_ms()["total"] > 0
+    h.close()
