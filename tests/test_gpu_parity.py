@@ -421,6 +421,21 @@ def test_person_1080p_plan_and_run(gpu_required):
     h.close()
 
 
+def _tables_checksum(orc, model, im, dtype=np.float32):
+    """Position-weighted checksum of the oracle's Ix / Iy / Ik tables in the order host/demo.cpp walks them."""
+    fr = orc.detect(model, im, capacity=1, keep=True, dtype=dtype)[4]
+    planes = sum(len(model.filterid[c][model.parentid[c][p]]) for c in range(model.ncomponents) for p in range(1, model.nparts(c)))
+    parts = []
+    for l in range(fr.nlevels):
+        Ix, Iy, Ik = fr.pointers(l, planes)
+        for pl in range(planes):
+            parts += [Ix[pl].ravel(), Iy[pl].ravel(), Ik[pl].ravel()]
+    fr.free()
+    v = np.concatenate(parts).astype(np.int64).astype(np.uint32).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        return int(np.sum((np.arange(len(v), dtype=np.uint64) + np.uint64(1)) * v, dtype=np.uint64))
+
+
 def test_cpp_host_demo_matches_oracle(gpu_required, orc, tmp_path):
     """The C++ host layer (partsbaseddetector_amd/host: pbd::PartsBasedDetector<float> etc.) driven by
     the reference's demo call sequence (src/demo.cpp:64-111), fused and stage by stage."""
@@ -440,6 +455,10 @@ def test_cpp_host_demo_matches_oracle(gpu_required, orc, tmp_path):
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         lines = out.stdout.strip().splitlines()
+        if extra:   # stage by stage through the reference's min()/argmin() signatures: the Ix / Iy / Ik tables they return
+            assert lines[0].startswith("Tables: ")
+            assert int(lines[0].split()[1]) == _tables_checksum(orc, m, im), "pointer tables differ from the oracle's"
+            lines = lines[1:]
         assert lines[0] == f"Number of candidates: {len(heads)}"
         assert len(lines) == 1 + len(heads)
         for ln, h, b in zip(lines[1:], heads, boxes):
