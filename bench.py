@@ -97,6 +97,7 @@ def main():
                          "ranks work on the SAME frames, each on an LPT-balanced set of pyramid levels (strong scaling, "
                          "BASELINE configs[3]: use with --width 1920 --height 1080)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("PBD_GRAPH", "1")), help="pbd_options.graph: replay a captured hipGraph per frame")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU-side smoke runs)")
     args = ap.parse_args()
@@ -137,7 +138,7 @@ def main():
 
     S = max(1, args.inflight)
     cap = 4096 if W * H <= 640 * 480 else 32768      # the 99.9th-percentile threshold scales the count with the area
-    handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=cap, dtype=dtype) for _ in range(S)]
+    handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=cap, dtype=dtype, graph=args.graph) for _ in range(S)]
     if by_levels:   # SURVEY 8e / configs[3]: one frame, levels spread over the ranks by greedy LPT on the cell counts
         from partsbaseddetector_amd.parallel import shard_levels_lpt
         g = handles[0].geometry(W, H)
@@ -269,6 +270,7 @@ def main():
                                    f"{W}x{H} BGR, full pyramid ({hd.geometry(W, H)['nlevels']} levels), "
                                    f"threshold = 99.9th pct of root scores",
                        "frames_per_step_per_gpu": 1, "inflight": S, "conv": args.conv, "input": "frames resident in HBM",
+                       "launch": "hipGraph replay (one hipGraphLaunch per frame)" if args.graph else "eager (~40 launches per frame)",
                        "prewarm_s": 0.0 if args.no_prewarm else PREWARM_S, "prewarm_frames": prewarm_frames,
                        "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}")},
             "frame_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),

@@ -102,6 +102,8 @@ typedef struct pbd_options {
   int32_t scalar_type;   /* PBD_SCALAR_F32 (default) or PBD_SCALAR_F64; a double
                             handle answers the *_f64 stage entry points
                             instead of the float ones                          */
+  int32_t graph;         /* 1: capture the ~40 launches of a frame into a hipGraph once per frame geometry and
+                            replay it (one hipGraphLaunch per frame instead of ~40 launches); 0: eager launches */
   int32_t reserved[2];   /* [0]: DP level groups on separate streams (0/1 = one chain, max 3)
                             [1]: distance transform kernel: 0/1 lane-per-line (default), 2 the
                                  experimental wave-per-line kernel (lines <= 512 elements)          */

@@ -42,7 +42,7 @@ EXPORTS = [
 class pbd_options(C.Structure):
     _fields_ = [("device", C.c_int32), ("conv_mode", C.c_int32), ("max_candidates", C.c_int32),
                 ("dt_correct_ptr", C.c_int32), ("level_begin", C.c_int32), ("level_end", C.c_int32),
-                ("scalar_type", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("scalar_type", C.c_int32), ("graph", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class pbd_candidate_head(C.Structure):
@@ -88,7 +88,7 @@ class Handle:
     """Owns one pbd_handle (one GPU, one stream)."""
 
     def __init__(self, model, device=0, conv_mode=PBD_CONV_AUTO, max_candidates=4096, dt_correct_ptr=0,
-                 level_begin=0, level_end=0, dp_groups=0, dt_mode=0, dtype=np.float32):
+                 level_begin=0, level_end=0, dp_groups=0, dt_mode=0, dtype=np.float32, graph=0):
         """dtype: np.float32 = PartsBasedDetector<float>, np.float64 = PartsBasedDetector<double>."""
         self.L = lib()
         self.model = model
@@ -99,7 +99,7 @@ class Handle:
         self._f64 = self.dtype == np.dtype(np.float64)
         self._ct = C.c_double if self._f64 else C.c_float
         opt = pbd_options(device, conv_mode, max_candidates, dt_correct_ptr, level_begin, level_end,
-                          PBD_SCALAR_F64 if self._f64 else PBD_SCALAR_F32, (C.c_int32 * 2)(dp_groups, dt_mode))
+                          PBD_SCALAR_F64 if self._f64 else PBD_SCALAR_F32, graph, (C.c_int32 * 2)(dp_groups, dt_mode))
         self.h = C.c_void_p()
         rc = self.L.pbd_create(C.byref(self.desc), C.byref(opt), C.byref(self.h))
         if rc != PBD_OK:
@@ -334,12 +334,12 @@ class Group:
     """pbd_group: one process driving several GPUs (include/pbd_c.h).  devices may repeat an ordinal."""
 
     def __init__(self, model, devices, gather=PBD_GATHER_AUTO, conv_mode=PBD_CONV_AUTO, max_candidates=4096,
-                 dtype=np.float32):
+                 dtype=np.float32, graph=0):
         self.L = lib()
         self.model = model
         self.desc = model.to_desc()
         f64 = np.dtype(dtype) == np.dtype(np.float64)
-        opt = pbd_options(0, conv_mode, max_candidates, 0, 0, 0, PBD_SCALAR_F64 if f64 else PBD_SCALAR_F32,
+        opt = pbd_options(0, conv_mode, max_candidates, 0, 0, 0, PBD_SCALAR_F64 if f64 else PBD_SCALAR_F32, graph,
                           (C.c_int32 * 2)(0, 0))
         dv = np.ascontiguousarray(list(devices), np.int32)
         self.g = C.c_void_p()

@@ -475,7 +475,7 @@ template <> struct Mfma16<float> {
   static __device__ __forceinline__ int drow(int reg, int ak) { return 4 * ak + reg; }
 };
 
-template <typename T, int KH, int KW, int NHALF, int WPE>   // WPE: waves per SIMD the register allocation must allow
+template <typename T, int KH, int KW, int NHALF, int WPE, int NTW = 1>   // WPE: waves per SIMD the register allocation must allow; NTW: 16-filter n-tiles per workgroup
 __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __restrict__ tiles,
                                                      const LevelDev* __restrict__ levels,
                                                      const T* __restrict__ feat, const T* __restrict__ wT,
@@ -488,19 +488,30 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   struct alignas(16) V { T e[EPV]; };
   T* ft = (T*)smem;                         // [TH][TW][CS]
   CONV_STAMP(0);
+#ifdef PBD_PROBES
+  {  // probe: issue priority by workgroup index, to pull co-resident workgroups out of phase
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const int mode = nfpad >> 16;
+    const unsigned pr = mode == 1 ? (lin & 3u) : mode == 2 ? ((lin >> 8) & 3u) : mode == 3 ? ((lin >> 3) & 3u) : mode == 4 ? ((lin >> 10) & 3u) : mode == 5 ? (blockIdx.y & 3u) : 0u;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
+  nfpad &= 0xffff;
+#endif
   const ConvTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const int H = lv.ch, W = lv.cw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nbase = blockIdx.y * 16;
+  const int nbase = blockIdx.y * (16 * NTW);
   const T* F = feat + lv.cell_off * PBD_FLEN;
   const int ai = lane & 15, ak = lane >> 4;
-  const T* bsrc = wT + (size_t)ak * nfpad + nbase + ai;     // B[k = ak][j = ai] of k-step 0, tap 0, half 0
-  typename MM::acc_t acc[4];
+  const T* bsrc = wT + (size_t)ak * nfpad + nbase + ai;     // B[k = ak][j = ai] of k-step 0, tap 0, half 0, n-tile 0 (n-tile nt: + 16 nt)
+  typename MM::acc_t acc[NTW][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[m][r] = (T)0;
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[nt][m][r] = (T)0;
   const T* abase = ft + ((4 * wave) * TW + ai) * CS + ak;   // M-tile m adds m*TW*CS
   const int mvalid = __builtin_amdgcn_readfirstlane(min(max(H - (t.y0 + 4 * wave), 0), 4));   // M-tiles (= cell rows) of this wave inside the level
 
@@ -508,9 +519,11 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   for (int half = 0; half < NHALF; ++half) {
     if (half) __syncthreads();
     const T* bh = bsrc + (size_t)(half * CH) * nfpad;
-    T b0[KS], b1[KS];
+    T b0[NTW][KS], b1[NTW][KS];
 #pragma unroll
-    for (int u = 0; u < KS; ++u) b0[u] = bh[(size_t)(4 * u) * nfpad];   // tap 0, issued before the staging
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int u = 0; u < KS; ++u) b0[nt][u] = bh[(size_t)(4 * u) * nfpad + 16 * nt];   // tap 0, issued before the staging
     {  // stage CH channels of every cell: LPC lanes x 16 B per cell, batches of independent loads
       constexpr int N = TH * TW * LPC, NB = (N + 255) / 256, BATCH = 7;
       for (int j0 = 0; j0 < NB; j0 += BATCH) {
@@ -541,19 +554,26 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
     }
     __syncthreads();
     CONV_STAMP(1 + 2 * half);
-    auto load_tap = [&](T (&dst)[KS], int tap) {
+    auto load_tap = [&](T (&dst)[NTW][KS], int tap) {
       const T* bs = bh + (size_t)min(tap, NTAP - 1) * PBD_FLEN * nfpad;
 #pragma unroll
-      for (int u = 0; u < KS; ++u) dst[u] = bs[(size_t)(4 * u) * nfpad];
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int u = 0; u < KS; ++u) dst[nt][u] = bs[(size_t)(4 * u) * nfpad + 16 * nt];
     };
-    auto mma_tap = [&](const T (&bw)[KS], int tap) {
+    auto mma_tap = [&](const T (&bw)[NTW][KS], int tap) {
       const int ti = tap / KW, tj = tap - ti * KW;
       const T* a = abase + (ti * TW + tj) * CS;
 #pragma unroll
       for (int u = 0; u < KS; ++u) {
+        T av[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (m < mvalid) acc[m] = MM::mma(a[m * TW * CS + 4 * u], bw[u], acc[m]);   // wave-uniform: rows past the level's last row do no MFMA work
+        for (int m = 0; m < 4; ++m) av[m] = a[m * TW * CS + 4 * u];    // one A element per M-tile, shared by the workgroup's n-tiles
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            if (m < mvalid) acc[nt][m] = MM::mma(av[m], bw[nt][u], acc[nt][m]);   // wave-uniform: rows past the level's last row do no MFMA work
       }
     };
     auto tap_pair = [&](int tap) {
@@ -564,7 +584,7 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
         mma_tap(b1, tap + 1);
       }
     };
-    if constexpr (NHALF == 1) {
+    if constexpr (NHALF == 1 && NTW == 1) {
       for (int tap = 0; tap < NTAP; tap += 2) tap_pair(tap);
     } else {   // with half the k-steps per tap hipcc would unroll all taps and run out of registers
       _Pragma("unroll 1") for (int tap = 0; tap < NTAP; tap += 2) tap_pair(tap);
@@ -573,31 +593,38 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   }
   __syncthreads();  // all waves are done reading the feature tile: reuse it for the epilogue
   CONV_STAMP(5);
-  // Epilogue: transpose the wave's 64-cell x 16-filter slab through LDS so lanes run along cells.
+  // Epilogue: transpose the wave's 64-cell x 16-filter slab of each n-tile through LDS so lanes run along cells
+  // (a store instruction then writes whole 64-B row segments of one response plane).  The slab is private to the
+  // wave and a wave's LDS operations execute in order, so the n-tiles simply follow each other.
   T* R = resp + lv.cell_off * nf;
   T* tr = ft + wave * (16 * 65);           // per-wave [16 filters][64 cells + 1]
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tr[ai * 65 + m * 16 + MM::drow(r, ak)] = acc[m][r];   // D[i][j = ai] of M-tile m
-  __syncthreads();
   const int py = t.y0 + 4 * wave + (lane >> 4), pxx = t.x0 + (lane & 15);
   const bool pvalid = (py < H && pxx < W);
-  for (int j = 0; j < 16; ++j) {
-    const int fn = nbase + j;
-    if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[j * 65 + lane];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tr[ai * 65 + m * 16 + MM::drow(r, ak)] = acc[nt][m][r];   // D[i][j = ai] of M-tile m
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int j = 0; j < 16; ++j) {
+      const int fn = nbase + 16 * nt + j;
+      if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[j * 65 + lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   CONV_STAMP(6);
 }
 
-template <typename T, int NHALF, int WPE>
+template <typename T, int NHALF, int WPE, int NTW = 1>
 static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
                                  const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
   const size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + 1), sizeof(T) * 4 * 16 * 65);
   static LdsOptIn optin;   // one per instantiation
-  optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE>, lds);
-  dim3 grid(ntiles, (nf + 15) / 16);
-  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad);
+  optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>, lds);
+  dim3 grid(ntiles, (nf + 16 * NTW - 1) / (16 * NTW));
+  static const int prio_mode = PBD_PROBE_ENV("PBD_CONV_PRIO") ? atoi(PBD_PROBE_ENV("PBD_CONV_PRIO")) : 0;   // probe build only
+  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16));
 }
 
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
@@ -623,7 +650,10 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                             const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s) {
   if (ntiles <= 0) return;
-  if (nhalf == 2) launch_conv_mfma16_t<float, 2, 5>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
+  if (nhalf == 5) launch_conv_mfma16_t<float, 2, 3, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);        // two n-tiles (32 filters) per workgroup
+  else if (nhalf == 6) launch_conv_mfma16_t<float, 2, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
+  else if (nhalf == 7) launch_conv_mfma16_t<float, 1, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);   // whole tile, 32 filters
+  else if (nhalf == 2) launch_conv_mfma16_t<float, 2, 5>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 3) launch_conv_mfma16_t<float, 2, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 4) launch_conv_mfma16_t<float, 4, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else launch_conv_mfma16_t<float, 1, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);

@@ -314,6 +314,8 @@ static int dev_upload(pbd_handle* h, T** p, const std::vector<T>& v) {
 }
 
 static void free_frame(pbd_handle* h) {
+  if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // the captured launches point into the buffers freed below
+  h->frames_on_plan = 0;
   for (void* p : h->frame_allocs) hipFree(p);
   h->frame_allocs.clear();
   h->fw = h->fh = h->fcn = 0;
@@ -676,7 +678,8 @@ static int run_pdf(pbd_handle* h) {
 }
 
 static int run_dp_min(pbd_handle* h) {
-  if (h->dp_timer_on) hipEventRecord(h->ev_dp0, h->stream);
+  const bool dpt = h->profiling && h->dp_timer_on;
+  if (dpt) hipEventRecord(h->ev_dp0, h->stream);
   // optional fork: every level group runs its chain of rounds on its own stream
   if (h->ngroups > 1) hipEventRecord(h->ev_fork, h->stream);
   if (h->ngroups == 1) {  // default: one chain of rounds on the handle's stream
@@ -706,7 +709,8 @@ static int run_dp_min(pbd_handle* h) {
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
   launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
               h->opt.max_candidates, h->ts, h->stream);
-  if (h->dp_timer_on) hipEventRecord(h->ev_dp1, h->stream);
+  if (dpt) hipEventRecord(h->ev_dp1, h->stream);
+  h->dp_timed = dpt;
   LAUNCHCHK(h, "DP min");
   h->have_dp = true;
   return PBD_OK;
@@ -736,7 +740,7 @@ static int run_argmin_enqueue(pbd_handle* h) {
 // `found` = the device-side count (h_cand_count[0], or the count a group gather delivered).
 int pbd_i_finish_frame(pbd_handle* h, int found) {
   h->pending = false;
-  if (h->dp_timer_on && h->have_dp) {
+  if (h->dp_timed && h->have_dp) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, h->ev_dp0, h->ev_dp1) == hipSuccess) { h->dp_ms_sum += ms; h->dp_frames++; }
   }
@@ -798,7 +802,7 @@ int pbd_i_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int3
 
 static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride);
 int pbd_i_enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) { return enqueue_all(h, d_src, stride); }
-static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
+static int enqueue_stages(pbd_handle* h, const uint8_t* d_src, int stride) {
   int rc;
   const bool prof = h->profiling;
   if (prof) hipEventRecord(h->ev[0], h->stream);
@@ -812,6 +816,42 @@ static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
   if (prof) hipEventRecord(h->ev[4], h->stream);
   if ((rc = run_argmin_enqueue(h))) return rc;
   if (prof) hipEventRecord(h->ev[5], h->stream);
+  return PBD_OK;
+}
+
+// A frame is ~40 launches whose arguments depend only on the frame geometry (the work tables are built once per
+// geometry): with pbd_options.graph the second frame of a geometry is captured into a hipGraph (the first one
+// runs eagerly: it also does the one-time per-device kernel attribute set-up, which is not a stream operation)
+// and every later frame is ONE hipGraphLaunch.  The graph reads the frame from the handle's own image buffer, so
+// an image that lives elsewhere in HBM is copied there first (0.9 MB, on the same stream).  Profiling runs (stage
+// events) and level groups on extra streams use the eager path.
+static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
+  const bool graphable = h->opt.graph && !h->profiling && h->ngroups == 1;
+  if (!graphable || h->frames_on_plan == 0) {
+    h->frames_on_plan++;
+    return enqueue_stages(h, d_src, stride);
+  }
+  const size_t row = (size_t)h->fw * h->fcn;
+  if (d_src != h->d_img) {
+    if ((size_t)stride == row) HIPCHK(h, hipMemcpyAsync(h->d_img, d_src, row * h->fh, hipMemcpyDeviceToDevice, h->stream));
+    else HIPCHK(h, hipMemcpy2DAsync(h->d_img, row, d_src, stride, row, h->fh, hipMemcpyDeviceToDevice, h->stream));
+  }
+  if (!h->gexec) {
+    hipGraph_t graph = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_stages(h, h->d_img, (int)row);
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(h, PBD_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { h->gexec = nullptr; return fail(h, PBD_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+  }
+  HIPCHK(h, hipGraphLaunch(h->gexec, h->stream));
+  h->frames_on_plan++;
+  h->have_pyr = h->have_feat = h->have_resp = h->have_dp = true;
+  h->dp_timed = false;
+  h->pending = true;
   return PBD_OK;
 }
 

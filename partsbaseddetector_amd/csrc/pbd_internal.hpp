@@ -182,7 +182,9 @@ struct pbd_handle {
   hipEvent_t ev[8] = {};
   float stage_ms[6] = {0, 0, 0, 0, 0, 0};
   hipEvent_t ev_dp0 = nullptr, ev_dp1 = nullptr;
-  double dp_ms_sum = 0; int dp_frames = 0; bool dp_timer_on = true;
+  double dp_ms_sum = 0; int dp_frames = 0; bool dp_timer_on = true; bool dp_timed = false;   // DP events are recorded only while profiling
+  hipGraphExec_t gexec = nullptr;   // pbd_options.graph: the frame's launches, captured once per geometry
+  int frames_on_plan = 0;           // frames enqueued since the last plan_frame
   std::vector<void*> frame_allocs;  // everything freed on re-plan
 };
 

@@ -20,9 +20,26 @@ static void run(Model& model, const Mat& im, bool stagewise) {
     vectorMat pyramid;
     pbd.features().pyramid(im, pyramid);
     vector2DMat pdf, rootv, rooti;
-    pbd.convolutionEngine().pdf(pyramid, pdf);
-    pbd.dp().min(rootv, rooti, pbd.ncomponents(), pdf);
-    pbd.dp().argmin(candidates);
+    vector4DMat Ix, Iy, Ik;
+    pbd.convolutionEngine().pdf(pyramid, pdf);                                  // src/PartsBasedDetector.cpp:78
+    pbd.dp().min(pbd.parts(), pdf, Ix, Iy, Ik, rootv, rooti);                   // :83, the reference's signature
+    // the tables came back in the reference's shapes: [level][component][part][parent mixture]
+    if (Ix.size() != pyramid.size() || Ix[0][0].size() != (size_t)pbd.parts().nparts(0) || !Ix[0][0][0].empty() ||
+        Ix[0][0][1].empty() || Ix[0][0][1][0].rows != pdf[0][0].rows || rootv[0][0].cols != pdf[0][0].cols) {
+      fprintf(stderr, "min(): unexpected table shapes\n");
+      exit(5);
+    }
+    // position-weighted checksum of every pointer table, in [level][component][part][parent mixture] order (Ix, Iy, Ik
+    // interleaved per table): the test compares it with the oracle's tables
+    unsigned long long sum = 0, idx = 0;
+    for (size_t n = 0; n < Ix.size(); ++n)
+      for (size_t c = 0; c < Ix[n].size(); ++c)
+        for (size_t p = 1; p < Ix[n][c].size(); ++p)
+          for (size_t m = 0; m < Ix[n][c][p].size(); ++m)
+            for (const Mat* t : {&Ix[n][c][p][m], &Iy[n][c][p][m], &Ik[n][c][p][m]})
+              for (int i = 0; i < t->rows * t->cols; ++i) sum += (++idx) * (unsigned long long)(unsigned)t->ptr<int32_t>()[i];
+    printf("Tables: %llu\n", sum);
+    pbd.dp().argmin(pbd.parts(), rootv, rooti, pbd.features().scales(), Ix, Iy, Ik, candidates);   // :89
   } else {
     Mat depth;
     pbd.detect(im, depth, candidates);

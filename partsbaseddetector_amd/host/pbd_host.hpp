@@ -344,34 +344,69 @@ static inline void append_candidates(std::vector<Candidate>& out, const std::vec
   }
 }
 
+// ---- include/Parts.hpp:51-261 (index tables only: all numerics run on the device) -------------------------
+class Parts {
+  vector3Di filterid_; vector2Di parentid_;
+ public:
+  Parts() {}
+  explicit Parts(Model& m) : filterid_(m.filterid()), parentid_(m.parentid()) {}
+  int ncomponents() const { return (int)filterid_.size(); }                  // :236
+  int nparts(int c) const { return (int)filterid_[c].size(); }               // :238
+  int nmixtures(int c, int p) const { return (int)filterid_[c][p].size(); }  // ComponentPart::nmixtures, :131
+  int parent(int c, int p) const { return p ? parentid_[c][p] : -1; }        // ComponentPart::parent, :143
+};
+
+// DynamicProgram<T> with the reference's signatures (include/DynamicProgram.hpp:74-75).  The tables stay on the
+// device; min() additionally materialises them in the reference's shapes — rootv / rooti[level][component] and,
+// unless fetchPointerTables(false), Ix / Iy / Ik[level][component][part][parent mixture] as CV_32S-like maps
+// (src/DynamicProgram.cpp:72-76,147-151; 250 MB for the person model at 640x480, which is why a caller that only
+// goes on to argmin() may switch them off: argmin() back-tracks on the device from the resident tables, the
+// vectors passed back in are not re-uploaded).
 template <typename T>
 class DynamicProgram {
   std::shared_ptr<Device> dev_;
+  bool fetch_ptr_ = true;
  public:
   DynamicProgram() {}
   explicit DynamicProgram(std::shared_ptr<Device> d) : dev_(d) {}
-  // min(parts, scores, Ix, Iy, Ik, rootv, rooti): the tables stay on the device; rootv/rooti are
-  // returned ([level][component]); pointer planes can be fetched with pbd_get_dp_pointers.
-  void min(vector2DMat& rootv, vector2DMat& rooti, int ncomponents, const vector2DMat& scores) {
+  void fetchPointerTables(bool on) { fetch_ptr_ = on; }
+  void min(Parts& parts, vector2DMat& scores, vector4DMat& Ix, vector4DMat& Iy, vector4DMat& Ik, vector2DMat& rootv,
+           vector2DMat& rooti) {
     dev_->check(pbd_dp_min(dev_->h));
-    rootv.assign(scores.size(), vectorMat(ncomponents));
-    rooti.assign(scores.size(), vectorMat(ncomponents));
-    for (size_t l = 0; l < scores.size(); ++l)
+    const size_t nscales = scores.size();
+    const int ncomponents = parts.ncomponents();
+    Ix.assign(nscales, vector3DMat(ncomponents)); Iy.assign(nscales, vector3DMat(ncomponents)); Ik.assign(nscales, vector3DMat(ncomponents));
+    rootv.assign(nscales, vectorMat(ncomponents));
+    rooti.assign(nscales, vectorMat(ncomponents));
+    for (size_t n = 0; n < nscales; ++n)
       for (int c = 0; c < ncomponents; ++c) {
-        rootv[l][c].create(scores[l][0].rows, scores[l][0].cols, DataType<T>::type);
-        rooti[l][c].create(scores[l][0].rows, scores[l][0].cols, PBD_32S);
-        if (!rootv[l][c].empty()) dev_->check(get_root(dev_->h, (int)l, c, rootv[l][c].template ptr<T>(), rooti[l][c].ptr<int32_t>()));
+        const int rows = scores[n][0].rows, cols = scores[n][0].cols;
+        rootv[n][c].create(rows, cols, DataType<T>::type);
+        rooti[n][c].create(rows, cols, PBD_32S);
+        if (!rootv[n][c].empty()) dev_->check(get_root(dev_->h, (int)n, c, rootv[n][c].template ptr<T>(), rooti[n][c].ptr<int32_t>()));
+        Ix[n][c].resize(parts.nparts(c)); Iy[n][c].resize(parts.nparts(c)); Ik[n][c].resize(parts.nparts(c));   // :89-91
+        for (int p = 1; p < parts.nparts(c) && fetch_ptr_; ++p) {
+          const int L = parts.nmixtures(c, parts.parent(c, p));
+          Ix[n][c][p].resize(L); Iy[n][c][p].resize(L); Ik[n][c][p].resize(L);
+          for (int m = 0; m < L; ++m) {
+            Ix[n][c][p][m].create(rows, cols, PBD_32S); Iy[n][c][p][m].create(rows, cols, PBD_32S); Ik[n][c][p][m].create(rows, cols, PBD_32S);
+            if (rows > 0 && cols > 0)
+              dev_->check(pbd_get_dp_pointers(dev_->h, (int)n, c, p, m, Ix[n][c][p][m].ptr<int32_t>(), Iy[n][c][p][m].ptr<int32_t>(),
+                                              Ik[n][c][p][m].ptr<int32_t>()));
+          }
+        }
       }
   }
   static int get_root(pbd_handle* h, int l, int c, float* v, int32_t* i) { return pbd_get_root(h, l, c, v, i); }
   static int get_root(pbd_handle* h, int l, int c, double* v, int32_t* i) { return pbd_get_root_f64(h, l, c, v, i); }
-  void argmin(vectorCandidate& candidates, int capacity = 4096) {
-    const int mp = pbd_max_parts(dev_->h);
+  void argmin(Parts& /*parts*/, const vector2DMat& /*rootv*/, const vector2DMat& /*rooti*/, const vectorf /*scales*/,
+              const vector4DMat& /*Ix*/, const vector4DMat& /*Iy*/, const vector4DMat& /*Ik*/, vectorCandidate& candidates) {
+    const int capacity = 4096, mp = pbd_max_parts(dev_->h);
     std::vector<pbd_candidate_head> heads(capacity);
     std::vector<int32_t> boxes((size_t)capacity * mp * 4), locs((size_t)capacity * mp * 3);
     int n = 0;
     dev_->check(pbd_dp_argmin(dev_->h, heads.data(), boxes.data(), locs.data(), capacity, &n));
-    append_candidates(candidates, heads, boxes, locs, n, mp);
+    append_candidates(candidates, heads, boxes, locs, n, mp);      // appends, like :246-251
   }
 };
 
@@ -383,6 +418,7 @@ class PartsBasedDetector {
   std::unique_ptr<IFeatures> features_;
   std::unique_ptr<IConvolutionEngine> convolution_engine_;
   DynamicProgram<T> dp_;
+  Parts parts_;
   int device_, conv_mode_, ncomponents_ = 0;
  public:
   explicit PartsBasedDetector(int device = 0, int conv_mode = PBD_CONV_AUTO) : device_(device), conv_mode_(conv_mode) {}
@@ -390,6 +426,7 @@ class PartsBasedDetector {
   IFeatures& features() { return *features_; }
   IConvolutionEngine& convolutionEngine() { return *convolution_engine_; }
   DynamicProgram<T>& dp() { return dp_; }
+  Parts& parts() { return parts_; }
   int ncomponents() const { return ncomponents_; }
   void distributeModel(Model& model) {             // src/PartsBasedDetector.cpp:102-127
     name_ = model.name();
@@ -399,6 +436,7 @@ class PartsBasedDetector {
     features_.reset(new HipHOGFeatures(dev_, model.binsize(), model.nscales()));
     convolution_engine_.reset(new HipConvolutionEngine(dev_));
     convolution_engine_->setFilters(model.filters());
+    parts_ = Parts(model);                         // :121-122
     dp_ = DynamicProgram<T>(dev_);
   }
   void detect(const Mat& im, vectorCandidate& candidates) { detect(im, Mat(), candidates); }

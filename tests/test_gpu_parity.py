@@ -421,6 +421,21 @@ def test_person_1080p_plan_and_run(gpu_required):
     h.close()
 
 
+def _tables_checksum(orc, model, im, dtype=np.float32):
+    """Position-weighted checksum of the oracle's Ix / Iy / Ik tables in the order host/demo.cpp walks them."""
+    fr = orc.detect(model, im, capacity=1, keep=True, dtype=dtype)[4]
+    planes = sum(len(model.filterid[c][model.parentid[c][p]]) for c in range(model.ncomponents) for p in range(1, model.nparts(c)))
+    parts = []
+    for l in range(fr.nlevels):
+        Ix, Iy, Ik = fr.pointers(l, planes)
+        for pl in range(planes):
+            parts += [Ix[pl].ravel(), Iy[pl].ravel(), Ik[pl].ravel()]
+    fr.free()
+    v = np.concatenate(parts).astype(np.int64).astype(np.uint32).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        return int(np.sum((np.arange(len(v), dtype=np.uint64) + np.uint64(1)) * v, dtype=np.uint64))
+
+
 def test_cpp_host_demo_matches_oracle(gpu_required, orc, tmp_path):
     """The C++ host layer (partsbaseddetector_amd/host: pbd::PartsBasedDetector<float> etc.) driven by
     the reference's demo call sequence (src/demo.cpp:64-111), fused and stage by stage."""
@@ -440,6 +455,10 @@ def test_cpp_host_demo_matches_oracle(gpu_required, orc, tmp_path):
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         lines = out.stdout.strip().splitlines()
+        if extra:   # stage by stage through the reference's min()/argmin() signatures: the Ix / Iy / Ik tables they return
+            assert lines[0].startswith("Tables: ")
+            assert int(lines[0].split()[1]) == _tables_checksum(orc, m, im), "pointer tables differ from the oracle's"
+            lines = lines[1:]
         assert lines[0] == f"Number of candidates: {len(heads)}"
         assert len(lines) == 1 + len(heads)
         for ln, h, b in zip(lines[1:], heads, boxes):
@@ -874,4 +893,30 @@ def test_inactive_level_getters_refuse(gpu_required):
         with pytest.raises(capi.PbdError) as e:
             fn()
         assert e.value.code == capi.PBD_ERR_STATE
+    h.close()
+
+
+def test_graph_replay_equals_eager(gpu_required, orc):
+    """pbd_options.graph: the frame's launches captured once per geometry and replayed — several frames (different
+    images, host and device-resident entry points), a geometry change in between (re-plan, re-capture), all equal to
+    the oracle like the eager path."""
+    import torch
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    ims = [make_image(i, 200, 150) for i in range(4)]
+    m.thresh = thresh_from_oracle(orc, m, ims[0], 99.3)
+    refs = [orc.detect(m, im)[:3] for im in ims]
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, graph=1)
+    for rep in range(2):
+        for im, ref in zip(ims, refs):                 # frame 0 eager, frame 1 captured, then replays
+            assert_candidates_equal(h.detect(im), ref)
+    d_im = torch.from_numpy(ims[2]).cuda()
+    torch.cuda.synchronize()
+    assert_candidates_equal(h.detect_dev(d_im.data_ptr(), 200, 150, 3), refs[2])
+    big = make_image(9, 260, 190)                      # geometry change: the graph is dropped with the plan
+    for _ in range(3):
+        assert_candidates_equal(h.detect(big), orc.detect(m, big)[:3])
+    assert_candidates_equal(h.detect(ims[1]), refs[1])
+    h.set_profiling(True)                              # profiling runs go through the eager path
+    assert_candidates_equal(h.detect(ims[3]), refs[3])
+    assert h.stage_ms()["total"] > 0
     h.close()

@@ -276,6 +276,10 @@ def test_cpp_host_demo_double_matches_oracle(gpu_required, orc, tmp_path):
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         lines = out.stdout.strip().splitlines()
+        if extra.startswith("stagewise"):   # min()/argmin() with the reference's signatures: their Ix / Iy / Ik tables
+            from tests.test_gpu_parity import _tables_checksum
+            assert int(lines[0].split()[1]) == _tables_checksum(orc, m, im, dtype=F64)
+            lines = lines[1:]
         assert lines[0] == f"Number of candidates: {len(heads)}"
         for ln, h, b in zip(lines[1:], heads, boxes):
             tok = ln.split()

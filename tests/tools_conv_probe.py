@@ -13,6 +13,6 @@ for _ in range(3):
     h.detect(im)
     st = (C.c_ulonglong * 8)()
     capi.lib().pbd_debug_conv_stamps(st)
-    d = [(st[i + 1] - st[i]) / 100.0 for i in range(4)]
-    print(f"conv WG(300,2) phases us: stage {d[0]:.1f} kloop {d[1]:.1f} barrier {d[2]:.1f} epilogue {d[3]:.1f}", flush=True)
+    d = [(st[i + 1] - st[i]) / 100.0 for i in range(6)]   # k_conv_mfma16 stamps: 0 start, 1/3 staged half 0/1, 2/4 K loop of half 0/1 done, 5 barrier, 6 end
+    print(f"conv WG(300,2) phases us: stage0 {d[0]:.1f} kloop0 {d[1]:.1f} stage1 {d[2]:.1f} kloop1 {d[3]:.1f} barrier {d[4]:.1f} epilogue {d[5]:.1f} total {(st[6] - st[0]) / 100.0:.1f}", flush=True)
 h.close()
