@@ -20,7 +20,7 @@
 //    stack ("local scan"): local z / B for every element of the segment.
 //    While it scans, a popped element's B slot (dead from then on) receives the element that popped it:
 //    B[e] > e marks e as popped and names its "popper".
-// 2. dt_stitch (one lane per line, segments left to right) replays what the GLOBAL run does when it reaches
+// 2. dt_stitch1 (one lane per segment boundary) replays what the GLOBAL run does when it reaches
 //    segment B = [s_p, s_{p+1}) with the stack G left by the segments before it.  Invariant: the part of the
 //    global stack made of B's elements is a suffix [F, ...] of the local stack, and every entry above F has the
 //    same z and the same "below" globally as locally (its predecessor is the same element); only F's z
@@ -48,13 +48,18 @@
 #ifdef __HIPCC__
 #define DT_HD __device__ __forceinline__
 #define DT_MUL24(a, b) __mul24((a), (b))
+#define DT_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)     // any active lane of the wavefront
 DT_HD unsigned long long dt_bits(double d) { return (unsigned long long)__double_as_longlong(d); }
 #else
 #define DT_HD static inline
 #define DT_MUL24(a, b) ((a) * (b))
+#define DT_ANY(c) (c)
 DT_HD unsigned long long dt_bits(double d) { unsigned long long u; memcpy(&u, &d, 8); return u; }
 #endif
 
+#ifndef DT_COUNT_ITER
+#define DT_COUNT_ITER() ((void)0)   // host-side statistics hook (tests/tools)
+#endif
 template <typename T> struct alignas(2 * sizeof(T)) DtPair { T x, y; };
 
 // segment p of P over a line of `len` elements: [dt_seg_start(p), dt_seg_start(p + 1))
@@ -145,34 +150,51 @@ DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const dou
   return suspect != 0;
 }
 
-// Stitch the local scans of segments 1..P-1 onto segment 0, left to right (see the header comment).  One lane
-// per line; a flattened state machine doing ONE intersection per iteration (lanes of a wavefront stitch
-// different lines: no lane waits in a nested loop for another's trip count).  F[p] receives the lowest element
-// of segment p that the global run left on the stack after segment p (meaningful only while the segment is
-// alive, see dt_seg_table); its z and "below" are patched to the global values.  Returns true if the invariant
-// was lost or a quotient was suspect (the caller redoes the line sequentially).
+// Stitch ONE boundary: replay what the global run does when it reaches segment [s0, s1) with the stack left by
+// the elements before s0 (see the header comment).  A flattened state machine doing one intersection per
+// iteration; everything an iteration needs from LDS is read in one batch at its top (the entry under test, its
+// link, the reciprocal, the links of q and F), so an iteration is one LDS round trip + one intersection.
+//
+// The P-1 boundaries of a line are stitched CONCURRENTLY, one lane each, i.e. before the segments to the left
+// have been stitched: speculation.  What a stitch reads from the left is correct as long as it stays strictly
+// above the element F that the left neighbour's own stitch finally leaves as its lowest survivor — entries above
+// F have their final z and links from the local scan — so the stitch reports `dmin`, the lowest element below
+// s0 it tested, and the validation pass (dt_stitch_validate) redoes, in order, the few stitches that went
+// deeper.  Outputs: f = lowest element of the segment left on the stack, patched to its global z / link (the
+// local values are returned in zsave / bsave so that a redo can restore them).  Returns true if the invariant
+// was lost or a quotient was suspect (the caller redoes the whole line sequentially).
 template <bool EXACT, typename T, typename IT>
-DT_HD bool dt_stitch(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R, int len, int P,
-                     double a, double b, IT* __restrict__ F, int fstride) {
+DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R, int s0, int s1,
+                      double a, double b, int& f_out, int& dmin_out, T& zsave, int& bsave) {
   const double twoa = 2 * a;
   unsigned suspect = 0;
   bool bad = false;
-  F[0] = (IT)0;
-  if (P < 2) return false;
-  int p = 1, s1 = dt_seg_start(2, P, len);
-  int q = dt_seg_start(1, P, len);          // the global run reaches the segment's first element: top of G = q - 1
-  double yq = (double)YZ[q].x;
-  int e = q - 1;
-  bool testf = false;                        // false: popping in G for q; true: e == F, tested with its global z
-  int f = 0, fb = 0;
+  int q = s0;                                // the global run reaches the segment's first element: top of the stack = s0 - 1
+  int e = s0 - 1;
+  bool testf = false;                        // false: popping below the segment for q; true: e == F, q is the next element whose local scan reached F
+  int f = s0, fb = 0, dmin = s0;
   T zf = (T)0;
   for (;;) {
+    DT_COUNT_ITER();
     const DtPair<T> ez = YZ[e];
-    const int eb = (int)B[e];
-    const T s = dt_isect<EXACT, T>((double)ez.x, e, yq, q, a, b, twoa, EXACT ? 0.0 : R[q - e], suspect);
+    const DtPair<T> qz = YZ[q];
+    const int eb = (int)B[e], bq = (int)B[q], bf = (int)B[f];
+    // An event whose local scan STOPPED at F (q sits on F locally: F's popper link does not name q) needs no
+    // arithmetic: the intersection the global run tests, s(F, q), is the z the local scan stored for q.  Most
+    // steps of a stitch are of this kind, and the lanes of a wavefront reach them together (each stitch starts
+    // with a few real intersections for the segment's first element): the intersection code is skipped whenever
+    // no lane of the wavefront needs it.
+    const bool cheap = testf && bf != q;
+    T s = qz.y;
+    if (DT_ANY(!cheap)) {
+      const double r = EXACT ? 0.0 : R[q - e];
+      const T si = dt_isect<EXACT, T>((double)ez.x, e, (double)qz.x, q, a, b, twoa, r, suspect);
+      s = cheap ? s : si;
+    }
+    if (!testf) dmin = e < dmin ? e : dmin;
     const bool pass = (s <= (testf ? zf : ez.y)) && (e != 0);      // :162; only the bottom of the whole stack is protected
     if (pass) {
-      e = testf ? fb : eb;                   // F popped: continue below it; otherwise one more pop in G
+      e = testf ? fb : eb;                   // F popped: continue below it; otherwise one more pop below the segment
       testf = false;
       continue;
     }
@@ -180,28 +202,45 @@ DT_HD bool dt_stitch(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const doubl
     if (!testf) {                            // q is pushed on e: the new F, top of the segment's part of the stack
       f = q; zf = s; fb = e;
       nq = q + 1;                            // F is the top: the next element tests it
-    } else {                                 // F survives q: fine iff the local run stopped at F too (q sits on F)
-      if ((int)B[f] == q) bad = true;        // ... but it popped F (F's popper link names q): invariant lost
-      const int pq = (int)B[q];              // q alive at the end of its segment: its "below"; popped: its popper
-      nq = pq > q ? pq : s1;                 // the next element to reach F is the one that pops q
+    } else {                                 // F survives q
+      if (!cheap) bad = true;                // ... although the local scan popped it (bf == q): invariant lost
+      nq = bq > q ? bq : s1;                 // q popped locally: its popper is the next element to reach F; else none
     }
-    if (nq >= s1) {                          // segment done: patch F to its global z / below
-      YZ[f].y = zf;
-      B[f] = (IT)fb;
-      F[p * fstride] = (IT)f;
-      if (++p >= P) break;
-      q = s1;
-      s1 = dt_seg_start(p + 1, P, len);
-      e = q - 1;
-      testf = false;
-    } else {
-      q = nq;
-      e = f;
-      testf = true;
-    }
-    yq = (double)YZ[q].x;
+    if (nq >= s1) break;
+    q = nq;
+    e = f;
+    testf = true;
   }
+  zsave = YZ[f].y;
+  bsave = (int)B[f];
+  YZ[f].y = zf;
+  B[f] = (IT)fb;
+  f_out = f;
+  dmin_out = dmin;
   return bad || suspect != 0;
+}
+
+// Validation of the speculative stitches of one line, left to right (one lane per line): stitch p is kept iff
+// every element it tested below its segment lies strictly above F[p-1], the final lowest survivor of the
+// segment to its left (boundary 1 is always valid: segment 0's local scan IS the global run).  Otherwise it is
+// redone now, with everything to its left final.  F / DMIN / ZSAVE / BSAVE: per-segment tables (stride tstride).
+template <bool EXACT, typename T, typename IT>
+DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R, int len, int P,
+                              double a, double b, IT* __restrict__ F, const IT* __restrict__ DMIN,
+                              const T* __restrict__ ZSAVE, const IT* __restrict__ BSAVE, int tstride) {
+  bool bad = false;
+  F[0] = (IT)0;
+  for (int p = 2; p < P; ++p) {
+    if ((int)DMIN[p * tstride] > (int)F[(p - 1) * tstride]) continue;
+    const int fo = (int)F[p * tstride];
+    YZ[fo].y = ZSAVE[p * tstride];           // undo the speculative patch, then stitch again
+    B[fo] = BSAVE[p * tstride];
+    int f, dmin, bs;
+    T zs;
+    bad |= dt_stitch1<EXACT, T, IT>(YZ, B, R, dt_seg_start(p, P, len), dt_seg_start(p + 1, P, len), a, b, f, dmin, zs, bs);
+    F[p * tstride] = (IT)f;
+  }
+  return bad;
 }
 
 // After the stitch: which segments still own entries of the final stack, where the chain enters them (ENT[p]:

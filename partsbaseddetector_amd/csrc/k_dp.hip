@@ -66,8 +66,11 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   int* pstr = (int*)(smem + 64 * 16);          // [64] pointer-output element stride of each line
   int* FLAG = (int*)(smem + 64 * 20);          // [64] per line: redo sequentially (suspect quotient / lost stitch invariant); then: segments in use
   T* ZLO = (T*)(smem + 64 * 24);               // [64] per lane (p * lpb + line): z of the segment's lowest surviving element
-  IT* FT = (IT*)(smem + 64 * 32);              // [64] per lane: that element
+  T* ZSAVE = (T*)(smem + 64 * 32);             // [64] per lane: that element's local z (before the stitch patched it)
+  IT* FT = (IT*)(smem + 64 * 40);              // [64] per lane: that element
   IT* ENT = FT + 64;                           // [64] topmost surviving element of the segment (or dead)
+  IT* DMIN = ENT + 64;                         // [64] lowest element the segment's speculative stitch tested
+  IT* BSAVE = DMIN + 64;                       // [64] local link of FT (before the patch)
   double* R = (double*)(smem + DT_HDR);        // [nmb][S] 1/(2a*dx) per map of this block
   const IT dead = (IT)~(IT)0;
   const int total = g.nmaps * g.nlines;
@@ -147,10 +150,20 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   }
   __syncthreads();
   DT_STAMP(3);
-  // ---- stitch the segments into the sequential result; one lane per line ----
+  // ---- stitch the segments into the sequential result: every boundary by its own lane, concurrently ----
+  if (mine && p >= 1 && p < P && !FLAG[line]) {
+    int f, dmin, bs;
+    T zs;
+    const bool bad = dt_stitch1<EX, T, IT>(YZl, Bl, Rl, dt_seg_start(p, P, len), dt_seg_start(p + 1, P, len), mp.a, mp.b, f, dmin, zs, bs);
+    FT[lane] = (IT)f; DMIN[lane] = (IT)dmin; ZSAVE[lane] = zs; BSAVE[lane] = (IT)bs;
+    if (bad) FLAG[line] = 1;
+  }
+  __syncthreads();
+  DT_STAMP(6);
+  // ---- validate the speculation (redo the few stitches that reached below their neighbour's survivors), tables ----
   if (mine && p == 0) {
     bool redo = FLAG[line] != 0;
-    if (!redo && P > 1) redo = dt_stitch<EX, T, IT>(YZl, Bl, Rl, len, P, mp.a, mp.b, FT + line, lpb);
+    if (!redo && P > 2) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, Rl, len, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
     int Pl = P;
     if (redo) DT_COUNT_REDO();
     if (redo) {   // a quotient next to a float rounding boundary, or near-degenerate geometry: the whole line sequentially, IEEE divisions
@@ -162,7 +175,6 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     FLAG[line] = Pl;                             // segments the read-out lanes look at
   }
   __syncthreads();
-  DT_STAMP(6);
   DT_STAMP(4);
 
   // ---- read out (:172-178) ----

@@ -18,5 +18,5 @@ for (r, c) in [(8, 10), (118, 158), (118, 158), (16, 158), (158, 16), (64, 64)]:
     L.pbd_debug_dt_stamps(st)
     us = lambda a, b: (st[b] - st[a]) / 100.0
     print(f"{r}x{c} y-pass block0 phases us: setup+rtable {us(0, 1):.1f} load {us(1, 2):.1f} segment scans {us(2, 3):.1f} "
-          f"stitch+table {us(3, 6):.1f} phase A {us(6, 4):.1f} read-out {us(4, 5):.1f}; lines redone sequentially: {st[7]}", flush=True)
+          f"stitches {us(3, 6):.1f} validate+table {us(6, 4):.1f} read-out {us(4, 5):.1f}; lines redone sequentially: {st[7]}", flush=True)
 h.close()
