@@ -104,9 +104,7 @@ typedef struct pbd_options {
                             instead of the float ones                          */
   int32_t graph;         /* 1: capture the ~40 launches of a frame into a hipGraph once per frame geometry and
                             replay it (one hipGraphLaunch per frame instead of ~40 launches); 0: eager launches */
-  int32_t reserved[2];   /* [0]: DP level groups on separate streams (0/1 = one chain, max 3)
-                            [1]: distance transform kernel: 0/1 lane-per-line (default), 2 the
-                                 experimental wave-per-line kernel (lines <= 512 elements)          */
+  int32_t reserved[2];   /* [0]: DP level groups on separate streams (0/1 = one chain, max 3); [1]: unused     */
 } pbd_options;
 
 /* ---- output record: include/Candidate.hpp:56-111 --------------------------
@@ -291,8 +289,6 @@ int pbd_debug_dt_stamps(unsigned long long out[8]);
 int pbd_debug_hog_stamps(unsigned long long out[8]);
 /* same for the MFMA filter bank: tile staging, K loop, barrier, epilogue                    */
 int pbd_debug_conv_stamps(unsigned long long out[8]);
-/* wave-per-line distance transform: [0] lines processed, [1] repair rounds, [2] sequential fallbacks */
-int pbd_debug_dtw_stats(unsigned long long out[4], int reset);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,7 @@ EXPORTS = [
     "pbd_candidates_sort", "pbd_candidates_nms", "pbd_get_stage_ms", "pbd_set_profiling",
     "pbd_detect_enqueue_u8", "pbd_group_create", "pbd_group_destroy", "pbd_group_last_error", "pbd_group_size",
     "pbd_group_gather_mode", "pbd_group_member", "pbd_group_detect_batch_u8", "pbd_group_detect_u8",
-    "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps", "pbd_debug_dtw_stats",
+    "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps",
 ]
 
 
@@ -88,7 +88,7 @@ class Handle:
     """Owns one pbd_handle (one GPU, one stream)."""
 
     def __init__(self, model, device=0, conv_mode=PBD_CONV_AUTO, max_candidates=4096, dt_correct_ptr=0,
-                 level_begin=0, level_end=0, dp_groups=0, dt_mode=0, dtype=np.float32, graph=0):
+                 level_begin=0, level_end=0, dp_groups=0, dtype=np.float32, graph=0):
         """dtype: np.float32 = PartsBasedDetector<float>, np.float64 = PartsBasedDetector<double>."""
         self.L = lib()
         self.model = model
@@ -99,7 +99,7 @@ class Handle:
         self._f64 = self.dtype == np.dtype(np.float64)
         self._ct = C.c_double if self._f64 else C.c_float
         opt = pbd_options(device, conv_mode, max_candidates, dt_correct_ptr, level_begin, level_end,
-                          PBD_SCALAR_F64 if self._f64 else PBD_SCALAR_F32, graph, (C.c_int32 * 2)(dp_groups, dt_mode))
+                          PBD_SCALAR_F64 if self._f64 else PBD_SCALAR_F32, graph, (C.c_int32 * 2)(dp_groups, 0))
         self.h = C.c_void_p()
         rc = self.L.pbd_create(C.byref(self.desc), C.byref(opt), C.byref(self.h))
         if rc != PBD_OK:

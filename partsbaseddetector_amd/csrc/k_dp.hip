@@ -225,12 +225,6 @@ __global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks
   DT_STAMP(0);
   const DtTask t = tasks[blockIdx.x];
   const DtGroup g = groups[t.group];
-  // A pass lasts as long as its longest lines (level 0: one residency round of the whole chip), and a block
-  // shares its SIMD with one other block, usually of a smaller level that has slack: the long-line blocks take
-  // the issue slots first (g.prio: 3 for the longest lines of the launch ... 0 for lines under half of that).
-  if (g.prio == 3) __builtin_amdgcn_s_setprio(3);
-  else if (g.prio == 2) __builtin_amdgcn_s_setprio(2);
-  else if (g.prio == 1) __builtin_amdgcn_s_setprio(1);
   if (g.stride <= 256) dt_block<T, unsigned char>(smem, t, g, maps);    // stack indices < 255 fit a byte
   else dt_block<T, unsigned short>(smem, t, g, maps);
 }

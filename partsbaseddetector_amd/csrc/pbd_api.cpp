@@ -462,13 +462,12 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       h->level_group[l] = gcur;
     }
   }
-  int wave_maxlen = 0;
   for (int gi_ = 0; gi_ < PBD_NGROUPS; ++gi_) h->grl[gi_].clear();
   for (size_t r = 0; r < h->rounds.size(); ++r) {
     const std::vector<int>& rnd = h->rounds[r];
     for (int grp = 0; grp < h->ngroups; ++grp) {
     pbd_handle::RoundLaunch R{};
-    std::vector<DtTask> xt, yt, xwt, ywt;
+    std::vector<DtTask> xt, yt;
     for (int l = 0; l < n && !rnd.empty(); ++l) {
       const Level& L = h->lv[l];
       if (!L.active || L.cw == 0 || L.ch == 0 || h->level_group[l] != grp) continue;
@@ -499,18 +498,11 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       groups.push_back(gx);
       const int gyi = (int)groups.size();
       groups.push_back(gy);
-      auto use_wave = [&](int len) { return len <= 512 && h->dt_mode == 2; };
-      auto add_tasks = [&](const DtGroup& g, int gidx, std::vector<DtTask>& lane_t, std::vector<DtTask>& wave_t) {
-        if (use_wave(g.len)) {
-          for (int mi2 = 0; mi2 < g.nmaps; ++mi2)              // 16-line blocks, never straddling a map
-            for (int l0 = 0; l0 < g.nlines; l0 += 16) wave_t.push_back(DtTask{gidx, mi2 * g.nlines + l0});
-          wave_maxlen = std::max(wave_maxlen, g.len);
-        } else {
-          for (int g0 = 0; g0 < g.nmaps * g.nlines; g0 += g.lpb) lane_t.push_back(DtTask{gidx, g0});
-        }
+      auto add_tasks = [&](const DtGroup& g, int gidx, std::vector<DtTask>& lane_t) {
+        for (int g0 = 0; g0 < g.nmaps * g.nlines; g0 += g.lpb) lane_t.push_back(DtTask{gidx, g0});
       };
-      add_tasks(gx, gxi, xt, xwt);
-      add_tasks(gy, gyi, yt, ywt);
+      add_tasks(gx, gxi, xt);
+      add_tasks(gy, gyi, yt);
     }
     if (const char* e = PBD_PROBE_ENV("PBD_DEBUG_DUP")) {   // scaling probe: every DT block issued n times (identical outputs)
       const int ndup = atoi(e);
@@ -521,10 +513,6 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     tasks.insert(tasks.end(), xt.begin(), xt.end());
     R.ytask0 = (int)tasks.size(); R.nytasks = (int)yt.size();
     tasks.insert(tasks.end(), yt.begin(), yt.end());
-    R.xw0 = (int)tasks.size(); R.nxw = (int)xwt.size();
-    tasks.insert(tasks.end(), xwt.begin(), xwt.end());
-    R.yw0 = (int)tasks.size(); R.nyw = (int)ywt.size();
-    tasks.insert(tasks.end(), ywt.begin(), ywt.end());
     // reduce waves of this round (slot state is advanced once per wave, after the last group)
     std::vector<char> slot_w = slot_init;
     for (const std::vector<int>& wave : h->red_rounds[r]) {
@@ -570,13 +558,6 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     if (grp == h->ngroups - 1) slot_init = slot_w;
     }  // groups
   }
-  {  // issue priority of a group's blocks: by line length relative to the frame's longest line
-    static const int prio_on = PBD_PROBE_ENV("PBD_DT_PRIO") ? atoi(PBD_PROBE_ENV("PBD_DT_PRIO")) : 1;
-    for (DtGroup& g : groups)
-      g.prio = !prio_on ? 0 : (g.len * 8 >= maxlen * 7) ? 3 : (g.len * 4 >= maxlen * 3) ? 2 : (g.len * 2 >= maxlen) ? 1 : 0;
-  }
-  h->dtw_lds = wave_maxlen ? dtw_lds_bytes(wave_maxlen) : 0;
-  if (h->dtw_lds > 160 * 1024 || wave_maxlen > 512) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the wave-per-line distance transform");
   if ((rc = dev_upload(h, &h->d_dtmaps, maps))) return rc;
   if ((rc = dev_upload(h, &h->d_dtgroups, groups))) return rc;
   if ((rc = dev_upload(h, &h->d_dttasks, tasks))) return rc;
@@ -684,9 +665,7 @@ static int run_dp_min(pbd_handle* h) {
   if (h->ngroups > 1) hipEventRecord(h->ev_fork, h->stream);
   if (h->ngroups == 1) {  // default: one chain of rounds on the handle's stream
     for (auto& R : h->grl[0]) {
-      launch_dt_wave(h->d_dttasks + R.xw0, R.nxw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, h->stream);
       launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->stream);
-      launch_dt_wave(h->d_dttasks + R.yw0, R.nyw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, h->stream);
       launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->stream);
       for (auto& Wv : R.waves)
         launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
@@ -696,9 +675,7 @@ static int run_dp_min(pbd_handle* h) {
     hipStream_t s = h->gstream[g];
     hipStreamWaitEvent(s, h->ev_fork, 0);
     for (auto& R : h->grl[g]) {
-      launch_dt_wave(h->d_dttasks + R.xw0, R.nxw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, s);
       launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, s);
-      launch_dt_wave(h->d_dttasks + R.yw0, R.nyw, h->d_dtgroups, h->d_dtmaps, h->dtw_lds, s);
       launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, s);
       for (auto& Wv : R.waves)
         launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, s);
@@ -882,12 +859,10 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   int rc = ingest_model(h, model);
   if (rc) return rc;
   h->ngroups = std::min(std::max(o.reserved[0], 1), PBD_NGROUPS);
-  h->dt_mode = o.reserved[1];
   h->conv_mode = o.conv_mode;
   if (h->conv_mode == PBD_CONV_AUTO)  // a dense contraction when N x K is GEMM-sized
     h->conv_mode = ((size_t)model->nfilters * model->kh * model->kw * model->flen >= 32 * 800 && model->kh == 5 && model->kw == 5)
                        ? PBD_CONV_MFMA : PBD_CONV_EXACT;
-  if (h->ts == 8 && o.reserved[1] == 2) return fail(h, PBD_ERR_UNSUPPORTED, "the wave-per-line distance transform is float only");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(h, PBD_ERR_HIP, "no HIP device visible");
   if (o.device < 0 || o.device >= ndev) return fail(h, PBD_ERR_ARG, "bad device ordinal");
@@ -1217,11 +1192,9 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
   DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz), dt_group(1, 1, cols, rows, budget, tsz)};
   std::vector<DtTask> tasks;
-  const bool use_wave_x = h->dt_mode == 2 && cols <= 512 && dtw_lds_bytes(cols) <= 160 * 1024;
-  const bool use_wave_y = h->dt_mode == 2 && rows <= 512 && dtw_lds_bytes(rows) <= 160 * 1024;
-  for (int g0 = 0; g0 < rows; g0 += (use_wave_x ? 16 : groups[0].lpb)) tasks.push_back(DtTask{0, g0});
+  for (int g0 = 0; g0 < rows; g0 += groups[0].lpb) tasks.push_back(DtTask{0, g0});
   const int nx = (int)tasks.size();
-  for (int g0 = 0; g0 < cols; g0 += (use_wave_y ? 16 : groups[1].lpb)) tasks.push_back(DtTask{1, g0});
+  for (int g0 = 0; g0 < cols; g0 += groups[1].lpb) tasks.push_back(DtTask{1, g0});
   DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks;
   HIPCHK(h, hipMalloc(&d_maps, sizeof(maps))); HIPCHK(h, hipMalloc(&d_groups, sizeof(groups)));
   HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size()));
@@ -1229,10 +1202,8 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMemcpyAsync(d_groups, groups, sizeof(groups), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
-  if (use_wave_x) launch_dt_wave(d_tasks, nx, d_groups, d_maps, dtw_lds_bytes(cols), h->stream);
-  else launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, tsz, h->stream);
+  launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, tsz, h->stream);
   if (PBD_PROBE_ENV("PBD_DEBUG_SKIP_Y")) { hipMemsetAsync(d_sdt, 0, HW * ts, h->stream); hipMemsetAsync(d_iy, 0, HW * 2, h->stream); }   // probe build: leave the x pass as the last DT launch (its stamps are then readable)
-  else if (use_wave_y) launch_dt_wave(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, dtw_lds_bytes(rows), h->stream);
   else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, tsz, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_sdt, HW * ts, hipMemcpyDeviceToHost, h->stream));   // the y pass's scores, untouched
@@ -1443,7 +1414,6 @@ int pbd_get_work(const pbd_handle* h, double work[6]) {
 int pbd_debug_dt_stamps(unsigned long long* out) { if (!out) return PBD_ERR_ARG; dt_debug_read(out); return PROBE_RC; }
 int pbd_debug_hog_stamps(unsigned long long* out) { if (!out) return PBD_ERR_ARG; hog_debug_read(out); return PROBE_RC; }
 int pbd_debug_conv_stamps(unsigned long long* out) { if (!out) return PBD_ERR_ARG; conv_debug_read(out); return PROBE_RC; }
-int pbd_debug_dtw_stats(unsigned long long* out, int reset) { dtw_stats_read(out, reset); return PBD_OK; }
 
 int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes) {
   if (!h) return PBD_ERR_ARG;

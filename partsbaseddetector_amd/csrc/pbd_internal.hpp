@@ -61,7 +61,7 @@ struct DtMap {       // one 1-D pass over one score map
   double a, b;       // Quadratic(a, b)
   int os, ptr_natural;  // ptr_natural: write ptr row-major [line][q] instead of transposed
 };
-struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, nmb, prio; };  // stride: LDS elements per line (even); lpb: lines per block; nmb: max maps a block touches; prio: s_setprio of the group's blocks (long lines first)
+struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, nmb, pad; };  // stride: LDS elements per line (even); lpb: lines per block; nmb: max maps a block touches
 struct DtTask { int group, g0; };
 
 #define PBD_MAX_CH 8   // children of one parent folded into one reduce job
@@ -154,7 +154,7 @@ struct pbd_handle {
   DtMap* d_dtmaps = nullptr; DtGroup* d_dtgroups = nullptr; DtTask* d_dttasks = nullptr;
   ReduceJob* d_redjobs = nullptr; ReduceBlock* d_redblocks = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
   struct ReduceWave { int blk0, nblks; };
-  struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; int xw0, nxw, yw0, nyw; std::vector<ReduceWave> waves; };
+  struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; std::vector<ReduceWave> waves; };
   // Pyramid levels never interact in the DP (src/DynamicProgram.cpp:83-87), so levels are split into
   // PBD_NGROUPS size classes, each running its own chain of rounds on its own stream: a launch then
   // only waits for the longest line of ITS levels, and the big-level group fits one wave of blocks.
@@ -165,8 +165,6 @@ struct pbd_handle {
   int level_group[PBD_MAX_LEVELS] = {};
   int ngroups = 1;   // pbd_options.reserved[0]: 1 (default) .. PBD_NGROUPS; measured slower than one chain on MI355X
   size_t dt_lds = 0;                                 // dynamic LDS of every k_dt_pass launch
-  size_t dtw_lds = 0;                                // dynamic LDS of every k_dt_wave launch
-  int dt_mode = 0;                                   // pbd_options.reserved[1]: 0/1 lane-per-line (k_dt_pass, default), 2 wave-per-line (k_dt_wave, experimental) for len <= 512
   std::vector<RoundLaunch> rl;
   int n_rootjobs = 0; unsigned root_cells = 0;
   // candidates
@@ -265,9 +263,6 @@ void launch_backtrack(const int* count, const CandRec* rec, int capacity, const 
                       const unsigned long long* scr_base, const int16_t* ix, const int16_t* iy, int correct_ptr,
                       hipStream_t s);
 void dt_debug_read(unsigned long long* out);
-void launch_dt_wave(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, hipStream_t s);
-size_t dtw_lds_bytes(int len);
-void dtw_stats_read(unsigned long long* out, int reset);
 void hog_debug_read(unsigned long long* out);
 void conv_debug_read(unsigned long long* out);
 void launch_nms_map(const float* src, int rows, int cols, int sz, uint8_t* dst, hipStream_t s);

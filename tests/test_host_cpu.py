@@ -131,6 +131,20 @@ def test_pack_unpack_roundtrip():
     np.testing.assert_array_equal(out[2], locs)
 
 
+def test_dt_core_host(tmp_path):
+    """partsbaseddetector_amd/csrc/dt_core.hpp — the segment-parallel distance transform k_dt_pass compiles — run on
+    the host, lanes one after the other, against the oracle's sequential loop (tests/tools/dt_core_test.cpp): random,
+    smooth, quantised (exact ties), sparse-peak, constant and concave lines, 1..16 lanes per line, lengths 1..700,
+    float and double, every speculative-stitch order; every output and pointer bit-identical."""
+    exe = tmp_path / "dt_core_test"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "partsbaseddetector_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "tools", "dt_core_test.cpp"), "-L", os.path.join(ROOT, "oracle"), "-lorc",
+                           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-o", str(exe)])
+    out = subprocess.run([str(exe), "120000", "2026"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("bit-identical") == 2
+
+
 def test_pack_candidates_overflow_raises():
     """A rank holding more candidates than the exchange buffer must fail loudly (the C ABI reports
     PBD_ERR_CAPACITY for the same condition), never drop detections in the multi-GPU merge."""
