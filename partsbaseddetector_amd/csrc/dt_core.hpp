@@ -62,8 +62,9 @@ DT_HD unsigned long long dt_bits(double d) { unsigned long long u; memcpy(&u, &d
 #endif
 template <typename T> struct alignas(2 * sizeof(T)) DtPair { T x, y; };
 
-// segment p of P over a line of `len` elements: [dt_seg_start(p), dt_seg_start(p + 1))
-DT_HD int dt_seg_start(int p, int P, int len) { return (int)(((long long)p * len) / P); }
+// segment p of P over a line of `len` elements: [dt_seg_start(p), dt_seg_start(p + 1)).  p * len < 2^20 (p <= 16, len < 2^15):
+// a 32-bit division; the kernel evaluates it once per block into a table (seg[0..P]) that the routines below take.
+DT_HD int dt_seg_start(int p, int P, int len) { return (int)((unsigned)(p * len) / (unsigned)P); }
 // segments actually used for a line: at least 8 elements each (short lines gain nothing from stitching)
 DT_HD int dt_segments(int lanes_per_line, int len) {
   int P = len / 8;
@@ -225,9 +226,9 @@ DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const doub
 // segment to its left (boundary 1 is always valid: segment 0's local scan IS the global run).  Otherwise it is
 // redone now, with everything to its left final.  F / DMIN / ZSAVE / BSAVE: per-segment tables (stride tstride).
 template <bool EXACT, typename T, typename IT>
-DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R, int len, int P,
-                              double a, double b, IT* __restrict__ F, const IT* __restrict__ DMIN,
-                              const T* __restrict__ ZSAVE, const IT* __restrict__ BSAVE, int tstride) {
+DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R,
+                              const int* __restrict__ seg, int P, double a, double b, IT* __restrict__ F,
+                              const IT* __restrict__ DMIN, const T* __restrict__ ZSAVE, const IT* __restrict__ BSAVE, int tstride) {
   bool bad = false;
   F[0] = (IT)0;
   for (int p = 2; p < P; ++p) {
@@ -237,7 +238,7 @@ DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, co
     B[fo] = BSAVE[p * tstride];
     int f, dmin, bs;
     T zs;
-    bad |= dt_stitch1<EXACT, T, IT>(YZ, B, R, dt_seg_start(p, P, len), dt_seg_start(p + 1, P, len), a, b, f, dmin, zs, bs);
+    bad |= dt_stitch1<EXACT, T, IT>(YZ, B, R, seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
     F[p * tstride] = (IT)f;
   }
   return bad;
@@ -247,11 +248,11 @@ DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, co
 // topmost surviving element of segment p, or `dead`) and the z of their lowest entry (ZLO[p] = z of F[p]).  One
 // lane per line, top segment first.
 template <typename T, typename IT>
-DT_HD void dt_seg_table(const DtPair<T>* __restrict__ YZ, const IT* __restrict__ B, int len, int P,
+DT_HD void dt_seg_table(const DtPair<T>* __restrict__ YZ, const IT* __restrict__ B, const int* __restrict__ seg, int P,
                         const IT* __restrict__ F, IT* __restrict__ ENT, T* __restrict__ ZLO, int tstride, IT dead) {
-  int e = len - 1;
+  int e = seg[P] - 1;                        // the last element of the line is the top of the stack
   for (int p = P - 1; p >= 0; --p) {
-    if (e >= dt_seg_start(p, P, len)) {
+    if (e >= seg[p]) {
       const int f = (int)F[p * tstride];
       ENT[p * tstride] = (IT)e;
       ZLO[p * tstride] = YZ[f].y;

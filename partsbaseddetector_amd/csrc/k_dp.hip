@@ -46,9 +46,9 @@ void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i]
 // LDS per block: per-lane descriptors and segment tables (DT_HDR bytes), per map touched by the block a table of
 // exact reciprocals 1/(2a*dx), dx < len (double[S]), and per line {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
 // 9 bytes per line element for float: the lines resident on a CU are bounded by these bytes.
-#define DT_HDR 3072
+#define DT_HDR 3200
 size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts) {   // ts = sizeof(T): (y, z) is a float or a double pair
-  return (size_t)lpb * stride * (2 * ts + (stride <= 256 ? 1 : 2)) + DT_HDR + (size_t)nmb * stride * 8 + 16;
+  return (size_t)lpb * stride * (2 * ts + (stride <= 256 ? 1 : 2)) + DT_HDR + (((size_t)nmb * stride + 1) & ~(size_t)1) * 8 + 16;
 }
 
 // One block = one wavefront = up to g.lpb lines of one group (lpb chosen per group so that every block of the
@@ -71,13 +71,14 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   IT* ENT = FT + 64;                           // [64] topmost surviving element of the segment (or dead)
   IT* DMIN = ENT + 64;                         // [64] lowest element the segment's speculative stitch tested
   IT* BSAVE = DMIN + 64;                       // [64] local link of FT (before the patch)
+  int* SEG = (int*)(smem + 3072);                // [P + 1 <= 17] start of every segment (len and P are uniform over the block), [17..18]: {0, len}
   double* R = (double*)(smem + DT_HDR);        // [nmb][S] 1/(2a*dx) per map of this block
   const IT dead = (IT)~(IT)0;
   const int total = g.nmaps * g.nlines;
   const int nl = min(lpb, total - t.g0);
   const int m_first = t.g0 / g.nlines, m_last = (t.g0 + nl - 1) / g.nlines;
   const int nmb = m_last - m_first + 1;
-  P2* YZ = (P2*)(R + g.nmb * S);               // [lpb][S] .x: line values (never modified); .y: z of the element when pushed
+  P2* YZ = (P2*)(R + ((g.nmb * S + 1) & ~1));  // [lpb][S] (16-byte aligned: S is odd) .x: line values (never modified); .y: z of the element when pushed
   IT* B = (IT*)(YZ + lpb * S);                 // [lpb][S] element below on the stack when pushed; later: element above (read-out)
   if (lane < nl) {
     const int gi = t.g0 + lane;
@@ -133,6 +134,9 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   const int nsub = 64 / lpb;                     // lanes per line
   const int P = dt_segments(nsub, len);          // segments per line
   const int line = lane % lpb, p = lane / lpb;
+  if (lane <= P) SEG[lane] = dt_seg_start(lane, P, len);
+  if (lane == 0) { SEG[17] = 0; SEG[18] = len; }
+  __syncthreads();
   const bool mine = line < nl && p < nsub;
   DtMap mp;
   const double* Rl = R;
@@ -146,7 +150,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   }
   // ---- local scans: the envelope of every segment (DistanceTransform.hpp:156-170 on the segment alone) ----
   if (mine && p < P) {
-    if (dt_seg_scan<EX, T, IT>(YZl, Bl, Rl, dt_seg_start(p, P, len), dt_seg_start(p + 1, P, len), mp.a, mp.b)) FLAG[line] = 1;
+    if (dt_seg_scan<EX, T, IT>(YZl, Bl, Rl, SEG[p], SEG[p + 1], mp.a, mp.b)) FLAG[line] = 1;
   }
   __syncthreads();
   DT_STAMP(3);
@@ -154,7 +158,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   if (mine && p >= 1 && p < P && !FLAG[line]) {
     int f, dmin, bs;
     T zs;
-    const bool bad = dt_stitch1<EX, T, IT>(YZl, Bl, Rl, dt_seg_start(p, P, len), dt_seg_start(p + 1, P, len), mp.a, mp.b, f, dmin, zs, bs);
+    const bool bad = dt_stitch1<EX, T, IT>(YZl, Bl, Rl, SEG[p], SEG[p + 1], mp.a, mp.b, f, dmin, zs, bs);
     FT[lane] = (IT)f; DMIN[lane] = (IT)dmin; ZSAVE[lane] = zs; BSAVE[lane] = (IT)bs;
     if (bad) FLAG[line] = 1;
   }
@@ -163,7 +167,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   // ---- validate the speculation (redo the few stitches that reached below their neighbour's survivors), tables ----
   if (mine && p == 0) {
     bool redo = FLAG[line] != 0;
-    if (!redo && P > 2) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, Rl, len, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
+    if (!redo && P > 2) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, Rl, SEG, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
     int Pl = P;
     if (redo) DT_COUNT_REDO();
     if (redo) {   // a quotient next to a float rounding boundary, or near-degenerate geometry: the whole line sequentially, IEEE divisions
@@ -171,7 +175,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       Pl = 1;
     }
     FT[line] = (IT)0;
-    dt_seg_table<T, IT>(YZl, Bl, len, Pl, FT + line, ENT + line, ZLO + line, lpb, dead);
+    dt_seg_table<T, IT>(YZl, Bl, Pl == 1 ? SEG + 17 : SEG, Pl, FT + line, ENT + line, ZLO + line, lpb, dead);
     FLAG[line] = Pl;                             // segments the read-out lanes look at
   }
   __syncthreads();

@@ -322,11 +322,12 @@ static void free_frame(pbd_handle* h) {
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
 }
 
-// DT block geometry under an LDS budget.  stride = len+1 rounded up to even (keeps the double
-// table and the float arrays 8-byte aligned); lpb = lines per block (any value 4..64: the scan runs
-// one lane per line and is VALU-issue bound, so lanes per wave = throughput);
+// DT block geometry under an LDS budget.  stride = LDS elements per line: >= len + 1 and ODD — the (y, z) pairs of
+// element e of consecutive lines are then 2 * (stride mod 32) banks apart instead of in the same banks (lanes of
+// different lines work on similar element indices at the same time: with an even stride of 160 every LDS access
+// of the scan was an lpb-way bank conflict); lpb = lines per block (any value 4..64);
 // nmb = maps a block of lpb consecutive lines can touch.
-static int dt_stride_for(int len) { return (len + 2) & ~1; }
+static int dt_stride_for(int len) { return (len + 1) | 1; }
 static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (lpb + nlines - 2) / nlines + 1); }
 static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget, int ts) {
   int lpb = 64;

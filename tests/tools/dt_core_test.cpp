@@ -31,9 +31,11 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
   for (int i = 0; i < len; ++i) YZ[i].x = src[i];
   if (!EX) for (int dx = 0; dx < len; ++dx) R[dx] = 1.0 / ((2 * a) * (double)dx);
   int P = dt_segments(lanes, len);
+  std::vector<int> seg(P + 1);
+  for (int p = 0; p <= P; ++p) seg[p] = dt_seg_start(p, P, len);
   bool flag = false;
   for (int p = 0; p < P; ++p)
-    flag |= dt_seg_scan<EX, T, IT>(YZ.data(), B.data(), R.data(), dt_seg_start(p, P, len), dt_seg_start(p + 1, P, len), a, b);
+    flag |= dt_seg_scan<EX, T, IT>(YZ.data(), B.data(), R.data(), seg[p], seg[p + 1], a, b);
   if (flag) st.suspect++;
   if (!flag && P > 1) {
     // the kernel stitches all boundaries concurrently (speculation); any interleaving must give the same result:
@@ -48,20 +50,21 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
     for (int p : order) {
       int f, dmin, bs;
       T zs;
-      bad |= dt_stitch1<EX, T, IT>(YZ.data(), B.data(), R.data(), dt_seg_start(p, P, len), dt_seg_start(p + 1, P, len), a, b, f, dmin, zs, bs);
+      bad |= dt_stitch1<EX, T, IT>(YZ.data(), B.data(), R.data(), seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
       F[p] = (IT)f; DM[p] = (IT)dmin; ZS[p] = zs; BS[p] = (IT)bs;
     }
     for (int p = 2; p < P; ++p) if ((int)DM[p] <= (int)F[p - 1]) { st.events++; break; }
-    bad |= dt_stitch_validate<EX, T, IT>(YZ.data(), B.data(), R.data(), len, P, a, b, F.data(), DM.data(), ZS.data(), BS.data(), 1);
+    bad |= dt_stitch_validate<EX, T, IT>(YZ.data(), B.data(), R.data(), seg.data(), P, a, b, F.data(), DM.data(), ZS.data(), BS.data(), 1);
     if (bad) st.inconsistent++;
     flag |= bad;
   }
   if (flag) {                      // fallback: the whole line sequentially, IEEE divisions
     P = 1;
+    seg[1] = len;
     dt_seg_scan<true, T, IT>(YZ.data(), B.data(), R.data(), 0, len, a, b);
   }
   F[0] = 0;
-  dt_seg_table<T, IT>(YZ.data(), B.data(), len, P, F.data(), ENT.data(), ZLO.data(), 1, dead);
+  dt_seg_table<T, IT>(YZ.data(), B.data(), seg.data(), P, F.data(), ENT.data(), ZLO.data(), 1, dead);
   const int nsub = lanes, chunk = (len + nsub - 1) / nsub;
   for (int sub = 0; sub < nsub; ++sub) {        // read-out (:172-178), as in the kernel: descending q
     const int q0 = sub * chunk, q1 = std::min(len, q0 + chunk);
