@@ -272,6 +272,7 @@ static void launch_hog_t(const HogTile* tiles, int ntiles, const LevelDev* level
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(HOG_NT), lds, s, tiles, levels, pyr, feat, cn, sbin, tc);
   };
   if (sbin == 4 && tc == 16) go(k_hog<T, 4, 16>);
+  else if (sbin == 4 && tc == 8) go(k_hog<T, 4, 8>);
   else if (sbin == 8 && tc == 8) go(k_hog<T, 8, 8>);
   else go(k_hog<T, 0, 0>);
 }

@@ -10,9 +10,10 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-B="python $REPO/bench.py"
+B="python $REPO/bench.py --graph 0 --no-prewarm"   # eager launches under the profiler (the timed loop of the default run replays a hipGraph)
 # throughput line (default flags) and the sequential line
-$B --steps 300 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+python $REPO/bench.py --steps 300 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_n1_driverflags.json" 2>> "$OUT/bench_n1.err"
 $B --steps 100 --inflight 1 --no-cpu-baseline > "$OUT/bench_n1_inflight1.json" 2>> "$OUT/bench_n1.err"
 $B --steps 50 --dtype f64 > "$OUT/bench_n1_f64.json" 2>> "$OUT/bench_n1.err"
 # per-kernel durations: sequential (undisturbed) and default (4 frames in flight)
@@ -23,4 +24,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_f64" -o run 
 for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o run -- $B --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline > "$OUT/pmc_$c.log" 2>&1
 done
-ls -R "$OUT" | head -60
+# SQ activity of the distance-transform / reduce / filter-bank kernels: one counter per pass
+for c in SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/sq_$c" -o run -- $B --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline > "$OUT/sq_$c.log" 2>&1
+done
+# configs[4]: direct VALU correlation vs MFMA implicit GEMM for N = 26 .. 312 filters (stage times + per-kernel view)
+python $REPO/profiles/conv_modes.py > "$OUT/conv_modes.json" 2> "$OUT/conv_modes.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_conv_modes" -o run -- python $REPO/profiles/conv_modes.py > /dev/null 2>&1
+# gpurun merges at most 64 MiB back: the per-dispatch traces are not needed by summarize.py (stats + counter CSVs are)
+find "$OUT" -name "*kernel_trace.csv" -delete
+find "$OUT" -name "*agent_info.csv" -delete
+du -sh "$OUT"

@@ -66,7 +66,12 @@ for d, title in (("stats_seq", "rocprofv3 --kernel-trace --stats -- python bench
         shutil.copy(path, os.path.join(HERE, f"{tag}_kernel_{d}.csv"))
 fetch, write, clk = pmc("FETCH_SIZE"), pmc("WRITE_SIZE"), pmc("GRBM_GUI_ACTIVE")
 if fetch:
-    nframes = max(1, fetch.get("k_root<float>", fetch.get("k_root", [1]))[0])
+    def frames_of(acc):   # every pass runs its own number of frames: one k_root launch per frame
+        for k in acc:
+            if k.startswith("k_root"):
+                return max(1, acc[k][0])
+        return 1
+    nframes, nframes_w = frames_of(fetch), frames_of(write)
     md += ["## PMC passes (one counter per run): rocprofv3 --pmc <C> --kernel-trace -- python bench.py --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline",
            f"({nframes} frames per run.)  FETCH_SIZE / WRITE_SIZE are in KB; gfx950 note (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
            "under-reports coalesced streaming reads by 2x — RAW values here, `traffic_dp.json` applies the x2.  "
@@ -77,17 +82,58 @@ if fetch:
         c_ = clk.get(k)
         ghz = f"{c_[1] / 8 / c_[2]:.2f}" if c_ and c_[2] else "-"
         md.append(f"| `{k}` | {f_[0]} | {f_[1] / f_[0]:.1f} | {w_[1] / max(w_[0], 1):.1f} | {f_[1] / nframes / 1e3:.1f} | "
-                  f"{w_[1] / nframes / 1e3:.1f} | {ghz} |")
+                  f"{w_[1] / nframes_w / 1e3:.1f} | {ghz} |")
     dpk = [k for k in fetch if k.startswith(("k_dt_pass", "k_reduce", "k_root"))]
     fb = sum(fetch[k][1] for k in dpk) * 1e3 / nframes
-    wb = sum(write.get(k, [0, 0.0])[1] for k in dpk) * 1e3 / nframes
+    wb = sum(write.get(k, [0, 0.0])[1] for k in dpk) * 1e3 / nframes_w
     json.dump({"round": tag, "source": f"profiles/{tag}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --inflight 1)",
                "kernels": sorted(dpk), "fetch_bytes_raw": fb, "write_bytes": wb,
                "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated, taken as is",
                "hbm_bytes_per_frame_corrected": 2 * fb + wb}, open(os.path.join(HERE, "traffic_dp.json"), "w"), indent=1)
     md += ["", f"dp_min stage ({', '.join(sorted(dpk))}): fetch {fb / 1e6:.1f} MB raw (x2 = {2 * fb / 1e6:.1f} MB) + write {wb / 1e6:.1f} MB "
            f"= {(2 * fb + wb) / 1e6:.1f} MB per frame (algorithmic B_dp: see bench line)."]
-for b in ("bench_n1.json", "bench_n1_inflight1.json", "bench_n1_f64.json"):
+# SQ counters (one per pass) for the kernels of the dp_min stage and the filter bank
+sq = {}
+for d in sorted(glob.glob(os.path.join(src, "sq_*"))):
+    c = os.path.basename(d)[3:]
+    if not os.path.isdir(d):
+        continue
+    f = glob.glob(os.path.join(d, "*counter_collection.csv")) + glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    if not f:
+        continue
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] != c:
+            continue
+        k = short(r["Kernel_Name"])
+        if not k.startswith(("k_dt_pass", "k_reduce", "k_conv", "k_hog")):
+            continue
+        a = sq.setdefault(k, {}).setdefault(c, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+if sq:
+    cs = sorted({c for k in sq for c in sq[k]})
+    md += ["", "## SQ counters per launch (rocprofv3 --pmc <C> --kernel-trace, one counter per pass, sequential frames; SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* "
+           "count quad-cycles summed over all waves)", "| kernel | " + " | ".join(cs) + " | ACTIVE_INST_ANY / WAVE_CYCLES | INSTS_VALU per WAVE_CYCLE |",
+           "|---|" + "---|" * (len(cs) + 2)]
+    for k in sorted(sq):
+        v = {c: sq[k][c][1] / sq[k][c][0] for c in sq[k]}
+        wc = v.get("SQ_WAVE_CYCLES", 0)
+        md.append(f"| `{k}` | " + " | ".join(f"{v[c]:.3g}" if c in v else "-" for c in cs) +
+                  f" | {v.get('SQ_ACTIVE_INST_ANY', 0) / wc if wc else 0:.3f} | {v.get('SQ_INSTS_VALU', 0) / wc if wc else 0:.3f} |")
+cm = os.path.join(src, "conv_modes.json")
+if os.path.exists(cm) and os.path.getsize(cm):
+    j = json.load(open(cm))
+    shutil.copy(cm, os.path.join(HERE, f"{tag}_conv_modes.json"))
+    md += ["", f"## configs[4]: direct VALU correlation vs fp32 MFMA implicit GEMM ({j['workload']}; profiles/conv_modes.py, stage times from HIP events)",
+           "| K | filters N | N x 800 | exact VALU ms | TFLOP/s | MFMA ms | TFLOP/s | PBD_CONV_AUTO |", "|---|---|---|---|---|---|---|---|"]
+    for r in j["rows"]:
+        md.append(f"| {r['mixtures']} | {r['filters']} | {r['contraction_NxK']} | {r['exact_valu_ms']} | {r['exact_valu_tflops']} | {r['mfma_f32_ms']} | "
+                  f"{r['mfma_f32_tflops']} | {r['auto_picks']} |")
+    t, path = stats_table("stats_conv_modes")
+    if t:
+        md += ["", "per-kernel view of the same script (rocprofv3 --kernel-trace --stats):", t]
+        shutil.copy(path, os.path.join(HERE, f"{tag}_kernel_stats_conv_modes.csv"))
+for b in ("bench_n1.json", "bench_n1_driverflags.json", "bench_n1_inflight1.json", "bench_n1_f64.json"):
     p = os.path.join(src, b)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(HERE, f"{tag}_{b}"))
