@@ -479,7 +479,7 @@ template <typename T, int KH, int KW, int NHALF, int WPE, int NTW = 1>   // WPE:
 __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __restrict__ tiles,
                                                      const LevelDev* __restrict__ levels,
                                                      const T* __restrict__ feat, const T* __restrict__ wT,
-                                                     T* __restrict__ resp, int nf, int nfpad) {
+                                                     T* __restrict__ resp, int nf, int nfpad, int ntiles_total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Mfma16<T> MM;
   constexpr int TW = CT + KW - 1, TH = CT + KH - 1, NTAP = KH * KW;
@@ -490,18 +490,28 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   CONV_STAMP(0);
 #ifdef PBD_PROBES
   {  // probe: issue priority by workgroup index, to pull co-resident workgroups out of phase
-    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned lin_ = blockIdx.x + blockIdx.y * gridDim.x;
     const int mode = nfpad >> 16;
-    const unsigned pr = mode == 1 ? (lin & 3u) : mode == 2 ? ((lin >> 8) & 3u) : mode == 3 ? ((lin >> 3) & 3u) : mode == 4 ? ((lin >> 10) & 3u) : mode == 5 ? (blockIdx.y & 3u) : 0u;
+    const unsigned pr = mode == 1 ? (lin_ & 3u) : mode == 2 ? ((lin_ >> 8) & 3u) : mode == 3 ? ((lin_ >> 3) & 3u) : mode == 4 ? ((lin_ >> 10) & 3u) : mode == 5 ? (blockIdx.y & 3u) : 0u;
     if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3);
   }
   nfpad &= 0xffff;
 #endif
-  const ConvTile t = tiles[blockIdx.x];
+  // XCD-aware workgroup -> (tile, n-tile) mapping.  Workgroup b runs on XCD b % 8 and every XCD has its own L2; the
+  // ny n-tile workgroups of one spatial tile all stage the same 20x20-cell feature tile.  With (tile, n-tile) =
+  // (blockIdx.x, blockIdx.y) they were 604 workgroups apart and on 8 different XCDs: the tile came from HBM ~10
+  // times (FETCH 5.9x the algorithmic bytes, r01).  Here groups of 8 tiles x ny n-tiles are laid out so that all
+  // n-tiles of a tile share b % 8 and are dispatched within 8 * ny consecutive workgroups: one HBM fetch, ny - 1 L2 hits.
+  const int ny = gridDim.y;                      // n-tiles (the launch keeps the 2-D grid shape; only the roles are permuted)
+  const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+  const int grp = lin / (8 * ny), rem = lin - grp * (8 * ny);
+  const int tile_i = grp * 8 + (rem & 7), ntile_i = rem >> 3;
+  if (tile_i >= ntiles_total) return;            // the grid is padded to a multiple of 8 tiles
+  const ConvTile t = tiles[tile_i];
   const LevelDev lv = levels[t.level];
   const int H = lv.ch, W = lv.cw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nbase = blockIdx.y * (16 * NTW);
+  const int nbase = ntile_i * (16 * NTW);
   const T* F = feat + lv.cell_off * PBD_FLEN;
   const int ai = lane & 15, ak = lane >> 4;
   const T* bsrc = wT + (size_t)ak * nfpad + nbase + ai;     // B[k = ak][j = ai] of k-step 0, tap 0, half 0, n-tile 0 (n-tile nt: + 16 nt)
@@ -622,9 +632,9 @@ static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelD
   const size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + 1), sizeof(T) * 4 * 16 * 65);
   static LdsOptIn optin;   // one per instantiation
   optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>, lds);
-  dim3 grid(ntiles, (nf + 16 * NTW - 1) / (16 * NTW));
+  dim3 grid((ntiles + 7) / 8 * 8, (nf + 16 * NTW - 1) / (16 * NTW));   // tiles padded to a multiple of 8 (XCD-aware mapping in the kernel)
   static const int prio_mode = PBD_PROBE_ENV("PBD_CONV_PRIO") ? atoi(PBD_PROBE_ENV("PBD_CONV_PRIO")) : 0;   // probe build only
-  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16));
+  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles);
 }
 
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
