@@ -32,6 +32,7 @@ void hog_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i
 struct HogLds {
   int PT;        // pixel window side
   int NB;        // blocks per side (TC+2)
+  int P0;        // window rows / columns kept before the first pixel that contributes to the tile's first block
   int MG;        // raw-tile margin before the window (source clamping can reach back sbin/2 pixels)
   int RT;        // raw tile side
   size_t mag_off, bin_off, hist_off, norm_off, ninv_off, tab_off, raw_off, total;
@@ -40,19 +41,28 @@ struct HogLds {
 __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int cn, int ts) {   // ts = sizeof(T)
   HogLds L;
   L.NB = tc + 2;
-  L.PT = L.NB * sbin + sbin + 2;
+  // A pixel y feeds the blocks floor((y + 0.5) / sbin - 0.5) and the next one (:252-255): block b receives exactly the
+  // 2*sbin pixels from b*sbin - sbin/2 on when sbin is even, so NB blocks need (NB + 1) * sbin window rows.  Odd cell
+  // sizes keep one spare row on either side.  (For sbin 4 / 16-cell tiles: 76 instead of 78 rows — with the
+  // overlays below 52.8 KB of LDS per workgroup, i.e. THREE workgroups per CU: the 604 tiles of a 640x480 pyramid
+  // are then resident at once instead of in two generations.)
+  L.P0 = (sbin & 1) ? 1 : 0;
+  L.PT = L.NB * sbin + sbin + 2 * L.P0;
   L.MG = sbin / 2 + 2;
   L.RT = L.PT + L.MG + 1;
   size_t o = 0;
-  L.mag_off = o; o += (size_t)ts * L.PT * L.PT;
+  // (|g|, bin) per window pixel are dead once the histograms are complete: the block energies and the normalisers
+  // are written over them (a barrier separates the phases)
+  L.mag_off = o; L.norm_off = o; L.ninv_off = o + (size_t)ts * L.NB * L.NB;
+  {
+    const size_t a = (size_t)ts * L.PT * L.PT, b = (size_t)ts * (L.NB * L.NB + (tc + 1) * (tc + 1));
+    o += ((a > b ? a : b) + 7) & ~(size_t)7;
+  }
   // the staged source pixels (raw) are dead once (|g|, bin) are computed and the histograms are not live
-  // before: they share one region (one barrier more) — 20 KB less LDS per workgroup, which leaves room for
-  // other kernels' workgroups on the CU
+  // before: they share one region (one barrier more)
   const size_t hist_bytes = (size_t)ts * L.NB * L.NB * PBD_NORIENT, raw_bytes = (size_t)L.RT * L.RT * cn;
   L.hist_off = o; L.raw_off = o;
   o += ((hist_bytes > raw_bytes ? hist_bytes : raw_bytes) + 7) & ~(size_t)7;
-  L.norm_off = o; o += (size_t)ts * L.NB * L.NB;
-  L.ninv_off = o; o += (size_t)ts * (tc + 1) * (tc + 1);
   L.tab_off = o; o += ((size_t)ts * 2 + sizeof(int)) * 2 * L.PT;  // w0,w1,ip for y and x
   L.bin_off = o; o += L.PT * L.PT;
   L.total = (o + 15) & ~(size_t)15;
@@ -92,8 +102,8 @@ __global__ __launch_bounds__(HOG_NT) void k_hog(const HogTile* __restrict__ tile
   const int vw = bw * sbin, vh = bh * sbin;  // :176 visible
   const uint8_t* im = pyr + lv.img_off;
   const int stride = w * cn;
-  // pixel window origin: first pixel that can touch block (cy0, cx0), minus one for safety
-  const int py0 = t.cy0 * sbin - sbin / 2 - 1, px0 = t.cx0 * sbin - sbin / 2 - 1;
+  // pixel window origin: first pixel that can touch block (cy0, cx0) (one more before it for odd cell sizes)
+  const int py0 = t.cy0 * sbin - (sbin + 1) / 2 - L.P0, px0 = t.cx0 * sbin - (sbin + 1) / 2 - L.P0;
   const int ry0 = py0 - L.MG, rx0 = px0 - L.MG;  // raw tile origin (source coordinates, clamped on load)
 
   // ---- stage the source pixels of the window (+margins) in LDS, coalesced byte rows ----
