@@ -77,6 +77,41 @@ def cpu_info():
     return model, (len(cores) or nthreads), nthreads
 
 
+def main_group(args):
+    """bench.py --group --gpus N: the single-process path of SURVEY 8b / 8e (pbd_group_detect_batch_u8)."""
+    import torch
+    from partsbaseddetector_amd import capi
+    from partsbaseddetector_amd.model import make_image, make_person_model
+    W, H, N, S = args.width, args.height, args.gpus, max(1, args.inflight)
+    if torch.cuda.device_count() < N:
+        raise SystemExit(f"--gpus {N} but only {torch.cuda.device_count()} devices are visible")
+    model = make_person_model(K=args.mixtures)
+    dtype = np.float64 if args.dtype == "f64" else np.float32
+    model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).cuda(), W, H, dtype=dtype)
+    conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA}[args.conv]
+    g = capi.Group(model, [d for _ in range(S) for d in range(N)], gather=capi.PBD_GATHER_HOST, conv_mode=conv, dtype=dtype, graph=args.graph)
+    pinned = [torch.from_numpy(make_image(i, W, H)).pin_memory() for i in range(8)]
+    frames = [t.numpy() for t in pinned]
+    t0 = time.perf_counter()
+    nwarm = 0
+    while time.perf_counter() - t0 < PREWARM_S and not args.no_prewarm:
+        g.detect_batch([frames[i % 8] for i in range(4 * N * S)]); nwarm += 4 * N * S
+    g.detect_batch([frames[i % 8] for i in range(max(1, args.warmup) * N)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = g.detect_batch([frames[i % 8] for i in range(args.steps * N)])
+    dt = time.perf_counter() - t0
+    line = {"metric": f"detect() frames/sec, {W}x{H}, 26-part person model", "value": round(args.steps * N / dt, 3), "unit": "frames/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"person 26 parts x {args.mixtures} mixtures, {W}x{H} BGR, full pyramid, threshold = 99.9th pct of root scores",
+                       "frames_per_step_per_gpu": 1, "inflight": S, "input": "pinned host images (H2D inside the timed region)",
+                       "parallelism": f"pbd_group: one process, {N} device(s) x {S} members, host gather", "prewarm_frames": nwarm,
+                       "candidates_last_frame": int(len(outs[-1][0]))}}
+    print(json.dumps(line), flush=True)
+    g.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +131,10 @@ def main():
                     help="N>1: 'frames' = every rank its own frames (weak scaling, the BASELINE metric); 'levels' = all "
                          "ranks work on the SAME frames, each on an LPT-balanced set of pyramid levels (strong scaling, "
                          "BASELINE configs[3]: use with --width 1920 --height 1080)")
+    ap.add_argument("--group", action="store_true",
+                    help="ONE process driving --gpus N devices through pbd_group (no torchrun): every device listed --inflight "
+                         "times, frames round-robin and software-pipelined over the members, host images in (H2D inside "
+                         "the timed region), host gather of the candidates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("PBD_GRAPH", "1")), help="pbd_options.graph: replay a captured hipGraph per frame")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm (profiling runs)")
@@ -108,6 +147,8 @@ def main():
     from partsbaseddetector_amd.model import make_image, make_person_model
     from partsbaseddetector_amd.parallel import gather_candidates
 
+    if args.group:
+        return main_group(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -232,7 +232,43 @@ int pbd_group_detect_batch_u8(pbd_group* g, const uint8_t* const* ims, int nfram
   if (rc) return rc;
   const int mp = g->m[0]->max_parts;
   int status = PBD_OK;
-  for (int f0 = 0; f0 < nframes; f0 += n) {
+  auto emit_frame = [&](int i, int f) -> int {      // member i's records -> the caller's slot of frame f
+    counts[f] = g->found[i];
+    std::vector<const char*> recs((size_t)g->found[i]);
+    for (int j = 0; j < g->found[i]; ++j) recs[j] = rec_ptr(g, i, j);
+    int r = pbd_i_emit(g->m[i], recs, heads + (size_t)f * capacity, boxes ? boxes + (size_t)f * capacity * mp * 4 : nullptr,
+                       locs ? locs + (size_t)f * capacity * mp * 3 : nullptr, capacity);
+    if (r == PBD_ERR_CAPACITY) { status = gfail(g, r, "frame " + std::to_string(f) + ": output capacity too small"); return PBD_OK; }
+    if (r) return gfail(g, r, pbd_last_error(g->m[i]));
+    return PBD_OK;
+  };
+  if (g->mode == PBD_GATHER_HOST) {
+    // software pipeline: a member gets its next frame as soon as its previous one has been collected, so every
+    // member always has a frame in flight (list a device several times to keep several frames in flight on it)
+    g->found.assign(n, 0);
+    std::vector<int> frame_of(n, -1);
+    auto collect_member = [&](int i) -> int {
+      pbd_handle* h = g->m[i];
+      GHIP(g, hipSetDevice(g->dev[i]));
+      GHIP(g, hipStreamSynchronize(h->stream));
+      g->found[i] = h->h_cand_count[0];
+      GMEMBER(g, i, pbd_i_finish_frame(h, g->found[i]));
+      const int f = frame_of[i];
+      frame_of[i] = -1;
+      return emit_frame(i, f);
+    };
+    for (int f = 0; f < nframes; ++f) {
+      const int i = f % n;
+      if (!ims[f]) return gfail(g, PBD_ERR_ARG, "null frame pointer");
+      if (frame_of[i] >= 0 && (rc = collect_member(i))) return rc;
+      GMEMBER(g, i, pbd_detect_enqueue_u8(g->m[i], ims[f], w, hgt, cn, stride));
+      frame_of[i] = f;
+    }
+    for (int f = std::max(0, nframes - n); f < nframes; ++f)      // drain in frame order
+      if (frame_of[f % n] == f && (rc = collect_member(f % n))) return rc;
+    return status;
+  }
+  for (int f0 = 0; f0 < nframes; f0 += n) {        // RCCL gather is a collective over the members: waves of n frames
     const int k = std::min(n, nframes - f0);
     std::vector<char> active(n, 0);
     for (int i = 0; i < k; ++i) {   // frame f0+i on member i: asynchronous H2D + all kernels, nothing waits here
@@ -241,16 +277,8 @@ int pbd_group_detect_batch_u8(pbd_group* g, const uint8_t* const* ims, int nfram
       active[i] = 1;
     }
     if ((rc = gather(g, active))) return rc;
-    for (int i = 0; i < k; ++i) {
-      const int f = f0 + i;
-      counts[f] = g->found[i];
-      std::vector<const char*> recs((size_t)g->found[i]);
-      for (int j = 0; j < g->found[i]; ++j) recs[j] = rec_ptr(g, i, j);
-      rc = pbd_i_emit(g->m[i], recs, heads + (size_t)f * capacity, boxes ? boxes + (size_t)f * capacity * mp * 4 : nullptr,
-                      locs ? locs + (size_t)f * capacity * mp * 3 : nullptr, capacity);
-      if (rc == PBD_ERR_CAPACITY) { status = gfail(g, rc, "frame " + std::to_string(f) + ": output capacity too small"); continue; }
-      if (rc) return gfail(g, rc, pbd_last_error(g->m[i]));
-    }
+    for (int i = 0; i < k; ++i)
+      if ((rc = emit_frame(i, f0 + i))) return rc;
   }
   return status;
 }

@@ -801,7 +801,13 @@ def test_group_batch_two_handles_one_gpu_equals_single_handle(gpu_required, orc)
     # level-sharded single frame over the same two members, then batches again (level sets are reset)
     assert_candidates_equal(g.detect(frames[1]), single.detect(frames[1]))
     assert_candidates_equal(g.detect_batch(frames[:1])[0], single.detect(frames[0]))
-    single.close(); g.close()
+    g.close()
+    # three members replaying captured graphs, a batch longer than the group (software pipeline: a member gets its
+    # next frame as soon as its previous one is collected)
+    g3 = capi.Group(m, [0, 0, 0], conv_mode=capi.PBD_CONV_EXACT, graph=1)
+    for got, f in zip(g3.detect_batch(frames * 3), frames * 3):
+        assert_candidates_equal(got, single.detect(f))
+    single.close(); g3.close()
 
 
 def test_group_level_sharding_more_members_than_needed(gpu_required, orc):
