@@ -483,7 +483,10 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Mfma16<T> MM;
   constexpr int TW = CT + KW - 1, TH = CT + KH - 1, NTAP = KH * KW;
-  constexpr int CH = PBD_FLEN / NHALF, CS = CH + 1, KS = CH / 4;   // channels per pass, LDS cell stride, k-steps per tap
+  // channels per pass, LDS cell stride, k-steps per tap.  Float: stride CH + 2 = 18 dwords: the 32 lanes of one LDS
+  // access group (16 cells x 2 channels) then hit 32 different banks (16 * 18 mod 32 are the 16 even residues); with
+  // 17 the cell 15 / channel 1 lane fell on cell 0's bank (SQ_LDS_BANK_CONFLICT was twice SQ_ACTIVE_INST_LDS)
+  constexpr int CH = PBD_FLEN / NHALF, CS = CH + (sizeof(T) == 4 ? 2 : 1), KS = CH / 4;
   constexpr int EPV = 16 / (int)sizeof(T), LPC = CH / EPV;         // elements per 16-byte vector, lanes per cell
   struct alignas(16) V { T e[EPV]; };
   T* ft = (T*)smem;                         // [TH][TW][CS]
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
 template <typename T, int NHALF, int WPE, int NTW = 1>
 static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
                                  const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
-  const size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + 1), sizeof(T) * 4 * 16 * 65);
+  const size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + (sizeof(T) == 4 ? 2 : 1)), sizeof(T) * 4 * 16 * 65);
   static LdsOptIn optin;   // one per instantiation
   optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>, lds);
   dim3 grid((ntiles + 7) / 8 * 8, (nf + 16 * NTW - 1) / (16 * NTW));   // tiles padded to a multiple of 8 (XCD-aware mapping in the kernel)
