@@ -62,7 +62,7 @@ DT_HD unsigned long long dt_bits(double d) { unsigned long long u; memcpy(&u, &d
 #endif
 template <typename T> struct alignas(2 * sizeof(T)) DtPair { T x, y; };
 
-// segment p of P over a line of `len` elements: [dt_seg_start(p), dt_seg_start(p + 1)).  p * len < 2^20 (p <= 16, len < 2^15):
+// segment p of P over a line of `len` elements: [dt_seg_start(p), dt_seg_start(p + 1)).  p * len < 2^20 (p <= 32, len < 2^15):
 // a 32-bit division; the kernel evaluates it once per block into a table (seg[0..P]) that the routines below take.
 DT_HD int dt_seg_start(int p, int P, int len) { return (int)((unsigned)(p * len) / (unsigned)P); }
 // segments actually used for a line: at least 8 elements each (short lines gain nothing from stitching)

@@ -30,8 +30,27 @@
 // debug: per-phase timestamps (100 MHz wall clock) of block 0 of the last k_dt_pass launch
 #ifdef PBD_PROBES
 __device__ unsigned long long pbd_dt_dbg[8];
-#define DT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pbd_dt_dbg[i] = wall_clock64(); } while (0)
 #define DT_COUNT_REDO() atomicAdd(&pbd_dt_dbg[7], 1ull)
+#define DT_NOVALIDATE(g) ((g).pad & 1)
+// block trace: (start, end) wall clock and hardware id of every block of the first 40 launches since the last read
+#define DT_TRACE_L 40
+#define DT_TRACE_B 4096
+__device__ unsigned long long pbd_dt_trace[DT_TRACE_L][DT_TRACE_B][8];   // [0..6]: the DT_STAMP phases, [7]: end
+__device__ unsigned pbd_dt_trace_hw[DT_TRACE_L][DT_TRACE_B];
+__device__ int pbd_dt_trace_launch = DT_TRACE_L;   // off until PBD_DT_TRACE is set
+static int g_dt_trace_seq = 0;
+#define DT_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); if (blockIdx.x == 0) pbd_dt_dbg[i] = now_; \
+    if (i && pbd_dt_trace_launch < 40 && blockIdx.x < 4096) pbd_dt_trace[pbd_dt_trace_launch][blockIdx.x][i] = now_; } } while (0)
+#define DT_TRACE(k) do { if (threadIdx.x == 0 && pbd_dt_trace_launch < DT_TRACE_L && blockIdx.x < DT_TRACE_B) { \
+    pbd_dt_trace[pbd_dt_trace_launch][blockIdx.x][k ? 7 : 0] = wall_clock64(); \
+    if (k == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); pbd_dt_trace_hw[pbd_dt_trace_launch][blockIdx.x] = (hw & 0xffffff) | (xcc << 24); } } } while (0)
+int dt_debug_trace(unsigned long long* t, unsigned* hw, int* nlaunch) {
+  hipMemcpyFromSymbol(t, HIP_SYMBOL(pbd_dt_trace), sizeof(unsigned long long) * DT_TRACE_L * DT_TRACE_B * 8);
+  hipMemcpyFromSymbol(hw, HIP_SYMBOL(pbd_dt_trace_hw), sizeof(unsigned) * DT_TRACE_L * DT_TRACE_B);
+  *nlaunch = g_dt_trace_seq;
+  g_dt_trace_seq = 0;
+  return 0;
+}
 void dt_debug_read(unsigned long long* out) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_dt_dbg), sizeof(unsigned long long) * 8);
   const unsigned long long z = 0;
@@ -40,39 +59,44 @@ void dt_debug_read(unsigned long long* out) {
 #else
 #define DT_STAMP(i) do { } while (0)
 #define DT_COUNT_REDO() do { } while (0)
+#define DT_NOVALIDATE(g) false
+#define DT_TRACE(k) do { } while (0)
 void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i] = 0; }
 #endif
 
-// LDS per block: per-lane descriptors and segment tables (DT_HDR bytes), per map touched by the block a table of
-// exact reciprocals 1/(2a*dx), dx < len (double[S]), and per line {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
+// LDS per block: a header (per-line and per-lane descriptors, segment table), per map touched by the block a table
+// of exact reciprocals 1/(2a*dx), dx < len (double[S]), and per line {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
 // 9 bytes per line element for float: the lines resident on a CU are bounded by these bytes.
-#define DT_HDR 3200
-size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts) {   // ts = sizeof(T): (y, z) is a float or a double pair
-  return (size_t)lpb * stride * (2 * ts + (stride <= 256 ? 1 : 2)) + DT_HDR + (((size_t)nmb * stride + 1) & ~(size_t)1) * 8 + 16;
+#define DT_SEGS 40                                   // SEG entries: P + 1 <= 33 starts, then {0, len} for a line redone as one segment
+__host__ __device__ inline size_t dt_hdr_bytes(int nt, int ts, int its) {
+  return ((size_t)64 * 8 + 64 * 4 + DT_SEGS * 4 + (size_t)nt * (2 * ts + 4 * its) + 15) & ~(size_t)15;
+}
+size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts, int nt) {   // ts = sizeof(T): (y, z) is a float or a double pair
+  const int its = stride <= 256 ? 1 : 2;
+  return (size_t)lpb * stride * (2 * ts + its) + dt_hdr_bytes(nt, ts, its) + (((size_t)nmb * stride + 1) & ~(size_t)1) * 8 + 16;
 }
 
-// One block = one wavefront = up to g.lpb lines of one group (lpb chosen per group so that every block of the
-// launch fits the same LDS budget: long lines -> fewer lines per block -> many more blocks).  LDS capacity leaves
-// most lanes of a wave without a line of their own, so the 64 / lpb lanes that share a line each scan one SEGMENT of
-// it concurrently and the segments are stitched into the sequential result (dt_core.hpp): lane = p * lpb + line.
+// One block = NT lanes (one or two wavefronts) = up to g.lpb lines of one group (lpb chosen per group so that every
+// block of the launch fits the same LDS budget: long lines -> fewer lines per block -> many more blocks).  LDS
+// capacity leaves most lanes without a line of their own, so the NT / lpb lanes that share a line each scan one
+// SEGMENT of it concurrently and the segments are stitched into the sequential result (dt_core.hpp):
+// lane = p * lpb + line.
 template <typename T, typename IT>
 __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, NT = blockDim.x;
   const int len = g.len, S = g.stride, lpb = g.lpb;
   typedef DtPair<T> P2;
   constexpr bool EX = sizeof(T) == 8;          // DistanceTransform<double>: s is not narrowed, every intersection takes the IEEE division
   const T** lptr = (const T**)smem;            // [64] source pointer of each line of this block
-  int16_t** pptr = (int16_t**)(smem + 64 * 8); // [64] pointer-output base of each line
-  int* pstr = (int*)(smem + 64 * 16);          // [64] pointer-output element stride of each line
-  int* FLAG = (int*)(smem + 64 * 20);          // [64] per line: redo sequentially (suspect quotient / lost stitch invariant); then: segments in use
-  T* ZLO = (T*)(smem + 64 * 24);               // [64] per lane (p * lpb + line): z of the segment's lowest surviving element
-  T* ZSAVE = (T*)(smem + 64 * 32);             // [64] per lane: that element's local z (before the stitch patched it)
-  IT* FT = (IT*)(smem + 64 * 40);              // [64] per lane: that element
-  IT* ENT = FT + 64;                           // [64] topmost surviving element of the segment (or dead)
-  IT* DMIN = ENT + 64;                         // [64] lowest element the segment's speculative stitch tested
-  IT* BSAVE = DMIN + 64;                       // [64] local link of FT (before the patch)
-  int* SEG = (int*)(smem + 3072);                // [P + 1 <= 17] start of every segment (len and P are uniform over the block), [17..18]: {0, len}
-  double* R = (double*)(smem + DT_HDR);        // [nmb][S] 1/(2a*dx) per map of this block
+  int* FLAG = (int*)(smem + 64 * 8);           // [64] per line: redo sequentially (suspect quotient / lost stitch invariant); then: segments in use
+  int* SEG = FLAG + 64;                        // [P + 1 <= 33] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
+  T* ZLO = (T*)(SEG + DT_SEGS);                // [NT] per lane (p * lpb + line): z of the segment's lowest surviving element
+  T* ZSAVE = ZLO + NT;                         // [NT] per lane: that element's local z (before the stitch patched it)
+  IT* FT = (IT*)(ZSAVE + NT);                  // [NT] per lane: that element
+  IT* ENT = FT + NT;                           // [NT] topmost surviving element of the segment (or dead)
+  IT* DMIN = ENT + NT;                         // [NT] lowest element the segment's speculative stitch tested
+  IT* BSAVE = DMIN + NT;                       // [NT] local link of FT (before the patch)
+  double* R = (double*)(smem + dt_hdr_bytes(NT, sizeof(T), sizeof(IT)));   // [nmb][S] 1/(2a*dx) per map of this block
   const IT dead = (IT)~(IT)0;
   const int total = g.nmaps * g.nlines;
   const int nl = min(lpb, total - t.g0);
@@ -85,17 +109,13 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const int mi = gi / g.nlines, li = gi - mi * g.nlines;
     const DtMap& mp0 = maps[g.map0 + mi];
     lptr[lane] = (const T*)mp0.src + (size_t)li * len;
-    // pointers: transposed like dst (y pass -> natural layout) or natural (x pass)
-    const bool nat = mp0.ptr_natural != 0;
-    pptr[lane] = mp0.ptr + (nat ? (size_t)li * len : (size_t)li);
-    pstr[lane] = nat ? 1 : g.nlines;
     FLAG[lane] = 0;
   }
   // reciprocal tables: one IEEE division per (map, dx), spread over the 64 lanes
   if constexpr (!EX) {
     for (int ms = 0; ms < nmb; ++ms) {
       const double a = maps[g.map0 + m_first + ms].a;
-      for (int dx = lane; dx < len; dx += 64) R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
+      for (int dx = lane; dx < len; dx += NT) R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
     }
   }
   __syncthreads();
@@ -109,21 +129,22 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     // chunk -> (line, chunk of line) by a reciprocal multiply: an integer division per load and per store
     // costs more VALU time than the loads take (c * CH < 2^20 here: c < 64 * CH, CH <= 512)
     const unsigned inv = (1u << 20) / (unsigned)CH + 1u;
-    constexpr int LB = 36;                   // loads in flight per lane (one round trip covers a whole 11-12 line block)
-    for (int c0 = 0; c0 < nch; c0 += LB) {
+    constexpr int LB = sizeof(T) == 8 ? 18 : 36;   // loads in flight per lane (float: one round trip covers a whole 11-12 line block)
+    const int W = NT >> 6, wv = __builtin_amdgcn_readfirstlane(lane >> 6), l64 = lane & 63;   // chunks are dealt to the wavefronts in turn
+    for (int c0 = 0; c0 * W < nch; c0 += LB) {
       T r[LB];
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
-        const int c = min(c0 + j, nch - 1);
+        const int c = min((c0 + j) * W + wv, nch - 1);
         const int i = (int)(((unsigned)c * inv) >> 20);
-        const int q = min((c - i * CH) * 64 + lane, len - 1);
+        const int q = min((c - i * CH) * 64 + l64, len - 1);
         r[j] = lptr[i][q];
       }
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
-        const int c = c0 + j, cc = min(c, nch - 1);
+        const int c = (c0 + j) * W + wv, cc = min(c, nch - 1);
         const int i = (int)(((unsigned)cc * inv) >> 20);
-        const int q = (cc - i * CH) * 64 + lane;
+        const int q = (cc - i * CH) * 64 + l64;
         if (c < nch && q < len) YZ[i * S + q].x = r[j];
       }
     }
@@ -131,11 +152,11 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   __syncthreads();
   DT_STAMP(2);
 
-  const int nsub = 64 / lpb;                     // lanes per line
+  const int nsub = NT / lpb;                     // lanes per line
   const int P = dt_segments(nsub, len);          // segments per line
   const int line = lane % lpb, p = lane / lpb;
   if (lane <= P) SEG[lane] = dt_seg_start(lane, P, len);
-  if (lane == 0) { SEG[17] = 0; SEG[18] = len; }
+  if (lane == 0) { SEG[DT_SEGS - 2] = 0; SEG[DT_SEGS - 1] = len; }
   __syncthreads();
   const bool mine = line < nl && p < nsub;
   DtMap mp;
@@ -167,7 +188,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   // ---- validate the speculation (redo the few stitches that reached below their neighbour's survivors), tables ----
   if (mine && p == 0) {
     bool redo = FLAG[line] != 0;
-    if (!redo && P > 2) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, Rl, SEG, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
+    if (!redo && P > 2 && !DT_NOVALIDATE(g)) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, Rl, SEG, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
     int Pl = P;
     if (redo) DT_COUNT_REDO();
     if (redo) {   // a quotient next to a float rounding boundary, or near-degenerate geometry: the whole line sequentially, IEEE divisions
@@ -175,7 +196,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       Pl = 1;
     }
     FT[line] = (IT)0;
-    dt_seg_table<T, IT>(YZl, Bl, Pl == 1 ? SEG + 17 : SEG, Pl, FT + line, ENT + line, ZLO + line, lpb, dead);
+    dt_seg_table<T, IT>(YZl, Bl, Pl == 1 ? SEG + DT_SEGS - 2 : SEG, Pl, FT + line, ENT + line, ZLO + line, lpb, dead);
     FLAG[line] = Pl;                             // segments the read-out lanes look at
   }
   __syncthreads();
@@ -191,8 +212,10 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const int gi = t.g0 + line;
     const int mi = gi / g.nlines, li = gi - mi * g.nlines;
     const double a = mp.a, b = mp.b;
-    int16_t* pp = pptr[line];
-    const int pst = pstr[line];
+    // pointers: transposed like dst (y pass -> natural layout) or natural (x pass)
+    const bool nat = mp.ptr_natural != 0;
+    int16_t* pp = mp.ptr + (nat ? (size_t)li * len : (size_t)li);
+    const int pst = nat ? 1 : g.nlines;
     const int chunk = (len + nsub - 1) / nsub;
     const int q0 = p * chunk, q1 = min(len, q0 + chunk);
     if (q0 < q1) {
@@ -223,29 +246,42 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void k_dt_pass(const DtTask* __restrict__ tasks, const DtGroup* __restrict__ groups,
+__global__ __launch_bounds__(128, 4) void k_dt_pass(const DtTask* __restrict__ tasks, const DtGroup* __restrict__ groups,
                                                 const DtMap* __restrict__ maps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   DT_STAMP(0);
+  DT_TRACE(0);
   const DtTask t = tasks[blockIdx.x];
   const DtGroup g = groups[t.group];
   if (g.stride <= 256) dt_block<T, unsigned char>(smem, t, g, maps);    // stack indices < 255 fit a byte
   else dt_block<T, unsigned short>(smem, t, g, maps);
+  DT_TRACE(1);
 }
 
 template <typename T>
 static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,
-                             hipStream_t s) {
+                             int nt, hipStream_t s) {
   static LdsOptIn optin;   // one per instantiation, per-device state inside
   optin.ensure((const void*)k_dt_pass<T>, lds);
-  hipLaunchKernelGGL(k_dt_pass<T>, dim3(ntasks), dim3(64), lds, s, tasks, groups, maps);
+#ifdef PBD_PROBES
+  static const bool tracing = getenv("PBD_DT_TRACE") != nullptr;
+  if (tracing && g_dt_trace_seq == 0) {
+    int nb = -1; hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dt_pass<T>, nt, lds);
+    fprintf(stderr, "occupancy: k_dt_pass nt %d lds %zu -> %d blocks/CU (%s)\n", nt, lds, nb, hipGetErrorString(e));
+    hipFuncAttributes a; hipFuncGetAttributes(&a, (const void*)k_dt_pass<T>);
+    fprintf(stderr, "attrs: numRegs %d sharedSizeBytes %zu maxDynamicSharedSizeBytes %d maxThreadsPerBlock %d localSizeBytes %zu constSizeBytes %zu\n", a.numRegs, a.sharedSizeBytes, a.maxDynamicSharedSizeBytes, a.maxThreadsPerBlock, a.localSizeBytes, a.constSizeBytes);
+    for (int t2 : {64, 128}) for (size_t l2 : {(size_t)1024, (size_t)20480}) { int n2 = -1; hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (const void*)k_dt_pass<T>, t2, l2); fprintf(stderr, "  nt %d lds %zu -> %d\n", t2, l2, n2); }
+  }
+  if (tracing) { static int seqs[4096]; const int seq = g_dt_trace_seq++; seqs[seq & 4095] = seq; hipMemcpyToSymbolAsync(HIP_SYMBOL(pbd_dt_trace_launch), &seqs[seq & 4095], sizeof(int), 0, hipMemcpyHostToDevice, s); }
+#endif
+  hipLaunchKernelGGL(k_dt_pass<T>, dim3(ntasks), dim3(nt), lds, s, tasks, groups, maps);
 }
 // ts = sizeof(T): DistanceTransform<float> / DistanceTransform<double>
 void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, int ts,
-                    hipStream_t s) {
+                    int nt, hipStream_t s) {
   if (ntasks <= 0) return;
-  if (ts == 8) launch_dt_pass_t<double>(tasks, ntasks, groups, maps, lds, s);
-  else launch_dt_pass_t<float>(tasks, ntasks, groups, maps, lds, s);
+  if (ts == 8) launch_dt_pass_t<double>(tasks, ntasks, groups, maps, lds, nt, s);
+  else launch_dt_pass_t<float>(tasks, ntasks, groups, maps, lds, nt, s);
 }
 
 // ---------------------------------------------------------------------------

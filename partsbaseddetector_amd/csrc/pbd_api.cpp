@@ -329,22 +329,25 @@ static void free_frame(pbd_handle* h) {
 // nmb = maps a block of lpb consecutive lines can touch.
 static int dt_stride_for(int len) { return (len + 1) | 1; }
 static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (lpb + nlines - 2) / nlines + 1); }
-static int dt_lpb_for(int stride, int nlines, int nmaps, size_t budget, int ts) {
+static int dt_lpb_for(int stride, int len, int nlines, int nmaps, size_t budget, int ts, int nt, int seg) {
   int lpb = 64;
-  while (lpb > 4 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts) > budget) --lpb;
-  // the 64 / lpb lanes that share a line scan one segment of it each (dt_core.hpp).  Probe knob: round the lane
-  // count UP (P = ceil(64 / lpb) segments, lpb = 64 / P: a few lines fewer per block, a shorter scan) — measured
-  // slower than filling the budget with lines (dp_min 0.877 vs 0.851 ms at 20 KB)
-  static const int snap = PBD_PROBE_ENV("PBD_DT_SNAP") ? atoi(PBD_PROBE_ENV("PBD_DT_SNAP")) : 0;   // probe-build knob
-  if (snap && lpb < 64) lpb = 64 / ((64 + lpb - 1) / lpb);
+  while (lpb > 4 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts, nt) > budget) --lpb;
+  // The nt / lpb lanes that share a line scan one segment of it each (dt_core.hpp), and a block lasts as long as
+  // its segments are: with a target segment length, lines are given up for lanes per line where the budget
+  // would put so many lines into a block that each is left with one or two lanes.
+  if (seg > 0) {
+    const int P = std::max(1, std::min(nt / 4, (len + seg - 1) / seg));
+    lpb = std::max(4, std::min(lpb, nt / P));
+  }
   return lpb;
 }
-static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts) {
+static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts, int nt, int seg) {
   DtGroup g{};
   g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len;
   g.stride = dt_stride_for(len);
-  g.lpb = dt_lpb_for(g.stride, nlines, nmaps, budget, ts);
+  g.lpb = dt_lpb_for(g.stride, len, nlines, nmaps, budget, ts, nt, seg);
   g.nmb = dt_nmb_for(g.lpb, nlines, nmaps);
+  if (PBD_PROBE_ENV("PBD_DEBUG_NOVALIDATE")) g.pad = 1;   // timing probe: speculative stitches taken as they are (results may be wrong)
   return g;
 }
 
@@ -423,14 +426,17 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   if ((rc = dev_alloc(h, &h->d_dt_ixT, h->dt_cap_elems))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_iy, h->dt_cap_elems))) return rc;
 
-  // DT LDS budget: ~36 KB per block (4 blocks per CU) unless the longest line needs more at 8 lines/block
+  // DT LDS budget per block unless the longest line needs more at 4 lines/block
   int maxlen = 1;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
-  size_t dt_base = 20 * 1024;   // 8 one-wave blocks per CU: measured optimum on MI355X (12..32 KB swept)
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = atoi(e) == 64 ? 64 : 128;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_SEG")) h->dt_seg = atoi(e);
+  size_t dt_base = 25 * 1024;   // 6 two-wave blocks per CU (3 wavefronts per SIMD): measured optimum on MI355X (20..40 KB swept)
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
-  size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 4, 2, h->ts));
+  size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 4, 2, h->ts, h->dt_nt));
   if (dt_budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
   h->dt_lds = dt_budget;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_LDS_REQUEST_KB")) h->dt_lds = std::max(h->dt_lds, (size_t)atoi(e) * 1024);   // occupancy probe
   std::vector<DtMap> maps;
   std::vector<DtGroup> groups;
   std::vector<DtTask> tasks;
@@ -455,7 +461,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     for (int l = 0; l < n; ++l) {
       const Level& L = h->lv[l];
       if (L.active && L.cw > 0 && L.ch > 0) {
-        const DtGroup gx = dt_group(0, (int)maxK, L.ch, L.cw, dt_budget, h->ts);
+        const DtGroup gx = dt_group(0, (int)maxK, L.ch, L.cw, dt_budget, h->ts, h->dt_nt, h->dt_seg);
         const size_t b = ((size_t)maxK * L.ch + gx.lpb - 1) / gx.lpb;
         if (blocks + b > 800 && blocks > 0 && gcur < h->ngroups - 1) { gcur++; blocks = 0; }
         blocks += b;
@@ -492,8 +498,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
           gx_nmaps++;
         }
       }
-      const DtGroup gx = dt_group(gx_map0, gx_nmaps, L.ch, L.cw, dt_budget, h->ts);
-      const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, dt_budget, h->ts);
+      const DtGroup gx = dt_group(gx_map0, gx_nmaps, L.ch, L.cw, dt_budget, h->ts, h->dt_nt, h->dt_seg);
+      const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, dt_budget, h->ts, h->dt_nt, h->dt_seg);
       for (auto& my : ymaps) maps.push_back(my);
       const int gxi = (int)groups.size();
       groups.push_back(gx);
@@ -502,6 +508,10 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       auto add_tasks = [&](const DtGroup& g, int gidx, std::vector<DtTask>& lane_t) {
         for (int g0 = 0; g0 < g.nmaps * g.nlines; g0 += g.lpb) lane_t.push_back(DtTask{gidx, g0});
       };
+      if (PBD_PROBE_ENV("PBD_DEBUG_PLAN") && r == 0)
+        fprintf(stderr, "plan: level %d  x: len %d lines %d maps %d lpb %d P %d tasks %zu..  y: len %d lines %d lpb %d P %d tasks %zu..\n", l,
+                gx.len, gx.nlines, gx.nmaps, gx.lpb, std::max(1, std::min(h->dt_nt / gx.lpb, gx.len / 8)), xt.size(),
+                gy.len, gy.nlines, gy.lpb, std::max(1, std::min(h->dt_nt / gy.lpb, gy.len / 8)), yt.size());
       add_tasks(gx, gxi, xt);
       add_tasks(gy, gyi, yt);
     }
@@ -510,6 +520,27 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       const std::vector<DtTask> x0 = xt, y0 = yt;
       for (int i = 1; i < ndup; ++i) { xt.insert(xt.end(), x0.begin(), x0.end()); yt.insert(yt.end(), y0.begin(), y0.end()); }
     }
+    // Workgroup b runs on XCD b % 8, each with its own L2.  A block writes its lpb lines transposed, i.e. runs of
+    // 4 * lpb bytes — a fraction of a 128-byte line; the neighbouring runs belong to the next tasks of the same
+    // map.  Order the table so that `xcd_chunk` consecutive tasks share an XCD and the partial lines merge in
+    // one L2 instead of going out to HBM from several.
+    {
+      int c = h->xcd_chunk;
+      if (const char* e = PBD_PROBE_ENV("PBD_DT_XCD_CHUNK")) c = atoi(e);
+      auto xcd_order = [c](std::vector<DtTask>& v) {
+        if (c <= 0) return;
+        const size_t win = (size_t)8 * c, full = v.size() / win * win;
+        std::vector<DtTask> o(v);
+        for (size_t b = 0; b < full; ++b) {
+          const size_t xcd = b & 7, idx = b >> 3;
+          o[b] = v[((idx / c) * 8 + xcd) * c + idx % c];
+        }
+        v.swap(o);
+      };
+      xcd_order(xt);
+      xcd_order(yt);
+    }
+    if (PBD_PROBE_ENV("PBD_DEBUG_PLAN")) fprintf(stderr, "plan: round %zu group %d: %zu x blocks, %zu y blocks\n", r, grp, xt.size(), yt.size());
     R.xtask0 = (int)tasks.size(); R.nxtasks = (int)xt.size();
     tasks.insert(tasks.end(), xt.begin(), xt.end());
     R.ytask0 = (int)tasks.size(); R.nytasks = (int)yt.size();
@@ -666,8 +697,8 @@ static int run_dp_min(pbd_handle* h) {
   if (h->ngroups > 1) hipEventRecord(h->ev_fork, h->stream);
   if (h->ngroups == 1) {  // default: one chain of rounds on the handle's stream
     for (auto& R : h->grl[0]) {
-      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->stream);
-      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->stream);
+      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, h->stream);
+      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, h->stream);
       for (auto& Wv : R.waves)
         launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
     }
@@ -676,8 +707,8 @@ static int run_dp_min(pbd_handle* h) {
     hipStream_t s = h->gstream[g];
     hipStreamWaitEvent(s, h->ev_fork, 0);
     for (auto& R : h->grl[g]) {
-      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, s);
-      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, s);
+      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, s);
+      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, s);
       for (auto& Wv : R.waves)
         launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, s);
     }
@@ -1190,11 +1221,12 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMalloc(&d_ixT, HW * 2)); HIPCHK(h, hipMalloc(&d_iy, HW * 2));
   HIPCHK(h, hipMemcpyAsync(d_in, in, HW * ts, hipMemcpyHostToDevice, h->stream));
   DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = atoi(e) == 64 ? 64 : 128;
   size_t dt_base = 40 * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
-  const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 4, 1, tsz));
+  const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 4, 1, tsz, h->dt_nt));
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
-  DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz), dt_group(1, 1, cols, rows, budget, tsz)};
+  DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz, h->dt_nt, h->dt_seg), dt_group(1, 1, cols, rows, budget, tsz, h->dt_nt, h->dt_seg)};
   std::vector<DtTask> tasks;
   for (int g0 = 0; g0 < rows; g0 += groups[0].lpb) tasks.push_back(DtTask{0, g0});
   const int nx = (int)tasks.size();
@@ -1206,9 +1238,9 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMemcpyAsync(d_groups, groups, sizeof(groups), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
-  launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, tsz, h->stream);
+  launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, tsz, h->dt_nt, h->stream);
   if (PBD_PROBE_ENV("PBD_DEBUG_SKIP_Y")) { hipMemsetAsync(d_sdt, 0, HW * ts, h->stream); hipMemsetAsync(d_iy, 0, HW * 2, h->stream); }   // probe build: leave the x pass as the last DT launch (its stamps are then readable)
-  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, tsz, h->stream);
+  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, tsz, h->dt_nt, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_sdt, HW * ts, hipMemcpyDeviceToHost, h->stream));   // the y pass's scores, untouched
   HIPCHK(h, hipMemcpyAsync(hx.data(), d_ixT, HW * 2, hipMemcpyDeviceToHost, h->stream));   // the passes' own pointers
@@ -1414,6 +1446,9 @@ int pbd_get_work(const pbd_handle* h, double work[6]) {
 #define PROBE_RC PBD_OK
 #else
 #define PROBE_RC PBD_ERR_UNSUPPORTED   /* stamps exist only in libpbd_hip_probes.so (make probes) */
+#endif
+#ifdef PBD_PROBES
+extern "C" int pbd_debug_dt_trace(unsigned long long* t, unsigned* hw, int* nlaunch) { return dt_debug_trace(t, hw, nlaunch); }
 #endif
 int pbd_debug_dt_stamps(unsigned long long* out) { if (!out) return PBD_ERR_ARG; dt_debug_read(out); return PROBE_RC; }
 int pbd_debug_hog_stamps(unsigned long long* out) { if (!out) return PBD_ERR_ARG; hog_debug_read(out); return PROBE_RC; }

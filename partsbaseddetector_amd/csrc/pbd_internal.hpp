@@ -63,6 +63,9 @@ struct DtMap {       // one 1-D pass over one score map
 };
 struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, nmb, pad; };  // stride: LDS elements per line (even); lpb: lines per block; nmb: max maps a block touches
 struct DtTask { int group, g0; };
+#ifndef PBD_DT_NT_DEFAULT
+#define PBD_DT_NT_DEFAULT 128   // lanes of a k_dt_pass block
+#endif
 
 #define PBD_MAX_CH 8   // children of one parent folded into one reduce job
 struct ReduceChild {     // one child part's distance-transformed mixtures
@@ -165,6 +168,9 @@ struct pbd_handle {
   int level_group[PBD_MAX_LEVELS] = {};
   int ngroups = 1;   // pbd_options.reserved[0]: 1 (default) .. PBD_NGROUPS; measured slower than one chain on MI355X
   size_t dt_lds = 0;                                 // dynamic LDS of every k_dt_pass launch
+  int dt_nt = PBD_DT_NT_DEFAULT;                                   // lanes of a k_dt_pass block (64 or 128)
+  int dt_seg = 0;                                    // target segment length of the DT scans (0: as many lines per block as fit)
+  int xcd_chunk = 16;                                // consecutive k_dt_pass tasks kept on one XCD (0: table order)
   std::vector<RoundLaunch> rl;
   int n_rootjobs = 0; unsigned root_cells = 0;
   // candidates
@@ -221,7 +227,7 @@ struct LdsOptIn {
 // Per-phase wall-clock stamps and the environment tuning knobs are compiled only into the probe build
 // (make probes -> libpbd_hip_probes.so, -DPBD_PROBES), which tests/tools_*.py load; the product library carries
 // neither (the pbd_debug_* entry points then return PBD_ERR_UNSUPPORTED).
-#ifdef PBD_PROBES
+#if defined(PBD_PROBES) || defined(PBD_TUNE)
 #define PBD_PROBE_ENV(name) getenv(name)
 #else
 #define PBD_PROBE_ENV(name) ((const char*)nullptr)
@@ -251,8 +257,8 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                             const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s);
 void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, int ts,
-                    hipStream_t s);
-size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts);
+                    int nt, hipStream_t s);
+size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts, int nt);
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
                    int ts, hipStream_t s);
 void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
@@ -263,6 +269,7 @@ void launch_backtrack(const int* count, const CandRec* rec, int capacity, const 
                       const unsigned long long* scr_base, const int16_t* ix, const int16_t* iy, int correct_ptr,
                       hipStream_t s);
 void dt_debug_read(unsigned long long* out);
+int dt_debug_trace(unsigned long long* t, unsigned* hw, int* nlaunch);   // probe build only
 void hog_debug_read(unsigned long long* out);
 void conv_debug_read(unsigned long long* out);
 void launch_nms_map(const float* src, int rows, int cols, int sz, uint8_t* dst, hipStream_t s);
