@@ -34,9 +34,9 @@
 //    Events need no search: while F is the top of the local stack the next element is the next event; once an
 //    element c sits on F, the next element to reach F is the one that pops c locally — c's popper link.
 //    Events are rare (a new "record" element of the segment) and each costs a few intersections.
-// 3. dt_seg_table: which segments still own entries of the final stack, where the chain enters them, and the z
-//    of their lowest entry — so that a read-out lane finds the entry covering its last output with a table
-//    look-up and a short walk.
+// 3. Per segment, the element its lowest remaining entry sits on and that entry's z (written by the segment's own
+//    lane): enough for a read-out lane to tell which segments still own entries of the final stack and where the
+//    chain enters them, i.e. to find the entry covering its last output with a short walk (dt_cover).
 // 4. The read-out (:172-178) runs over q in DESCENDING order, sub-ranges in lockstep (coalesced stores), stepping
 //    down the chain through the "below" links: k(q) = max{k : z[k] < os + q}, the same entry the reference's
 //    ascending `while (z[k+1] < os) k++` reaches because z is strictly increasing along the stack.
@@ -244,35 +244,26 @@ DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, co
   return bad;
 }
 
-// After the stitch: which segments still own entries of the final stack, where the chain enters them (ENT[p]:
-// topmost surviving element of segment p, or `dead`) and the z of their lowest entry (ZLO[p] = z of F[p]).  One
-// lane per line, top segment first.
+// After the stitches every segment p has F[p], its lowest element left on the stack when the run finished the
+// segment, patched to its global z and link: ZLO[p] = z of F[p], BELOW[p] = the element F[p] sits on (one lane
+// per segment writes them, no order).  Later segments may have popped all of segment p; what is then still true:
+//   - segment p owns entries of the FINAL stack iff no later segment sits below its start:
+//     m_p = min(len - 1, BELOW[p'] : p' > p) >= seg[p]     (pops are permanent and only ever reach further left);
+//   - m_p is then the topmost of those entries (the element the next surviving segment above sits on).
+// Read-out lane: the stack entry covering output position `osq` (= os + q, compared like `z[k+1] < os`, :174) is
+// the topmost entry whose z is < (T)osq: walk the segments top-down carrying m, stop at the first surviving segment
+// whose lowest entry qualifies (segment 0 always does: the bottom entry has z = -inf), then step down inside it.
 template <typename T, typename IT>
-DT_HD void dt_seg_table(const DtPair<T>* __restrict__ YZ, const IT* __restrict__ B, const int* __restrict__ seg, int P,
-                        const IT* __restrict__ F, IT* __restrict__ ENT, T* __restrict__ ZLO, int tstride, IT dead) {
-  int e = seg[P] - 1;                        // the last element of the line is the top of the stack
-  for (int p = P - 1; p >= 0; --p) {
-    if (e >= seg[p]) {
-      const int f = (int)F[p * tstride];
-      ENT[p * tstride] = (IT)e;
-      ZLO[p * tstride] = YZ[f].y;
-      e = (int)B[f];
-    } else {
-      ENT[p * tstride] = dead;
-    }
-  }
-}
-
-// Read-out lane: the stack entry covering output position `osq` (= os + q, compared like `z[k+1] < os`, :174):
-// the topmost entry whose z is < (T)osq.  It lies in the highest surviving segment whose lowest entry qualifies.
-template <typename T, typename IT>
-DT_HD int dt_cover(const DtPair<T>* __restrict__ YZ, const IT* __restrict__ B, int P, const IT* __restrict__ ENT,
-                   const T* __restrict__ ZLO, int tstride, IT dead, int osq) {
+DT_HD int dt_cover(const DtPair<T>* __restrict__ YZ, const IT* __restrict__ B, const int* __restrict__ seg, int P,
+                   const IT* __restrict__ BELOW, const T* __restrict__ ZLO, int tstride, int osq) {
   const T fos = (T)osq;
-  int ps = 0;                                // segment 0 always qualifies: z of the bottom entry is -inf
-  for (int p = 1; p < P; ++p)
-    if (ENT[p * tstride] != dead && ZLO[p * tstride] < fos) ps = p;
-  int e = (int)ENT[ps * tstride];
+  int m = seg[P] - 1;                        // the last element of the line is the top of the stack
+  for (int p = P - 1; p > 0; --p) {
+    if (m >= seg[p] && ZLO[p * tstride] < fos) break;
+    const int bl = (int)BELOW[p * tstride];
+    m = bl < m ? bl : m;
+  }
+  int e = m;
   while (!(YZ[e].y < fos)) e = (int)B[e];
   return e;
 }

@@ -69,7 +69,7 @@ void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i]
 // 9 bytes per line element for float: the lines resident on a CU are bounded by these bytes.
 #define DT_SEGS 40                                   // SEG entries: P + 1 <= 33 starts, then {0, len} for a line redone as one segment
 __host__ __device__ inline size_t dt_hdr_bytes(int nt, int ts, int its) {
-  return ((size_t)64 * 8 + 64 * 4 + DT_SEGS * 4 + (size_t)nt * (2 * ts + 4 * its) + 15) & ~(size_t)15;
+  return ((size_t)64 * 8 + 64 * 4 + 64 * 4 + DT_SEGS * 4 + (size_t)nt * (2 * ts + 4 * its) + 15) & ~(size_t)15;
 }
 size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts, int nt) {   // ts = sizeof(T): (y, z) is a float or a double pair
   const int its = stride <= 256 ? 1 : 2;
@@ -88,16 +88,16 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   typedef DtPair<T> P2;
   constexpr bool EX = sizeof(T) == 8;          // DistanceTransform<double>: s is not narrowed, every intersection takes the IEEE division
   const T** lptr = (const T**)smem;            // [64] source pointer of each line of this block
-  int* FLAG = (int*)(smem + 64 * 8);           // [64] per line: redo sequentially (suspect quotient / lost stitch invariant); then: segments in use
-  int* SEG = FLAG + 64;                        // [P + 1 <= 33] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
+  int* FLAG = (int*)(smem + 64 * 8);           // [64] per line: redo sequentially (suspect quotient / lost stitch invariant)
+  int* FIX = FLAG + 64;                        // [64] per line: a speculative stitch has to be redone
+  int* SEG = FIX + 64;                        // [P + 1 <= 33] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
   T* ZLO = (T*)(SEG + DT_SEGS);                // [NT] per lane (p * lpb + line): z of the segment's lowest surviving element
   T* ZSAVE = ZLO + NT;                         // [NT] per lane: that element's local z (before the stitch patched it)
   IT* FT = (IT*)(ZSAVE + NT);                  // [NT] per lane: that element
-  IT* ENT = FT + NT;                           // [NT] topmost surviving element of the segment (or dead)
-  IT* DMIN = ENT + NT;                         // [NT] lowest element the segment's speculative stitch tested
+  IT* BELOW = FT + NT;                         // [NT] the element FT sits on
+  IT* DMIN = BELOW + NT;                         // [NT] lowest element the segment's speculative stitch tested
   IT* BSAVE = DMIN + NT;                       // [NT] local link of FT (before the patch)
   double* R = (double*)(smem + dt_hdr_bytes(NT, sizeof(T), sizeof(IT)));   // [nmb][S] 1/(2a*dx) per map of this block
-  const IT dead = (IT)~(IT)0;
   const int total = g.nmaps * g.nlines;
   const int nl = min(lpb, total - t.g0);
   const int m_first = t.g0 / g.nlines, m_last = (t.g0 + nl - 1) / g.nlines;
@@ -110,14 +110,12 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const DtMap& mp0 = maps[g.map0 + mi];
     lptr[lane] = (const T*)mp0.src + (size_t)li * len;
     FLAG[lane] = 0;
+    FIX[lane] = 0;
   }
-  // reciprocal tables: one IEEE division per (map, dx), spread over the 64 lanes
-  if constexpr (!EX) {
-    for (int ms = 0; ms < nmb; ++ms) {
-      const double a = maps[g.map0 + m_first + ms].a;
-      for (int dx = lane; dx < len; dx += NT) R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
-    }
-  }
+  const int nsub = NT / lpb;                     // lanes per line
+  const int P = dt_segments(nsub, len);          // segments per line
+  if (lane <= P) SEG[lane] = dt_seg_start(lane, P, len);
+  if (lane == 0) { SEG[DT_SEGS - 2] = 0; SEG[DT_SEGS - 1] = len; }
   __syncthreads();
   DT_STAMP(1);
   // coalesced load of the nl lines.  Batches of LB independent loads are issued before the first
@@ -140,6 +138,15 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         const int q = min((c - i * CH) * 64 + l64, len - 1);
         r[j] = lptr[i][q];
       }
+      // reciprocal tables: one IEEE division per (map, dx), spread over the lanes — while the loads are in flight
+      if constexpr (!EX) {
+        if (c0 == 0) {
+          for (int ms = 0; ms < nmb; ++ms) {
+            const double a = maps[g.map0 + m_first + ms].a;
+            for (int dx = lane; dx < len; dx += NT) R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
         const int c = (c0 + j) * W + wv, cc = min(c, nch - 1);
@@ -152,12 +159,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   __syncthreads();
   DT_STAMP(2);
 
-  const int nsub = NT / lpb;                     // lanes per line
-  const int P = dt_segments(nsub, len);          // segments per line
   const int line = lane % lpb, p = lane / lpb;
-  if (lane <= P) SEG[lane] = dt_seg_start(lane, P, len);
-  if (lane == 0) { SEG[DT_SEGS - 2] = 0; SEG[DT_SEGS - 1] = len; }
-  __syncthreads();
   const bool mine = line < nl && p < nsub;
   DtMap mp;
   const double* Rl = R;
@@ -184,20 +186,36 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     if (bad) FLAG[line] = 1;
   }
   __syncthreads();
+  // ---- validate the speculation: a stitch is final iff everything it tested below its segment lies strictly
+  // above the lowest element its left neighbour's stitch left (dt_core.hpp); every lane checks its own, and
+  // publishes what the read-out needs to know about its segment ----
+  if (mine && p < P && !FLAG[line]) {
+    const int f = p ? (int)FT[lane] : 0;
+    if (p >= 2 && (int)DMIN[lane] <= (int)FT[lane - lpb]) FIX[line] = 1;
+    if (!p) FT[lane] = (IT)0;
+    BELOW[lane] = Bl[f];
+    ZLO[lane] = YZl[f].y;
+  }
+  __syncthreads();
   DT_STAMP(6);
-  // ---- validate the speculation (redo the few stitches that reached below their neighbour's survivors), tables ----
-  if (mine && p == 0) {
+  // the few lines with a stitch to redo (in order, everything to the left final), a suspect quotient or a lost
+  // invariant (the whole line sequentially, IEEE divisions): one lane per line
+  if (mine && p == 0 && (FLAG[line] | FIX[line])) {
     bool redo = FLAG[line] != 0;
-    if (!redo && P > 2 && !DT_NOVALIDATE(g)) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, Rl, SEG, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
-    int Pl = P;
-    if (redo) DT_COUNT_REDO();
-    if (redo) {   // a quotient next to a float rounding boundary, or near-degenerate geometry: the whole line sequentially, IEEE divisions
+    if (!redo) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, Rl, SEG, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
+    if (redo) {
+      DT_COUNT_REDO();
       dt_seg_scan<true, T, IT>(YZl, Bl, Rl, 0, len, mp.a, mp.b);
-      Pl = 1;
+      FLAG[line] = 1;                            // the read-out takes the line as one segment
+      BELOW[line] = Bl[0];
+      ZLO[line] = YZl[0].y;
+    } else {
+      for (int pp = 1; pp < P; ++pp) {
+        const int f = (int)FT[pp * lpb + line];
+        BELOW[pp * lpb + line] = Bl[f];
+        ZLO[pp * lpb + line] = YZl[f].y;
+      }
     }
-    FT[line] = (IT)0;
-    dt_seg_table<T, IT>(YZl, Bl, Pl == 1 ? SEG + DT_SEGS - 2 : SEG, Pl, FT + line, ENT + line, ZLO + line, lpb, dead);
-    FLAG[line] = Pl;                             // segments the read-out lanes look at
   }
   __syncthreads();
   DT_STAMP(4);
@@ -220,7 +238,8 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const int q0 = p * chunk, q1 = min(len, q0 + chunk);
     if (q0 < q1) {
       int os = mp.os + q1 - 1;
-      int e = dt_cover<T, IT>(YZl, Bl, FLAG[line], ENT + line, ZLO + line, lpb, dead, os);
+      const bool whole = FLAG[line] != 0;
+      int e = dt_cover<T, IT>(YZl, Bl, whole ? SEG + DT_SEGS - 2 : SEG, whole ? 1 : P, BELOW + line, ZLO + line, lpb, os);
       P2 eyz = YZl[e];
       // the piece below the current one is kept in registers, so stepping to it costs no LDS round trip on the
       // spot: the read of the piece below THAT overlaps this output's arithmetic.  The bottom of the stack
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(128, 4) void k_dt_pass(const DtTask* __restrict__ t
   DT_STAMP(0);
   DT_TRACE(0);
   const DtTask t = tasks[blockIdx.x];
-  const DtGroup g = groups[t.group];
+  const DtGroup& g = t.g;
   if (g.stride <= 256) dt_block<T, unsigned char>(smem, t, g, maps);    // stack indices < 255 fit a byte
   else dt_block<T, unsigned short>(smem, t, g, maps);
   DT_TRACE(1);

@@ -433,6 +433,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   if (const char* e = PBD_PROBE_ENV("PBD_DT_SEG")) h->dt_seg = atoi(e);
   size_t dt_base = 25 * 1024;   // 6 two-wave blocks per CU (3 wavefronts per SIMD): measured optimum on MI355X (20..40 KB swept)
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_B")) dt_base = (size_t)atoi(e);
   size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 4, 2, h->ts, h->dt_nt));
   if (dt_budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
   h->dt_lds = dt_budget;
@@ -506,7 +507,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       const int gyi = (int)groups.size();
       groups.push_back(gy);
       auto add_tasks = [&](const DtGroup& g, int gidx, std::vector<DtTask>& lane_t) {
-        for (int g0 = 0; g0 < g.nmaps * g.nlines; g0 += g.lpb) lane_t.push_back(DtTask{gidx, g0});
+        for (int g0 = 0; g0 < g.nmaps * g.nlines; g0 += g.lpb) lane_t.push_back(DtTask{gidx, g0, g});
       };
       if (PBD_PROBE_ENV("PBD_DEBUG_PLAN") && r == 0)
         fprintf(stderr, "plan: level %d  x: len %d lines %d maps %d lpb %d P %d tasks %zu..  y: len %d lines %d lpb %d P %d tasks %zu..\n", l,
@@ -1228,9 +1229,9 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
   DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz, h->dt_nt, h->dt_seg), dt_group(1, 1, cols, rows, budget, tsz, h->dt_nt, h->dt_seg)};
   std::vector<DtTask> tasks;
-  for (int g0 = 0; g0 < rows; g0 += groups[0].lpb) tasks.push_back(DtTask{0, g0});
+  for (int g0 = 0; g0 < rows; g0 += groups[0].lpb) tasks.push_back(DtTask{0, g0, groups[0]});
   const int nx = (int)tasks.size();
-  for (int g0 = 0; g0 < cols; g0 += groups[1].lpb) tasks.push_back(DtTask{1, g0});
+  for (int g0 = 0; g0 < cols; g0 += groups[1].lpb) tasks.push_back(DtTask{1, g0, groups[1]});
   DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks;
   HIPCHK(h, hipMalloc(&d_maps, sizeof(maps))); HIPCHK(h, hipMalloc(&d_groups, sizeof(groups)));
   HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size()));

@@ -62,7 +62,7 @@ struct DtMap {       // one 1-D pass over one score map
   int os, ptr_natural;  // ptr_natural: write ptr row-major [line][q] instead of transposed
 };
 struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, nmb, pad; };  // stride: LDS elements per line (even); lpb: lines per block; nmb: max maps a block touches
-struct DtTask { int group, g0; };
+struct DtTask { int group, g0; DtGroup g; };   // the block's group travels with the task: one dependent global load less at block start
 #ifndef PBD_DT_NT_DEFAULT
 #define PBD_DT_NT_DEFAULT 128   // lanes of a k_dt_pass block
 #endif

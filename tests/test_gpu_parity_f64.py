@@ -69,7 +69,7 @@ def test_pyramid_f64_levels_bit_exact(h64, orc):
 @pytest.mark.parametrize("nparts,K,seed", [(3, 3, 11), (5, 4, 12)])
 def test_pdf_f64_bit_exact(gpu_required, orc, nparts, K, seed):
     m = make_tree_model([-1] + [0] * (nparts - 1), K, seed=seed)
-    h = capi.Handle(m, dtype=F64)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dtype=F64)
     h.pyramid(make_image(seed, 120, 90))
     g = h._geo
     h.pdf()
@@ -117,7 +117,7 @@ def test_dt2d_f64_ties_and_plateaus(h64, orc):
 
 # ---------------------------------------------------------------- DynamicProgram<double>::min
 def _dp_case64(orc, model, w, h, seed):
-    hd = capi.Handle(model, dtype=F64)
+    hd = capi.Handle(model, conv_mode=capi.PBD_CONV_EXACT, dtype=F64)
     hd.begin_frame(w, h, 3)
     g = hd._geo
     rng = np.random.default_rng(seed)

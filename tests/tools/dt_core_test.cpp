@@ -23,10 +23,9 @@ template <typename T, typename IT>
 static void run_line(const T* src, int len, int lanes, double a, double b, int os, T* dst, int32_t* ptr, Stats& st, int order_mode) {
   const int S = (len + 2) & ~1;
   std::vector<DtPair<T>> YZ(S);
-  std::vector<IT> B(S), F(lanes), ENT(lanes);
+  std::vector<IT> B(S), F(lanes), BELOW(lanes);
   std::vector<T> ZLO(lanes);
   std::vector<double> R(S);
-  const IT dead = (IT)~(IT)0;
   constexpr bool EX = sizeof(T) == 8;
   for (int i = 0; i < len; ++i) YZ[i].x = src[i];
   if (!EX) for (int dx = 0; dx < len; ++dx) R[dx] = 1.0 / ((2 * a) * (double)dx);
@@ -53,8 +52,12 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
       bad |= dt_stitch1<EX, T, IT>(YZ.data(), B.data(), R.data(), seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
       F[p] = (IT)f; DM[p] = (IT)dmin; ZS[p] = zs; BS[p] = (IT)bs;
     }
-    for (int p = 2; p < P; ++p) if ((int)DM[p] <= (int)F[p - 1]) { st.events++; break; }
-    bad |= dt_stitch_validate<EX, T, IT>(YZ.data(), B.data(), R.data(), seg.data(), P, a, b, F.data(), DM.data(), ZS.data(), BS.data(), 1);
+    bool fix = false;                // every lane checks its own stitch (k_dt_pass); only then the sequential fix-up
+    for (int p = 2; p < P; ++p) if ((int)DM[p] <= (int)F[p - 1]) fix = true;
+    if (fix) {
+      st.events++;
+      bad |= dt_stitch_validate<EX, T, IT>(YZ.data(), B.data(), R.data(), seg.data(), P, a, b, F.data(), DM.data(), ZS.data(), BS.data(), 1);
+    }
     if (bad) st.inconsistent++;
     flag |= bad;
   }
@@ -64,13 +67,13 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
     dt_seg_scan<true, T, IT>(YZ.data(), B.data(), R.data(), 0, len, a, b);
   }
   F[0] = 0;
-  dt_seg_table<T, IT>(YZ.data(), B.data(), seg.data(), P, F.data(), ENT.data(), ZLO.data(), 1, dead);
+  for (int p = 0; p < P; ++p) { BELOW[p] = B[F[p]]; ZLO[p] = YZ[F[p]].y; }   // one lane per segment in the kernel
   const int nsub = lanes, chunk = (len + nsub - 1) / nsub;
   for (int sub = 0; sub < nsub; ++sub) {        // read-out (:172-178), as in the kernel: descending q
     const int q0 = sub * chunk, q1 = std::min(len, q0 + chunk);
     if (q0 >= q1) continue;
     int osq = os + q1 - 1;
-    int e = dt_cover<T, IT>(YZ.data(), B.data(), P, ENT.data(), ZLO.data(), 1, dead, osq);
+    int e = dt_cover<T, IT>(YZ.data(), B.data(), seg.data(), P, BELOW.data(), ZLO.data(), 1, osq);
     for (int q = q1 - 1; q >= q0; --q, --osq) {
       const T fos = (T)osq;
       while (!(YZ[e].y < fos)) e = (int)B[e];
