@@ -67,7 +67,7 @@ void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i]
 // LDS per block: a header (per-line and per-lane descriptors, segment table), per map touched by the block a table
 // of exact reciprocals 1/(2a*dx), dx < len (double[S]), and per line {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
 // 9 bytes per line element for float: the lines resident on a CU are bounded by these bytes.
-#define DT_SEGS 40                                   // SEG entries: P + 1 <= 33 starts, then {0, len} for a line redone as one segment
+#define DT_SEGS 72                                   // SEG entries: P + 1 <= 65 starts, then {0, len} for a line redone as one segment
 __host__ __device__ inline size_t dt_hdr_bytes(int nt, int ts, int its) {
   return ((size_t)64 * 8 + 64 * 4 + 64 * 4 + DT_SEGS * 4 + (size_t)nt * (2 * ts + 4 * its) + 15) & ~(size_t)15;
 }
@@ -90,7 +90,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   const T** lptr = (const T**)smem;            // [64] source pointer of each line of this block
   int* FLAG = (int*)(smem + 64 * 8);           // [64] per line: redo sequentially (suspect quotient / lost stitch invariant)
   int* FIX = FLAG + 64;                        // [64] per line: a speculative stitch has to be redone
-  int* SEG = FIX + 64;                        // [P + 1 <= 33] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
+  int* SEG = FIX + 64;                        // [P + 1 <= 65] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
   T* ZLO = (T*)(SEG + DT_SEGS);                // [NT] per lane (p * lpb + line): z of the segment's lowest surviving element
   T* ZSAVE = ZLO + NT;                         // [NT] per lane: that element's local z (before the stitch patched it)
   IT* FT = (IT*)(ZSAVE + NT);                  // [NT] per lane: that element
@@ -265,7 +265,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 }
 
 template <typename T>
-__global__ __launch_bounds__(128, 4) void k_dt_pass(const DtTask* __restrict__ tasks, const DtGroup* __restrict__ groups,
+__global__ __launch_bounds__(256, 4) void k_dt_pass(const DtTask* __restrict__ tasks, const DtGroup* __restrict__ groups,
                                                 const DtMap* __restrict__ maps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   DT_STAMP(0);

@@ -429,7 +429,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   // DT LDS budget per block unless the longest line needs more at 4 lines/block
   int maxlen = 1;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
-  if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = atoi(e) == 64 ? 64 : 128;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
   if (const char* e = PBD_PROBE_ENV("PBD_DT_SEG")) h->dt_seg = atoi(e);
   size_t dt_base = 25 * 1024;   // 6 two-wave blocks per CU (3 wavefronts per SIMD): measured optimum on MI355X (20..40 KB swept)
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
@@ -1222,7 +1222,7 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMalloc(&d_ixT, HW * 2)); HIPCHK(h, hipMalloc(&d_iy, HW * 2));
   HIPCHK(h, hipMemcpyAsync(d_in, in, HW * ts, hipMemcpyHostToDevice, h->stream));
   DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
-  if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = atoi(e) == 64 ? 64 : 128;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
   size_t dt_base = 40 * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
   const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 4, 1, tsz, h->dt_nt));

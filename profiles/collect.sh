@@ -29,8 +29,10 @@ for c in SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/sq_$c" -o run -- $B --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline > "$OUT/sq_$c.log" 2>&1
 done
 # configs[4]: direct VALU correlation vs MFMA implicit GEMM for N = 26 .. 312 filters (stage times + per-kernel view)
+if [ -z "${SKIP_CONV_MODES:-}" ]; then   # unchanged filter bank: SKIP_CONV_MODES=1 keeps the previous collection's table
 python $REPO/profiles/conv_modes.py > "$OUT/conv_modes.json" 2> "$OUT/conv_modes.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_conv_modes" -o run -- python $REPO/profiles/conv_modes.py > /dev/null 2>&1
+fi
 # gpurun merges at most 64 MiB back: the per-dispatch traces are not needed by summarize.py (stats + counter CSVs are)
 find "$OUT" -name "*kernel_trace.csv" -delete
 find "$OUT" -name "*agent_info.csv" -delete
