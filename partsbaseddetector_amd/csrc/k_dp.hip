@@ -27,6 +27,11 @@
 #include "pbd_internal.hpp"
 #include "dt_core.hpp"
 
+// pointers that come out of descriptors in memory are generic to the compiler (flat loads and stores, which also
+// count as LDS traffic for s_waitcnt): say that they are global
+#define GP(U) const __attribute__((address_space(1))) U*
+#define GPW(U) __attribute__((address_space(1))) U*
+
 // debug: per-phase timestamps (100 MHz wall clock) of block 0 of the last k_dt_pass launch
 #ifdef PBD_PROBES
 __device__ unsigned long long pbd_dt_dbg[8];
@@ -136,7 +141,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         const int c = min((c0 + j) * W + wv, nch - 1);
         const int i = (int)(((unsigned)c * inv) >> 20);
         const int q = min((c - i * CH) * 64 + l64, len - 1);
-        r[j] = lptr[i][q];
+        r[j] = ((GP(T))lptr[i])[q];
       }
       // reciprocal tables: one IEEE division per (map, dx), spread over the lanes — while the loads are in flight
       if constexpr (!EX) {
@@ -248,8 +253,8 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       P2 nyz = YZl[nx];
       int nnx = (int)Bl[nx];
       const int nlines = g.nlines;
-      T* dp = (T*)mp.dst + li + (size_t)(q1 - 1) * nlines;      // running output pointers: no 64-bit multiply per element
-      int16_t* ppq = pp + (size_t)(q1 - 1) * pst;
+      GPW(T) dp = (GPW(T))mp.dst + li + (size_t)(q1 - 1) * nlines;      // running output pointers: no 64-bit multiply per element
+      GPW(int16_t) ppq = (GPW(int16_t))pp + (size_t)(q1 - 1) * pst;
       for (int q = q1 - 1; q >= q0; --q) {
         const T fos = (T)os;                   // `z[k+1] < os`: int promoted to T (:174)
         while (!(eyz.y < fos)) { e = nx; eyz = nyz; nx = nnx; nyz = YZl[nx]; nnx = (int)Bl[nx]; }
@@ -327,21 +332,21 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
   if (L <= ML) {
     T acc[ML];
 #pragma unroll
-    for (int m = 0; m < ML; ++m) acc[m] = (m < L) ? ((const T*)J.par_in[m])[cell] : (T)0;
+    for (int m = 0; m < ML; ++m) acc[m] = (m < L) ? ((GP(T))J.par_in[m])[cell] : (T)0;
     for (int c = 0; c < J.nch; ++c) {
       const ReduceChild& C = J.ch[c];
       const int K = C.K;
       int bi[ML];
       T v[ML];
       if (K == 1) {  // Math::reduceMax K==1 shortcut: copy (Math.hpp:154-158)
-        const T sd = ((const T*)C.sdt)[cell];
+        const T sd = ((GP(T))C.sdt)[cell];
 #pragma unroll
         for (int m = 0; m < ML; ++m) { bi[m] = 0; v[m] = (m < L) ? sd + biasw[C.bias_off[0] + m] : (T)0; }
       } else {
 #pragma unroll
         for (int m = 0; m < ML; ++m) { bi[m] = 0; v[m] = -INFINITY; }
         for (int mm = 0; mm < K; ++mm) {
-          const T sd = ((const T*)C.sdt)[(size_t)mm * HW + cell];
+          const T sd = ((GP(T))C.sdt)[(size_t)mm * HW + cell];
           const int bo = C.bias_off[mm];
 #pragma unroll
           for (int m = 0; m < ML; ++m) {
@@ -355,35 +360,35 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
 #pragma unroll
       for (int m = 0; m < ML; ++m) {
         if (m < L) {
-          C.ok[(size_t)m * HW + cell] = (uint8_t)bi[m];          // Ik (:150); Ix / Iy are composed at back-tracking time
+          ((GPW(uint8_t))C.ok)[(size_t)m * HW + cell] = (uint8_t)bi[m];          // Ik (:150); Ix / Iy are composed at back-tracking time
           acc[m] = acc[m] + v[m];                                // parent.score += maxv (:156), child order kept
         }
       }
     }
 #pragma unroll
-    for (int m = 0; m < ML; ++m) if (m < L) ((T*)J.par_out[m])[cell] = acc[m];
+    for (int m = 0; m < ML; ++m) if (m < L) ((GPW(T))J.par_out[m])[cell] = acc[m];
     return;
   }
   for (int m = 0; m < L; ++m) {   // generic path (more than 8 parent mixtures)
-    T acc = ((const T*)J.par_in[m])[cell];
+    T acc = ((GP(T))J.par_in[m])[cell];
     for (int c = 0; c < J.nch; ++c) {
       const ReduceChild& C = J.ch[c];
       const int K = C.K;
       T v;
       int bi = 0;
       if (K == 1) {
-        v = ((const T*)C.sdt)[cell] + biasw[C.bias_off[0] + m];
+        v = ((GP(T))C.sdt)[cell] + biasw[C.bias_off[0] + m];
       } else {
         v = -INFINITY;
         for (int mm = 0; mm < K; ++mm) {
-          const T wv = ((const T*)C.sdt)[(size_t)mm * HW + cell] + biasw[C.bias_off[mm] + m];
+          const T wv = ((GP(T))C.sdt)[(size_t)mm * HW + cell] + biasw[C.bias_off[mm] + m];
           if (wv > v) { bi = mm; v = wv; }
         }
       }
-      C.ok[(size_t)m * HW + cell] = (uint8_t)bi;
+      ((GPW(uint8_t))C.ok)[(size_t)m * HW + cell] = (uint8_t)bi;
       acc = acc + v;
     }
-    ((T*)J.par_out[m])[cell] = acc;
+    ((GPW(T))J.par_out[m])[cell] = acc;
   }
 }
 
