@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256) void k_reduce(const ReduceJob* __restrict__ jo
                                                 const float* __restrict__ biasw, int correct_ptr) {
   // block -> (job, first cell) comes from a host-built table; the job descriptor (pointers, bias
   // offsets) is staged in LDS once per block instead of being chased through global memory.
+  // (reading the descriptor with scalar loads straight from global memory instead: same time, measured)
   __shared__ ReduceJob J;
   const ReduceBlock rb = blocks[blockIdx.x];
   {

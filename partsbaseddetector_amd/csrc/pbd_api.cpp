@@ -429,9 +429,13 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   // DT LDS budget per block unless the longest line needs more at 4 lines/block
   int maxlen = 1;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
+  // block geometry, measured on MI355X (profiles/sweep_dt.sh).  float: two wavefronts and 25 KB per
+  // block = 6 blocks = 3 wavefronts per SIMD (20 .. 40 KB swept); double (17 B per line element, an IEEE division
+  // per intersection): one wavefront and 20 KB = 8 blocks per CU (0.93 ms against 1.28 with the float geometry)
+  h->dt_nt = h->ts == 8 ? 64 : PBD_DT_NT_DEFAULT;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
   if (const char* e = PBD_PROBE_ENV("PBD_DT_SEG")) h->dt_seg = atoi(e);
-  size_t dt_base = 25 * 1024;   // 6 two-wave blocks per CU (3 wavefronts per SIMD): measured optimum on MI355X (20..40 KB swept)
+  size_t dt_base = (h->ts == 8 ? 20 : 25) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_B")) dt_base = (size_t)atoi(e);
   size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 4, 2, h->ts, h->dt_nt));
@@ -1222,6 +1226,7 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMalloc(&d_ixT, HW * 2)); HIPCHK(h, hipMalloc(&d_iy, HW * 2));
   HIPCHK(h, hipMemcpyAsync(d_in, in, HW * ts, hipMemcpyHostToDevice, h->stream));
   DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
+  h->dt_nt = tsz == 8 ? 64 : PBD_DT_NT_DEFAULT;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
   size_t dt_base = 40 * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;

@@ -3,8 +3,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 export PBD_LIBRARY=$REPO/partsbaseddetector_amd/libpbd_hip_tune.so
 for nt in ${NTS:-64 128}; do for seg in ${SEGS:-0 12 16 20 24 32}; do for kb in ${KBS:-20}; do
   export PBD_DT_NT=$nt PBD_DT_SEG=$seg PBD_DT_BUDGET_B=$kb   # bytes
-  a=$(python $REPO/bench.py --steps 30 --inflight 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['stage_ms_sequential']['dp_min'])")
-  b=$(python $REPO/bench.py --steps 200 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'])")
+  a=$(python $REPO/bench.py ${DTYPE:+--dtype $DTYPE} --steps 30 --inflight 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['stage_ms_sequential']['dp_min'])")
+  b=$(python $REPO/bench.py ${DTYPE:+--dtype $DTYPE} --steps 200 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'])")
   echo "nt $nt seg $seg kb $kb: dp_min $a ms, $b frames/s"
 done; done; done
 if [ -n "$HD" ]; then for kb in ${KBS:-20}; do for nt in ${NTS:-64 128}; do
