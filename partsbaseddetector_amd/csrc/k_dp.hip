@@ -3,26 +3,25 @@
 // include/Math.hpp:108-185.
 //
 // k_dt_pass   one 1-D generalised distance transform pass (Felzenszwalb &
-//             Huttenlocher upper envelope, DistanceTransform.hpp:151-182).
-//             One lane per score line, 64 lines (possibly from several maps of
-//             the same level) per wavefront.  The envelope is built with the
-//             reference's exact arithmetic: intersection in fp64, narrowed to
+//             Huttenlocher upper envelope, DistanceTransform.hpp:151-182) over all
+//             lines of a round: a block = 64 / 128 lanes = the lines that fit its LDS
+//             budget, several lanes per line, each scanning one segment of the line;
+//             the segments are stitched into the result of the sequential run
+//             (dt_core.hpp, compiled for the host too: tests/tools/dt_core_test.cpp).
+//             Reference arithmetic throughout: intersection in fp64, narrowed to
 //             fp32 (`T s = f(...)`, :161), `s <= z[k]` pops (:162), read-out
-//             `z[k+1] < os` with the int promoted to float (:174) and the value
-//             evaluated in fp64 (:175).  Stack (v, z) and the line live in LDS
-//             (the y-values of stack entries overwrite consumed line entries in
-//             place).  Lines are read coalesced (line-contiguous input) and the
-//             result is written TRANSPOSED (element q of line i at q*nlines+i),
-//             so the x pass (rows) feeds the y pass (columns) line-contiguously
-//             and the y pass lands in natural row-major layout again, every
-//             global access coalesced across the 64 lanes.
-// k_reduce    Math::reduceMax + reducePickIndex over the child mixtures for
-//             every parent mixture, the reference's pointer composition
-//             Iy'(m,n) = Iy(m, Ix(m,n)) (DistanceTransform.hpp:233-244), and the
-//             in-order accumulation into the parent score (DynamicProgram.cpp:134-156).
+//             `z[k+1] < os` with the int promoted to T (:174) and the value
+//             evaluated in fp64 (:175).  Lines are read coalesced (line-contiguous
+//             input) and the result is written TRANSPOSED (element q of line i at
+//             q*nlines+i), so the x pass (rows) feeds the y pass (columns)
+//             line-contiguously and the y pass lands in row-major layout again.
+// k_reduce    Math::reduceMax over the child mixtures for every parent mixture (Ik;
+//             Ix / Iy are composed from the DT's own pointer planes at back-tracking
+//             time, DistanceTransform.hpp:233-244) and the in-order accumulation
+//             into the parent score (DynamicProgram.cpp:134-156).
 // k_root      root bias + reduceMax (:163-171), strict threshold (:208) and
 //             compaction of the hits.
-// k_backtrack argmin (:219-245): one lane per candidate walks the part tree.
+// k_backtrack argmin (:219-245): one block per candidate, one lane per part, depth by depth.
 #include <type_traits>
 #include "pbd_internal.hpp"
 #include "dt_core.hpp"
