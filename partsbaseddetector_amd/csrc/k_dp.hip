@@ -72,12 +72,12 @@ void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i]
 // of exact reciprocals 1/(2a*dx), dx < len (double[S]), and per line {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
 // 9 bytes per line element for float: the lines resident on a CU are bounded by these bytes.
 #define DT_SEGS 72                                   // SEG entries: P + 1 <= 65 starts, then {0, len} for a line redone as one segment
-__host__ __device__ inline size_t dt_hdr_bytes(int nt, int ts, int its) {
-  return ((size_t)64 * 8 + 64 * 4 + 64 * 4 + DT_SEGS * 4 + (size_t)nt * (2 * ts + 4 * its) + 15) & ~(size_t)15;
+__host__ __device__ inline size_t dt_hdr_bytes(int nt, int ts, int its, int lpb) {   // per line 16 B, per lane 2 T + 4 IT
+  return ((size_t)lpb * 16 + DT_SEGS * 4 + (size_t)nt * (2 * ts + 4 * its) + 15) & ~(size_t)15;
 }
 size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts, int nt) {   // ts = sizeof(T): (y, z) is a float or a double pair
   const int its = stride <= 256 ? 1 : 2;
-  return (size_t)lpb * stride * (2 * ts + its) + dt_hdr_bytes(nt, ts, its) + (((size_t)nmb * stride + 1) & ~(size_t)1) * 8 + 16;
+  return (size_t)lpb * stride * (2 * ts + its) + dt_hdr_bytes(nt, ts, its, lpb) + (((size_t)nmb * stride + 1) & ~(size_t)1) * 8 + 16;
 }
 
 // One block = NT lanes (one or two wavefronts) = up to g.lpb lines of one group (lpb chosen per group so that every
@@ -91,17 +91,17 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   const int len = g.len, S = g.stride, lpb = g.lpb;
   typedef DtPair<T> P2;
   constexpr bool EX = sizeof(T) == 8;          // DistanceTransform<double>: s is not narrowed, every intersection takes the IEEE division
-  const T** lptr = (const T**)smem;            // [64] source pointer of each line of this block
-  int* FLAG = (int*)(smem + 64 * 8);           // [64] per line: redo sequentially (suspect quotient / lost stitch invariant)
-  int* FIX = FLAG + 64;                        // [64] per line: a speculative stitch has to be redone
-  int* SEG = FIX + 64;                        // [P + 1 <= 65] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
+  const T** lptr = (const T**)smem;            // [lpb] source pointer of each line of this block
+  int* FLAG = (int*)(smem + lpb * 8);          // [lpb] per line: redo sequentially (suspect quotient / lost stitch invariant)
+  int* FIX = FLAG + lpb;                       // [lpb] per line: a speculative stitch has to be redone
+  int* SEG = FIX + lpb;                        // [P + 1 <= 65] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
   T* ZLO = (T*)(SEG + DT_SEGS);                // [NT] per lane (p * lpb + line): z of the segment's lowest surviving element
   T* ZSAVE = ZLO + NT;                         // [NT] per lane: that element's local z (before the stitch patched it)
   IT* FT = (IT*)(ZSAVE + NT);                  // [NT] per lane: that element
   IT* BELOW = FT + NT;                         // [NT] the element FT sits on
   IT* DMIN = BELOW + NT;                         // [NT] lowest element the segment's speculative stitch tested
   IT* BSAVE = DMIN + NT;                       // [NT] local link of FT (before the patch)
-  double* R = (double*)(smem + dt_hdr_bytes(NT, sizeof(T), sizeof(IT)));   // [nmb][S] 1/(2a*dx) per map of this block
+  double* R = (double*)(smem + dt_hdr_bytes(NT, sizeof(T), sizeof(IT), lpb));   // [nmb][S] 1/(2a*dx) per map of this block
   const int total = g.nmaps * g.nlines;
   const int nl = min(lpb, total - t.g0);
   const int m_first = t.g0 / g.nlines, m_last = (t.g0 + nl - 1) / g.nlines;

@@ -325,12 +325,12 @@ static void free_frame(pbd_handle* h) {
 // DT block geometry under an LDS budget.  stride = LDS elements per line: >= len + 1 and ODD — the (y, z) pairs of
 // element e of consecutive lines are then 2 * (stride mod 32) banks apart instead of in the same banks (lanes of
 // different lines work on similar element indices at the same time: with an even stride of 160 every LDS access
-// of the scan was an lpb-way bank conflict); lpb = lines per block (any value 4..64);
+// of the scan was an lpb-way bank conflict); lpb = lines per block (4 .. lanes of the block);
 // nmb = maps a block of lpb consecutive lines can touch.
 static int dt_stride_for(int len) { return (len + 1) | 1; }
 static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (lpb + nlines - 2) / nlines + 1); }
 static int dt_lpb_for(int stride, int len, int nlines, int nmaps, size_t budget, int ts, int nt, int seg) {
-  int lpb = 64;
+  int lpb = std::min(nt, 128);   // at most one line per lane
   while (lpb > 4 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts, nt) > budget) --lpb;
   // The nt / lpb lanes that share a line scan one segment of it each (dt_core.hpp), and a block lasts as long as
   // its segments are: with a target segment length, lines are given up for lanes per line where the budget
