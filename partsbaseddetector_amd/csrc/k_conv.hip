@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_conv_exact(const ConvTile* __restrict__
   const ConvTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const int H = lv.ch, W = lv.cw;
-  const int TW = CT + KW - 1, TH = CT + KH - 1;
+  const int TW = CT + KW - 1;
   const int tid = threadIdx.x;
   const T* F = feat + lv.cell_off * PBD_FLEN;
   // stage the tile: 8 lanes x float4 (16 x double2) per cell -> coalesced 128 B (256 B) per cell

@@ -269,8 +269,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 4) void k_dt_pass(const DtTask* __restrict__ tasks, const DtGroup* __restrict__ groups,
-                                                const DtMap* __restrict__ maps) {
+__global__ __launch_bounds__(256, 4) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   DT_STAMP(0);
   DT_TRACE(0);
@@ -282,8 +281,7 @@ __global__ __launch_bounds__(256, 4) void k_dt_pass(const DtTask* __restrict__ t
 }
 
 template <typename T>
-static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds,
-                             int nt, hipStream_t s) {
+static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtMap* maps, size_t lds, int nt, hipStream_t s) {
   static LdsOptIn optin;   // one per instantiation, per-device state inside
   optin.ensure((const void*)k_dt_pass<T>, lds);
 #ifdef PBD_PROBES
@@ -297,14 +295,13 @@ static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtGroup* gro
   }
   if (tracing) { static int seqs[4096]; const int seq = g_dt_trace_seq++; seqs[seq & 4095] = seq; hipMemcpyToSymbolAsync(HIP_SYMBOL(pbd_dt_trace_launch), &seqs[seq & 4095], sizeof(int), 0, hipMemcpyHostToDevice, s); }
 #endif
-  hipLaunchKernelGGL(k_dt_pass<T>, dim3(ntasks), dim3(nt), lds, s, tasks, groups, maps);
+  hipLaunchKernelGGL(k_dt_pass<T>, dim3(ntasks), dim3(nt), lds, s, tasks, maps);
 }
 // ts = sizeof(T): DistanceTransform<float> / DistanceTransform<double>
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, int ts,
-                    int nt, hipStream_t s) {
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, size_t lds, int ts, int nt, hipStream_t s) {
   if (ntasks <= 0) return;
-  if (ts == 8) launch_dt_pass_t<double>(tasks, ntasks, groups, maps, lds, nt, s);
-  else launch_dt_pass_t<float>(tasks, ntasks, groups, maps, lds, nt, s);
+  if (ts == 8) launch_dt_pass_t<double>(tasks, ntasks, maps, lds, nt, s);
+  else launch_dt_pass_t<float>(tasks, ntasks, maps, lds, nt, s);
 }
 
 // ---------------------------------------------------------------------------

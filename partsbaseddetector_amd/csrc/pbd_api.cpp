@@ -596,7 +596,6 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     }  // groups
   }
   if ((rc = dev_upload(h, &h->d_dtmaps, maps))) return rc;
-  if ((rc = dev_upload(h, &h->d_dtgroups, groups))) return rc;
   if ((rc = dev_upload(h, &h->d_dttasks, tasks))) return rc;
   if ((rc = dev_upload(h, &h->d_redjobs, red))) return rc;
   if ((rc = dev_upload(h, &h->d_redblocks, redblk))) return rc;
@@ -702,8 +701,8 @@ static int run_dp_min(pbd_handle* h) {
   if (h->ngroups > 1) hipEventRecord(h->ev_fork, h->stream);
   if (h->ngroups == 1) {  // default: one chain of rounds on the handle's stream
     for (auto& R : h->grl[0]) {
-      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, h->stream);
-      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, h->stream);
+      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, h->stream);
+      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, h->stream);
       for (auto& Wv : R.waves)
         launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
     }
@@ -712,8 +711,8 @@ static int run_dp_min(pbd_handle* h) {
     hipStream_t s = h->gstream[g];
     hipStreamWaitEvent(s, h->ev_fork, 0);
     for (auto& R : h->grl[g]) {
-      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, s);
-      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtgroups, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, s);
+      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, s);
+      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, s);
       for (auto& Wv : R.waves)
         launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, s);
     }
@@ -1237,16 +1236,15 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   for (int g0 = 0; g0 < rows; g0 += groups[0].lpb) tasks.push_back(DtTask{0, g0, groups[0]});
   const int nx = (int)tasks.size();
   for (int g0 = 0; g0 < cols; g0 += groups[1].lpb) tasks.push_back(DtTask{1, g0, groups[1]});
-  DtMap* d_maps; DtGroup* d_groups; DtTask* d_tasks;
-  HIPCHK(h, hipMalloc(&d_maps, sizeof(maps))); HIPCHK(h, hipMalloc(&d_groups, sizeof(groups)));
+  DtMap* d_maps; DtTask* d_tasks;
+  HIPCHK(h, hipMalloc(&d_maps, sizeof(maps)));
   HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size()));
   HIPCHK(h, hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(d_groups, groups, sizeof(groups), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
-  launch_dt_pass(d_tasks, nx, d_groups, d_maps, budget, tsz, h->dt_nt, h->stream);
+  launch_dt_pass(d_tasks, nx, d_maps, budget, tsz, h->dt_nt, h->stream);
   if (PBD_PROBE_ENV("PBD_DEBUG_SKIP_Y")) { hipMemsetAsync(d_sdt, 0, HW * ts, h->stream); hipMemsetAsync(d_iy, 0, HW * 2, h->stream); }   // probe build: leave the x pass as the last DT launch (its stamps are then readable)
-  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_groups, d_maps, budget, tsz, h->dt_nt, h->stream);
+  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_maps, budget, tsz, h->dt_nt, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_sdt, HW * ts, hipMemcpyDeviceToHost, h->stream));   // the y pass's scores, untouched
   HIPCHK(h, hipMemcpyAsync(hx.data(), d_ixT, HW * 2, hipMemcpyDeviceToHost, h->stream));   // the passes' own pointers
@@ -1261,7 +1259,7 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
     if (iy) iy[i] = y;
   }
   hipFree(d_in); hipFree(d_tmp); hipFree(d_sdt); hipFree(d_ixT); hipFree(d_iy);
-  hipFree(d_maps); hipFree(d_groups); hipFree(d_tasks);
+  hipFree(d_maps); hipFree(d_tasks);
   return PBD_OK;
 }
 int pbd_dt2d(pbd_handle* h, const float* in, int rows, int cols, double ax, double bx, double ay, double by, int osx,

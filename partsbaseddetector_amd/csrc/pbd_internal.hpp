@@ -154,7 +154,7 @@ struct pbd_handle {
   HogTile* d_hog_tiles = nullptr; int n_hog_tiles = 0; int hog_tc = 16;
   ConvTile* d_conv_tiles = nullptr; int n_conv_tiles = 0;
   // DP tables (all rounds back to back)
-  DtMap* d_dtmaps = nullptr; DtGroup* d_dtgroups = nullptr; DtTask* d_dttasks = nullptr;
+  DtMap* d_dtmaps = nullptr; DtTask* d_dttasks = nullptr;   // a task carries its group descriptor
   ReduceJob* d_redjobs = nullptr; ReduceBlock* d_redblocks = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
   struct ReduceWave { int blk0, nblks; };
   struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; std::vector<ReduceWave> waves; };
@@ -256,8 +256,7 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
                           const double* wT, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                             const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s);
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtGroup* groups, const DtMap* maps, size_t lds, int ts,
-                    int nt, hipStream_t s);
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, size_t lds, int ts, int nt, hipStream_t s);
 size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts, int nt);
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
                    int ts, hipStream_t s);
