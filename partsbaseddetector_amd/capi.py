@@ -88,8 +88,10 @@ class Handle:
     """Owns one pbd_handle (one GPU, one stream)."""
 
     def __init__(self, model, device=0, conv_mode=PBD_CONV_AUTO, max_candidates=4096, dt_correct_ptr=0,
-                 level_begin=0, level_end=0, dp_groups=0, dtype=np.float32, graph=0):
-        """dtype: np.float32 = PartsBasedDetector<float>, np.float64 = PartsBasedDetector<double>."""
+                 level_begin=0, level_end=0, dp_groups=0, dtype=np.float32, graph=0, dp_mode=0):
+        """dtype: np.float32 = PartsBasedDetector<float>, np.float64 = PartsBasedDetector<double>.
+        dp_mode: 0 = messages folded by the parent's x pass where the model allows it (default), 1 = the
+        three-kernel structure (x pass, y pass, reduce) for every model.  dp_groups: ignored (kept for callers)."""
         self.L = lib()
         self.model = model
         self.desc = model.to_desc()
@@ -99,7 +101,7 @@ class Handle:
         self._f64 = self.dtype == np.dtype(np.float64)
         self._ct = C.c_double if self._f64 else C.c_float
         opt = pbd_options(device, conv_mode, max_candidates, dt_correct_ptr, level_begin, level_end,
-                          PBD_SCALAR_F64 if self._f64 else PBD_SCALAR_F32, graph, (C.c_int32 * 2)(dp_groups, 0))
+                          PBD_SCALAR_F64 if self._f64 else PBD_SCALAR_F32, graph, (C.c_int32 * 2)(0, dp_mode))
         self.h = C.c_void_p()
         rc = self.L.pbd_create(C.byref(self.desc), C.byref(opt), C.byref(self.h))
         if rc != PBD_OK:

@@ -76,12 +76,15 @@ DT_HD int dt_segments(int lanes_per_line, int len) {
 // narrowed to T like `T s = f(...)` at :161:
 //   num = ((y1 - y0) - b*(x1-x0)) + a*(x1^2 - x0^2)      (same fp64 operations, same order)
 //   s   = (T)(num / den),  den = (2a)*(x1-x0)
-// EXACT = false (float only): the fp64 division is replaced by ONE multiplication with the correctly rounded
-// reciprocal r = RN(1/den) from the per-map table: q1 = RN(num * r) carries two roundings, so q1 lies within
-// 3 ulp of RN(num/den) and (float)q1 can differ from (float)RN(num/den) only if a float rounding boundary (a
-// double whose low 29 mantissa bits are 0x10000000) lies within 3 ulp of q1 — low 29 bits in
-// 0x0FFFFFFC..0x10000004 are flagged — or the value leaves the normal float range.  A flagged line is redone
-// with EXACT = true (IEEE division), so the result is always bit-identical to the reference's.
+// EXACT = false (float only): the fp64 division is replaced by ONE multiplication on the dependent chain,
+// q1 = RN(num * r) with r = RN(i2a * RDX[dx]), i2a = RN(1/(2a)) (per map, computed once on the host) and
+// RDX[dx] = RN(1/dx) (a table shared by every line of a block, whatever its map): den = (2a)*dx is exact (a
+// comes from a float, dx < 2^15), so r = (1/den)(1+e1)(1+e2)(1+e3) and q1 = (num/den)(1+e1)..(1+e4), |ei| <= 2^-53:
+// |q1 - num/den| <= 4.01 * 2^-53 * |num/den| <= 4.01 ulp(q1), hence q1 and RN(num/den) are doubles at most
+// 4 ulp apart, and (float)q1 can differ from (float)RN(num/den) only if a float rounding boundary (a double
+// whose low 29 mantissa bits are 0x10000000) lies within 4 ulp of q1 — low 29 bits in 0x0FFFFFFA..0x10000006
+// (+-6) are flagged — or the value leaves the normal float range.  A flagged line is redone with EXACT = true
+// (IEEE division), so the result is always bit-identical to the reference's.
 template <bool EXACT, typename T>
 DT_HD T dt_isect(double yk, int vk, double yq, int q, double a, double b, double twoa, double r, unsigned& suspect) {
   const int dx = q - vk;
@@ -96,7 +99,7 @@ DT_HD T dt_isect(double yk, int vk, double yq, int q, double a, double b, double
     const unsigned long long bits = dt_bits(q1);
     const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
     const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-    suspect = (((lo29 - 0x0FFFFFFCu) <= 8u) | ((ex - 897u) > 252u)) ? 1u : suspect;
+    suspect = (((lo29 - 0x0FFFFFFAu) <= 12u) | ((ex - 897u) > 252u)) ? 1u : suspect;
   }
   return (T)q1;
 }
@@ -108,15 +111,15 @@ DT_HD T dt_isect(double yk, int vk, double yq, int q, double a, double b, double
 // registers; the entry two below (addressed through the top's "below of below" kept in a register), the
 // reciprocal a pop would need and the next line element are loaded at the top of an iteration and consumed at
 // its end; the z store goes unconditionally to q's own slot (dead when the step pops).
-// R[dx] = RN(1 / (2a*dx)) (EXACT = false only).  Returns the sticky "suspect" flag.
+// RDX[dx] = RN(1 / dx), i2a = RN(1 / (2a)) (EXACT = false only).  Returns the sticky "suspect" flag.
 template <bool EXACT, typename T, typename IT>
-DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R, int s0, int s1,
-                       double a, double b) {
+DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a,
+                       int s0, int s1, double a, double b) {
   const double twoa = 2 * a;
   YZ[s0].y = (T)-INFINITY;                  // z[0] = -inf (:158): the bottom of a stack is never popped (`k > 0`, :162)
   B[s0] = (IT)s0;
   if (s1 - s0 < 2) return false;
-  const double r1 = EXACT ? 0.0 : R[1];
+  const double r1 = EXACT ? 0.0 : i2a * RDX[1];
   int vk = s0, nv = s0, nb = s0;            // top, the entry below it, the entry below that (element indices)
   T zk = (T)-INFINITY, nz = (T)-INFINITY;
   double yk = (double)YZ[s0].x, ny = yk;
@@ -128,7 +131,7 @@ DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const dou
     // prefetches (addresses known now, values used after the arithmetic below)
     const DtPair<T> pyz = YZ[nb];
     const int pb = (int)B[nb];
-    const double r_nxt = EXACT ? 0.0 : R[q - nv];        // reciprocal for the entry below the top (used if this step pops)
+    const double r_nxt = EXACT ? 0.0 : i2a * RDX[q - nv];  // reciprocal for the entry below the top (used if this step pops)
     const T ynext_f = YZ[q + 1 < s1 ? q + 1 : s1 - 1].x;
     const double yq = (double)yq_f;
     const T s = dt_isect<EXACT, T>(yk, vk, yq, q, a, b, twoa, r_top, suspect);
@@ -165,8 +168,8 @@ DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const dou
 // local values are returned in zsave / bsave so that a redo can restore them).  Returns true if the invariant
 // was lost or a quotient was suspect (the caller redoes the whole line sequentially).
 template <bool EXACT, typename T, typename IT>
-DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R, int s0, int s1,
-                      double a, double b, int& f_out, int& dmin_out, T& zsave, int& bsave) {
+DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a,
+                      int s0, int s1, double a, double b, int& f_out, int& dmin_out, T& zsave, int& bsave) {
   const double twoa = 2 * a;
   unsigned suspect = 0;
   bool bad = false;
@@ -188,7 +191,7 @@ DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const doub
     const bool cheap = testf && bf != q;
     T s = qz.y;
     if (DT_ANY(!cheap)) {
-      const double r = EXACT ? 0.0 : R[q - e];
+      const double r = EXACT ? 0.0 : i2a * RDX[q - e];
       const T si = dt_isect<EXACT, T>((double)ez.x, e, (double)qz.x, q, a, b, twoa, r, suspect);
       s = cheap ? s : si;
     }
@@ -224,21 +227,32 @@ DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const doub
 // Validation of the speculative stitches of one line, left to right (one lane per line): stitch p is kept iff
 // every element it tested below its segment lies strictly above F[p-1], the final lowest survivor of the
 // segment to its left (boundary 1 is always valid: segment 0's local scan IS the global run).  Otherwise it is
-// redone now, with everything to its left final.  F / DMIN / ZSAVE / BSAVE: per-segment tables (stride tstride).
+// redone now, with everything to its left final — and so is EVERY stitch to its right: a redone stitch p moves
+// F[p] and un-patches / re-patches z and the link of the old and the new F[p], which the speculative stitch p + 1
+// (possibly running in another wavefront at the time) may have read in either state without going below the NEW
+// F[p]; comparing DMIN[p + 1] with the new F[p] alone would not see that.  Lines that come here are rare (a few
+// per thousand), so redoing the tail costs nothing.  F / DMIN / ZSAVE / BSAVE: per-segment tables (stride tstride).
 template <bool EXACT, typename T, typename IT>
-DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ R,
+DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a,
                               const int* __restrict__ seg, int P, double a, double b, IT* __restrict__ F,
                               const IT* __restrict__ DMIN, const T* __restrict__ ZSAVE, const IT* __restrict__ BSAVE, int tstride) {
-  bool bad = false;
+  bool bad = false, redo = false;
   F[0] = (IT)0;
-  for (int p = 2; p < P; ++p) {
-    if ((int)DMIN[p * tstride] > (int)F[(p - 1) * tstride]) continue;
+  // undo every speculative patch from the first failed check on (right to left: a patch only touches its own F),
+  // then stitch those boundaries again in order
+  int p0 = P;
+  for (int p = 2; p < P; ++p)
+    if ((int)DMIN[p * tstride] <= (int)F[(p - 1) * tstride]) { p0 = p; break; }
+  for (int p = P - 1; p >= p0; --p) {
     const int fo = (int)F[p * tstride];
-    YZ[fo].y = ZSAVE[p * tstride];           // undo the speculative patch, then stitch again
+    YZ[fo].y = ZSAVE[p * tstride];
     B[fo] = BSAVE[p * tstride];
+    redo = true;
+  }
+  for (int p = p0; p < P && redo; ++p) {
     int f, dmin, bs;
     T zs;
-    bad |= dt_stitch1<EXACT, T, IT>(YZ, B, R, seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
+    bad |= dt_stitch1<EXACT, T, IT>(YZ, B, RDX, i2a, seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
     F[p * tstride] = (IT)f;
   }
   return bad;

@@ -35,7 +35,6 @@
 #ifdef PBD_PROBES
 __device__ unsigned long long pbd_dt_dbg[8];
 #define DT_COUNT_REDO() atomicAdd(&pbd_dt_dbg[7], 1ull)
-#define DT_NOVALIDATE(g) ((g).pad & 1)
 // block trace: (start, end) wall clock and hardware id of every block of the first 40 launches since the last read
 #define DT_TRACE_L 40
 #define DT_TRACE_B 4096
@@ -63,21 +62,74 @@ void dt_debug_read(unsigned long long* out) {
 #else
 #define DT_STAMP(i) do { } while (0)
 #define DT_COUNT_REDO() do { } while (0)
-#define DT_NOVALIDATE(g) false
 #define DT_TRACE(k) do { } while (0)
 void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i] = 0; }
 #endif
 
-// LDS per block: a header (per-line and per-lane descriptors, segment table), per map touched by the block a table
-// of exact reciprocals 1/(2a*dx), dx < len (double[S]), and per line {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
+// LDS per block: a header (per-line and per-lane descriptors, segment table), ONE table of exact reciprocals
+// 1/dx, dx < len (double[S], shared by all lines whatever their map: dt_core.hpp), and per line
+// {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
 // 9 bytes per line element for float: the lines resident on a CU are bounded by these bytes.
 #define DT_SEGS 72                                   // SEG entries: P + 1 <= 65 starts, then {0, len} for a line redone as one segment
 __host__ __device__ inline size_t dt_hdr_bytes(int nt, int ts, int its, int lpb) {   // per line 16 B, per lane 2 T + 4 IT
   return ((size_t)lpb * 16 + DT_SEGS * 4 + (size_t)nt * (2 * ts + 4 * its) + 15) & ~(size_t)15;
 }
-size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts, int nt) {   // ts = sizeof(T): (y, z) is a float or a double pair
+size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): (y, z) is a float or a double pair
   const int its = stride <= 256 ? 1 : 2;
-  return (size_t)lpb * stride * (2 * ts + its) + dt_hdr_bytes(nt, ts, its, lpb) + (((size_t)nmb * stride + 1) & ~(size_t)1) * 8 + 16;
+  return (size_t)lpb * stride * (2 * ts + its) + dt_hdr_bytes(nt, ts, its, lpb) + (((size_t)stride + 1) & ~(size_t)1) * 8 + 16;
+}
+
+// ---- message fold (fold mode) -------------------------------------------------------------------------------
+// The reference sends a child's message as soon as the child has been transformed (src/DynamicProgram.cpp:134-156):
+//   for every parent mixture m: weighted[k] = sdt_k + bias(k)[m] (:139), (maxv, maxi) = reduceMax (:143: init -inf,
+//   strict >, first maximum wins; K == 1: copy), Ik = maxi (:150), parent.score(m) += maxv (:156, the parent's score
+//   is a copy of its raw response until its first message, :155) — children in DESCENDING index order (:95).
+// Nothing reads the parent's accumulated score before the parent's own transform (or, for a root, the root
+// reduction), so the fold is done by the consumer: acc[m] enters with the parent's raw response at the cell and
+// leaves as ((raw + msg_c1) + msg_c2) ... — the same float operations in the same order — and the accumulated
+// planes are never stored.  The K child values of a cell are loaded once for all L parent mixtures.
+template <typename T>
+__device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ biasw, size_t off,
+                                              size_t HW, int L, bool valid, T (&acc)[PBD_FOLD_MAXMIX]) {
+  constexpr int M = PBD_FOLD_MAXMIX;
+  const int nch = J->nch;
+  for (int c = 0; c < nch; ++c) {
+    const FoldChild& C = J->ch[c];
+    const int K = C.K;
+    T sd[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) sd[k] = ((GP(T))C.sdt[k < K ? k : K - 1])[off];   // clamped, never predicated: all K loads in flight
+    T v[M];
+    int bi[M];
+    if (K == 1) {   // Math::reduceMax K == 1 shortcut: copy (Math.hpp:154-158)
+      const int bo = C.bias_off[0];
+#pragma unroll
+      for (int m = 0; m < M; ++m) { bi[m] = 0; v[m] = (m < L) ? sd[0] + biasw[bo + m] : (T)0; }
+    } else {
+#pragma unroll
+      for (int m = 0; m < M; ++m) { bi[m] = 0; v[m] = -INFINITY; }
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        if (k < K) {
+          const int bo = C.bias_off[k];
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            if (m < L) {
+              const T wv = sd[k] + biasw[bo + m];             // DynamicProgram.cpp:139
+              if (wv > v[m]) { bi[m] = k; v[m] = wv; }          // strict >: first max wins
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (m < L) {
+        if (valid) ((GPW(uint8_t))C.ok)[(size_t)m * HW + off] = (uint8_t)bi[m];   // Ik (:150)
+        acc[m] = acc[m] + v[m];                                                  // parent.score += maxv (:156), child order kept
+      }
+    }
+  }
 }
 
 // One block = NT lanes (one or two wavefronts) = up to g.lpb lines of one group (lpb chosen per group so that every
@@ -85,13 +137,17 @@ size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts, int nt) {   // ts = si
 // capacity leaves most lanes without a line of their own, so the NT / lpb lanes that share a line each scan one
 // SEGMENT of it concurrently and the segments are stitched into the sequential result (dt_core.hpp):
 // lane = p * lpb + line.
-template <typename T, typename IT>
-__device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps) {
+// FOLD: the block's lines are nrows consecutive rows x the K mixtures of one part (line = mixture * nrows + row, so
+// that neighbouring lanes write neighbouring rows of one transposed plane) and the loader builds them from the part's
+// raw responses and its children's messages (fold_children).
+template <typename T, typename IT, bool FOLD>
+__device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps,
+                                         const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
   const int lane = threadIdx.x, NT = blockDim.x;
   const int len = g.len, S = g.stride, lpb = g.lpb;
   typedef DtPair<T> P2;
   constexpr bool EX = sizeof(T) == 8;          // DistanceTransform<double>: s is not narrowed, every intersection takes the IEEE division
-  const T** lptr = (const T**)smem;            // [lpb] source pointer of each line of this block
+  const T** lptr = (const T**)smem;            // [lpb] source pointer of each line of this block (plain)
   int* FLAG = (int*)(smem + lpb * 8);          // [lpb] per line: redo sequentially (suspect quotient / lost stitch invariant)
   int* FIX = FLAG + lpb;                       // [lpb] per line: a speculative stitch has to be redone
   int* SEG = FIX + lpb;                        // [P + 1 <= 65] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
@@ -101,18 +157,18 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   IT* BELOW = FT + NT;                         // [NT] the element FT sits on
   IT* DMIN = BELOW + NT;                         // [NT] lowest element the segment's speculative stitch tested
   IT* BSAVE = DMIN + NT;                       // [NT] local link of FT (before the patch)
-  double* R = (double*)(smem + dt_hdr_bytes(NT, sizeof(T), sizeof(IT), lpb));   // [nmb][S] 1/(2a*dx) per map of this block
-  const int total = g.nmaps * g.nlines;
-  const int nl = min(lpb, total - t.g0);
-  const int m_first = t.g0 / g.nlines, m_last = (t.g0 + nl - 1) / g.nlines;
-  const int nmb = m_last - m_first + 1;
-  P2* YZ = (P2*)(R + ((g.nmb * S + 1) & ~1));  // [lpb][S] (16-byte aligned: S is odd) .x: line values (never modified); .y: z of the element when pushed
+  double* RDX = (double*)(smem + dt_hdr_bytes(NT, sizeof(T), sizeof(IT), lpb));   // [S] 1/dx
+  const int nl = t.nl;                         // lines of this block
+  const int nrows = FOLD ? nl / g.nmaps : 0;   // FOLD: rows of this block
+  P2* YZ = (P2*)(RDX + ((S + 1) & ~1));        // [lpb][S] (16-byte aligned) .x: line values (never modified); .y: z of the element when pushed
   IT* B = (IT*)(YZ + lpb * S);                 // [lpb][S] element below on the stack when pushed; later: element above (read-out)
   if (lane < nl) {
-    const int gi = t.g0 + lane;
-    const int mi = gi / g.nlines, li = gi - mi * g.nlines;
-    const DtMap& mp0 = maps[g.map0 + mi];
-    lptr[lane] = (const T*)mp0.src + (size_t)li * len;
+    if (!FOLD) {
+      const int gi = t.g0 + lane;
+      const int mi = gi / g.nlines, li = gi - mi * g.nlines;
+      const DtMap& mp0 = maps[g.map0 + mi];
+      lptr[lane] = (const T*)mp0.src + (size_t)li * len;
+    }
     FLAG[lane] = 0;
     FIX[lane] = 0;
   }
@@ -120,12 +176,40 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   const int P = dt_segments(nsub, len);          // segments per line
   if (lane <= P) SEG[lane] = dt_seg_start(lane, P, len);
   if (lane == 0) { SEG[DT_SEGS - 2] = 0; SEG[DT_SEGS - 1] = len; }
-  __syncthreads();
+  if (!FOLD) __syncthreads();
   DT_STAMP(1);
-  // coalesced load of the nl lines.  Batches of LB independent loads are issued before the first
-  // wait (addresses are clamped instead of predicated: a predicated load makes hipcc branch and
-  // wait per element, which serialises one full memory round trip per 256 B).
-  {
+  if constexpr (FOLD) {
+    // ---- fold loader: one (row, element) per lane and step, all mixtures of the part at once ----
+    const FoldJob* J = folds + g.fold;
+    const int L = g.nmaps;
+    const size_t HW = (size_t)g.nlines * len;
+    const void* srcp[PBD_FOLD_MAXMIX];
+#pragma unroll
+    for (int m = 0; m < PBD_FOLD_MAXMIX; ++m) srcp[m] = maps[g.map0 + (m < L ? m : L - 1)].src;   // the part's raw response planes
+    const int n = nrows * len;
+    for (int e0 = 0; e0 < n; e0 += NT) {
+      const int e = e0 + lane, ec = min(e, n - 1);
+      const int j = (int)((unsigned)ec / (unsigned)len), q = ec - j * len;
+      const size_t off = (size_t)(t.g0 + j) * len + q;
+      T acc[PBD_FOLD_MAXMIX];
+#pragma unroll
+      for (int m = 0; m < PBD_FOLD_MAXMIX; ++m) acc[m] = ((GP(T))srcp[m])[off];
+      // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
+      if constexpr (!EX) {
+        if (e0 == 0)
+          for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
+      }
+      fold_children<T>(J, biasw, off, HW, L, e < n, acc);
+      if (e < n) {
+#pragma unroll
+        for (int m = 0; m < PBD_FOLD_MAXMIX; ++m)
+          if (m < L) YZ[(m * nrows + j) * S + q].x = acc[m];
+      }
+    }
+  } else {
+    // coalesced load of the nl lines.  Batches of LB independent loads are issued before the first
+    // wait (addresses are clamped instead of predicated: a predicated load makes hipcc branch and
+    // wait per element, which serialises one full memory round trip per 256 B).
     const int CH = (len + 63) >> 6;          // 64-element chunks per line
     const int nch = nl * CH;
     // chunk -> (line, chunk of line) by a reciprocal multiply: an integer division per load and per store
@@ -142,14 +226,10 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         const int q = min((c - i * CH) * 64 + l64, len - 1);
         r[j] = ((GP(T))lptr[i])[q];
       }
-      // reciprocal tables: one IEEE division per (map, dx), spread over the lanes — while the loads are in flight
+      // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
       if constexpr (!EX) {
-        if (c0 == 0) {
-          for (int ms = 0; ms < nmb; ++ms) {
-            const double a = maps[g.map0 + m_first + ms].a;
-            for (int dx = lane; dx < len; dx += NT) R[ms * S + dx] = 1.0 / ((2 * a) * (double)dx);
-          }
-        }
+        if (c0 == 0)
+          for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
@@ -165,19 +245,19 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 
   const int line = lane % lpb, p = lane / lpb;
   const bool mine = line < nl && p < nsub;
+  // line -> (map, line of the map): plain: map-major; FOLD: mixture-major inside the block's rows
+  int mi = 0, li = 0;
+  if (mine) {
+    if (FOLD) { mi = line / nrows; li = t.g0 + (line - mi * nrows); }
+    else { const int gi = t.g0 + line; mi = gi / g.nlines; li = gi - mi * g.nlines; }
+  }
   DtMap mp;
-  const double* Rl = R;
   P2* YZl = YZ + line * S;
   IT* Bl = B + line * S;
-  if (mine) {
-    const int gi = t.g0 + line;
-    const int mi = gi / g.nlines;
-    mp = maps[g.map0 + mi];
-    Rl = R + (mi - m_first) * S;
-  }
+  if (mine) mp = maps[g.map0 + mi];
   // ---- local scans: the envelope of every segment (DistanceTransform.hpp:156-170 on the segment alone) ----
   if (mine && p < P) {
-    if (dt_seg_scan<EX, T, IT>(YZl, Bl, Rl, SEG[p], SEG[p + 1], mp.a, mp.b)) FLAG[line] = 1;
+    if (dt_seg_scan<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b)) FLAG[line] = 1;
   }
   __syncthreads();
   DT_STAMP(3);
@@ -185,7 +265,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   if (mine && p >= 1 && p < P && !FLAG[line]) {
     int f, dmin, bs;
     T zs;
-    const bool bad = dt_stitch1<EX, T, IT>(YZl, Bl, Rl, SEG[p], SEG[p + 1], mp.a, mp.b, f, dmin, zs, bs);
+    const bool bad = dt_stitch1<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b, f, dmin, zs, bs);
     FT[lane] = (IT)f; DMIN[lane] = (IT)dmin; ZSAVE[lane] = zs; BSAVE[lane] = (IT)bs;
     if (bad) FLAG[line] = 1;
   }
@@ -206,10 +286,10 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   // invariant (the whole line sequentially, IEEE divisions): one lane per line
   if (mine && p == 0 && (FLAG[line] | FIX[line])) {
     bool redo = FLAG[line] != 0;
-    if (!redo) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, Rl, SEG, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
+    if (!redo) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
     if (redo) {
       DT_COUNT_REDO();
-      dt_seg_scan<true, T, IT>(YZl, Bl, Rl, 0, len, mp.a, mp.b);
+      dt_seg_scan<true, T, IT>(YZl, Bl, RDX, mp.r2a, 0, len, mp.a, mp.b);
       FLAG[line] = 1;                            // the read-out takes the line as one segment
       BELOW[line] = Bl[0];
       ZLO[line] = YZl[0].y;
@@ -231,8 +311,6 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   // transposed like the scores in the y pass, natural (2-byte runs per lane, merged in L2) in the x pass — no
   // LDS staging, that space holds more lines.
   if (mine) {
-    const int gi = t.g0 + line;
-    const int mi = gi / g.nlines, li = gi - mi * g.nlines;
     const double a = mp.a, b = mp.b;
     // pointers: transposed like dst (y pass -> natural layout) or natural (x pass)
     const bool nat = mp.ptr_natural != 0;
@@ -268,40 +346,41 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   DT_STAMP(5);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 4) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps) {
+template <typename T, bool FOLD>
+__global__ __launch_bounds__(256, 4) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
+                                                    const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   DT_STAMP(0);
   DT_TRACE(0);
   const DtTask t = tasks[blockIdx.x];
   const DtGroup& g = t.g;
-  if (g.stride <= 256) dt_block<T, unsigned char>(smem, t, g, maps);    // stack indices < 255 fit a byte
-  else dt_block<T, unsigned short>(smem, t, g, maps);
+  if (g.stride <= 256) dt_block<T, unsigned char, FOLD>(smem, t, g, maps, folds, biasw);    // stack indices < 255 fit a byte
+  else dt_block<T, unsigned short, FOLD>(smem, t, g, maps, folds, biasw);
   DT_TRACE(1);
 }
 
-template <typename T>
-static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtMap* maps, size_t lds, int nt, hipStream_t s) {
+template <typename T, bool FOLD>
+static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw,
+                             size_t lds, int nt, hipStream_t s) {
   static LdsOptIn optin;   // one per instantiation, per-device state inside
-  optin.ensure((const void*)k_dt_pass<T>, lds);
+  optin.ensure((const void*)k_dt_pass<T, FOLD>, lds);
 #ifdef PBD_PROBES
   static const bool tracing = getenv("PBD_DT_TRACE") != nullptr;
-  if (tracing && g_dt_trace_seq == 0) {
-    int nb = -1; hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dt_pass<T>, nt, lds);
-    fprintf(stderr, "occupancy: k_dt_pass nt %d lds %zu -> %d blocks/CU (%s)\n", nt, lds, nb, hipGetErrorString(e));
-    hipFuncAttributes a; hipFuncGetAttributes(&a, (const void*)k_dt_pass<T>);
-    fprintf(stderr, "attrs: numRegs %d sharedSizeBytes %zu maxDynamicSharedSizeBytes %d maxThreadsPerBlock %d localSizeBytes %zu constSizeBytes %zu\n", a.numRegs, a.sharedSizeBytes, a.maxDynamicSharedSizeBytes, a.maxThreadsPerBlock, a.localSizeBytes, a.constSizeBytes);
-    for (int t2 : {64, 128}) for (size_t l2 : {(size_t)1024, (size_t)20480}) { int n2 = -1; hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (const void*)k_dt_pass<T>, t2, l2); fprintf(stderr, "  nt %d lds %zu -> %d\n", t2, l2, n2); }
-  }
   if (tracing) { static int seqs[4096]; const int seq = g_dt_trace_seq++; seqs[seq & 4095] = seq; hipMemcpyToSymbolAsync(HIP_SYMBOL(pbd_dt_trace_launch), &seqs[seq & 4095], sizeof(int), 0, hipMemcpyHostToDevice, s); }
 #endif
-  hipLaunchKernelGGL(k_dt_pass<T>, dim3(ntasks), dim3(nt), lds, s, tasks, maps);
+  hipLaunchKernelGGL((k_dt_pass<T, FOLD>), dim3(ntasks), dim3(nt), lds, s, tasks, maps, folds, biasw);
 }
-// ts = sizeof(T): DistanceTransform<float> / DistanceTransform<double>
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, size_t lds, int ts, int nt, hipStream_t s) {
+// ts = sizeof(T): DistanceTransform<float> / DistanceTransform<double>; folds != nullptr: the tasks are fold blocks
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw, size_t lds,
+                    int ts, int nt, hipStream_t s) {
   if (ntasks <= 0) return;
-  if (ts == 8) launch_dt_pass_t<double>(tasks, ntasks, maps, lds, nt, s);
-  else launch_dt_pass_t<float>(tasks, ntasks, maps, lds, nt, s);
+  if (folds) {
+    if (ts == 8) launch_dt_pass_t<double, true>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+    else launch_dt_pass_t<float, true>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+  } else {
+    if (ts == 8) launch_dt_pass_t<double, false>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+    else launch_dt_pass_t<float, false>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -401,7 +480,8 @@ void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, int njobs, double thresh,
-                                              int* __restrict__ count, CandRec* __restrict__ rec, int capacity) {
+                                              int* __restrict__ count, CandRec* __restrict__ rec, int capacity,
+                                              const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
   const unsigned gid = blockIdx.x * 256u + threadIdx.x;
   int lo = 0, hi = njobs - 1;
   while (lo < hi) {
@@ -414,7 +494,26 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
   T v;
   int bi = 0;
   const T bias = J.bias;                             // `T bias = root.bias(0)[0]` (:165)
-  if (J.K == 1) {
+  if (J.fold >= 0) {
+    // fold mode: the root's accumulated score is built here from its raw responses and its children's messages
+    constexpr int M = PBD_FOLD_MAXMIX;
+    T acc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = ((GP(T))J.score[m < J.K ? m : J.K - 1])[cell];
+    fold_children<T>(folds + J.fold, biasw, cell, (size_t)J.H * J.W, J.K, true, acc);
+    if (J.K == 1) {
+      v = acc[0] + bias;
+    } else {
+      v = -INFINITY;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if (m < J.K) {
+          const T wv = acc[m] + bias;                      // DynamicProgram.cpp:169
+          if (wv > v) { bi = m; v = wv; }
+        }
+      }
+    }
+  } else if (J.K == 1) {
     v = ((const T*)J.score[0])[cell] + bias;
   } else {
     v = -INFINITY;
@@ -436,10 +535,10 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
 }
 
 void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
-                 int capacity, int ts, hipStream_t s) {
+                 int capacity, int ts, const FoldJob* folds, const float* biasw, hipStream_t s) {
   if (njobs <= 0 || total_cells == 0) return;
-  if (ts == 8) hipLaunchKernelGGL(k_root<double>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity);
-  else hipLaunchKernelGGL(k_root<float>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity);
+  if (ts == 8) hipLaunchKernelGGL(k_root<double>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity, folds, biasw);
+  else hipLaunchKernelGGL(k_root<float>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity, folds, biasw);
 }
 
 // ---------------------------------------------------------------------------

@@ -177,6 +177,17 @@ static int ingest_model(pbd_handle* h, const pbd_model_desc* m) {
   // float adds in DESCENDING child order (:156); to keep those bits, a child's message is folded
   // no earlier than every higher-indexed sibling's (reduce round = max over them), and siblings
   // folded in the same round go through ONE reduce job that adds them in that order.
+  // fold mode (messages folded by the consumer, no accumulated planes): needs every part's accumulator to be its own
+  // (no filter id shared inside a component: the reference's ncscores is indexed by FILTER id, so two parts with
+  // one id would share an accumulator) and its mixtures / its children's to fit the register arrays of the fold
+  h->fold = !aliasing && h->opt.reserved[1] != 1;
+  {
+    std::vector<int> nchild_flat(np, 0);
+    for (int fp = 0; fp < np; ++fp) {
+      if (h->parts[fp].K > PBD_FOLD_MAXMIX) h->fold = false;
+      if (h->parts[fp].p > 0 && ++nchild_flat[h->part_offset[h->parts[fp].comp] + h->parts[fp].parent] > PBD_MAX_CH) h->fold = false;
+    }
+  }
   h->rounds.clear();
   h->red_rounds.clear();
   if (aliasing) {  // shared filter ids inside a component: keep the reference's strictly sequential order
@@ -325,30 +336,49 @@ static void free_frame(pbd_handle* h) {
 // DT block geometry under an LDS budget.  stride = LDS elements per line: >= len + 1 and ODD — the (y, z) pairs of
 // element e of consecutive lines are then 2 * (stride mod 32) banks apart instead of in the same banks (lanes of
 // different lines work on similar element indices at the same time: with an even stride of 160 every LDS access
-// of the scan was an lpb-way bank conflict); lpb = lines per block (4 .. lanes of the block);
-// nmb = maps a block of lpb consecutive lines can touch.
+// of the scan was an lpb-way bank conflict); lpb = lines per block: 4 .. lanes of the block (plain), or a whole
+// number of rows x the K mixtures of the part (fold: unit = K).
 static int dt_stride_for(int len) { return (len + 1) | 1; }
-static int dt_nmb_for(int lpb, int nlines, int nmaps) { return std::min(nmaps, (lpb + nlines - 2) / nlines + 1); }
-static int dt_lpb_for(int stride, int len, int nlines, int nmaps, size_t budget, int ts, int nt, int seg) {
+static int dt_lpb_for(int stride, int len, int unit, size_t budget, int ts, int nt, int seg) {
+  const int lmin = unit > 1 ? unit : 4;
   int lpb = std::min(nt, 128);   // at most one line per lane
-  while (lpb > 4 && dt_lds_bytes(stride, lpb, dt_nmb_for(lpb, nlines, nmaps), ts, nt) > budget) --lpb;
+  if (unit > 1) lpb = std::max(unit, lpb / unit * unit);
+  while (lpb > lmin && dt_lds_bytes(stride, lpb, ts, nt) > budget) lpb -= (unit > 1 ? unit : 1);
   // The nt / lpb lanes that share a line scan one segment of it each (dt_core.hpp), and a block lasts as long as
   // its segments are: with a target segment length, lines are given up for lanes per line where the budget
   // would put so many lines into a block that each is left with one or two lanes.
   if (seg > 0) {
     const int P = std::max(1, std::min(nt / 4, (len + seg - 1) / seg));
-    lpb = std::max(4, std::min(lpb, nt / P));
+    int cap = std::max(lmin, nt / P);
+    if (unit > 1) cap = std::max(unit, cap / unit * unit);
+    lpb = std::min(lpb, cap);
   }
   return lpb;
 }
-static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts, int nt, int seg) {
+// fold >= 0: the group is one part at one level, a block = whole rows of its nmaps mixtures
+static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts, int nt, int seg, int fold = -1) {
   DtGroup g{};
-  g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len;
+  g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len; g.fold = fold;
   g.stride = dt_stride_for(len);
-  g.lpb = dt_lpb_for(g.stride, len, nlines, nmaps, budget, ts, nt, seg);
-  g.nmb = dt_nmb_for(g.lpb, nlines, nmaps);
-  if (PBD_PROBE_ENV("PBD_DEBUG_NOVALIDATE")) g.pad = 1;   // timing probe: speculative stitches taken as they are (results may be wrong)
+  g.lpb = dt_lpb_for(g.stride, len, fold >= 0 ? nmaps : 1, budget, ts, nt, seg);
   return g;
+}
+static void dt_add_tasks(const DtGroup& g, std::vector<DtTask>& out) {
+  if (g.fold >= 0) {
+    const int R = g.lpb / g.nmaps;
+    for (int r0 = 0; r0 < g.nlines; r0 += R) out.push_back(DtTask{r0, std::min(R, g.nlines - r0) * g.nmaps, g});
+  } else {
+    const int total = g.nmaps * g.nlines;
+    for (int g0 = 0; g0 < total; g0 += g.lpb) out.push_back(DtTask{g0, std::min(g.lpb, total - g0), g});
+  }
+}
+static DtMap dt_map(const void* src, void* dst, int16_t* ptr, float wq, float wl, int os, int natural) {
+  DtMap m{};
+  m.src = src; m.dst = dst; m.ptr = ptr;
+  m.a = -(double)wq; m.b = -(double)wl;      // Quadratic fx(-w0, -w1), fy(-w2, -w3) (src/DynamicProgram.cpp:125-127)
+  m.r2a = 1.0 / (2.0 * m.a);                 // IEEE division (dt_core.hpp: dt_isect)
+  m.os = os; m.ptr_natural = natural;
+  return m;
 }
 
 static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
@@ -381,7 +411,6 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   const size_t ts = (size_t)h->ts;   // sizeof(T); T buffers are char* addressed as elements * ts
   if ((rc = dev_alloc(h, &h->d_feat, cells * PBD_FLEN * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_resp, cells * m.nfilters * ts))) return rc;
-  if ((rc = dev_alloc(h, &h->d_acc, cells * h->nslots * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_pk, cells * std::max(h->nplanes, 1)))) return rc;
   if ((rc = dev_alloc(h, &h->d_rootv, cells * m.ncomponents * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_rooti, cells * m.ncomponents))) return rc;
@@ -413,20 +442,31 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   if ((rc = dev_upload(h, &h->d_conv_tiles, ct))) return rc;
 
   // ---- DP tables ---------------------------------------------------------------
-  // DT scratch: every (part, mixture) keeps its own x-pass / y-pass outputs until its message has
-  // been folded (a message may wait for a higher-indexed sibling), so nothing is recycled:
-  // 4 planes x 150 maps x 140 K cells = 250 MB for the person model, trivial next to 288 GB.
   size_t act_cells = 0;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) act_cells += (size_t)h->lv[l].cw * h->lv[l].ch;
   size_t allmaps = 0;
   for (const PartInfo& P : h->parts) if (P.p > 0) allmaps += P.K;
+  std::vector<size_t> roundK(h->rounds.size(), 0);   // maps transformed in round r (per level)
+  size_t maxK = 1;
+  for (size_t r = 0; r < h->rounds.size(); ++r) {
+    for (int fp : h->rounds[r]) roundK[r] += h->parts[fp].K;
+    maxK = std::max(maxK, roundK[r]);
+  }
+  const bool fold = h->fold;
+  // DT planes.  The passes' own pointer planes (int16) stay for the whole frame: back-tracking composes Ix / Iy from
+  // them.  Score planes — fold: the x pass's output lives only until the round's y pass (one round's worth, reused
+  // by every round), the y pass's output (the message source) keeps its own plane until the parent's x pass has
+  // read it; legacy: both kept per map (a message may wait several rounds for a higher-indexed sibling), plus the
+  // accumulated part scores.
   h->dt_cap_elems = std::max<size_t>(1, allmaps * act_cells);
-  if ((rc = dev_alloc(h, &h->d_dt_tmpT, h->dt_cap_elems * ts))) return rc;
+  const size_t tmp_elems = fold ? std::max<size_t>(1, maxK * act_cells) : h->dt_cap_elems;
+  if ((rc = dev_alloc(h, &h->d_dt_tmpT, tmp_elems * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_sdt, h->dt_cap_elems * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_ixT, h->dt_cap_elems))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_iy, h->dt_cap_elems))) return rc;
+  if (!fold && (rc = dev_alloc(h, &h->d_acc, cells * h->nslots * ts))) return rc;
 
-  // DT LDS budget per block unless the longest line needs more at 4 lines/block
+  // DT LDS budget per block unless the longest line needs more at the minimum number of lines per block
   int maxlen = 1;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
   // block geometry, measured on MI355X (profiles/sweep_dt.sh).  float: two wavefronts and 25 KB per
@@ -438,18 +478,32 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   size_t dt_base = (h->ts == 8 ? 20 : 25) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_B")) dt_base = (size_t)atoi(e);
-  size_t dt_budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(maxlen), 4, 2, h->ts, h->dt_nt));
-  if (dt_budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
-  h->dt_lds = dt_budget;
-  if (const char* e = PBD_PROBE_ENV("PBD_DT_LDS_REQUEST_KB")) h->dt_lds = std::max(h->dt_lds, (size_t)atoi(e) * 1024);   // occupancy probe
+  int max_mix = 4;
+  if (fold) for (const PartInfo& P : h->parts) max_mix = std::max(max_mix, P.K);
+  const size_t dt_need = dt_lds_bytes(dt_stride_for(maxlen), max_mix, h->ts, h->dt_nt);   // the longest line at the fewest lines a block can hold
+  if (dt_need > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "pyramid level too large for the LDS-resident distance transform");
+  h->dt_lds = std::max(dt_base, dt_need);
+  // A launch with fewer maps than the fullest round of the frame (the person tree: rounds of 4, 4, 4, 4, 2, 2, 2, 2, 1
+  // parts) would leave LDS — and lanes — idle at the full budget, while every launch lasts as long as its blocks'
+  // segments are: its blocks get proportionally FEWER lines (about the same number of blocks as the fullest launch),
+  // i.e. more lanes per line and shorter segments.
+  bool thin = true;
+  size_t thin_min = 10 * 1024;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_THIN")) thin = atoi(e) != 0;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_THIN_MIN_KB")) thin_min = (size_t)atoi(e) * 1024;
+  auto launch_budget = [&](size_t K_launch) {
+    size_t bgt = h->dt_lds;
+    if (thin && K_launch < maxK) bgt = std::max(thin_min, (size_t)((double)dt_base * (double)K_launch / (double)maxK));
+    return std::min(std::max(bgt, dt_need), h->dt_lds);
+  };
   std::vector<DtMap> maps;
-  std::vector<DtGroup> groups;
   std::vector<DtTask> tasks;
+  std::vector<FoldJob> folds;
   std::vector<ReduceJob> red;
   std::vector<ReduceBlock> redblk;
   h->rl.clear();
-  std::vector<char> slot_init((size_t)h->nslots, 0);  // ncscores[fid].empty() emulation (same for every level)
-  // scratch offset of (part, level): parts in flat order, levels inside
+  std::vector<char> slot_init((size_t)h->nslots, 0);  // legacy: ncscores[fid].empty() emulation (same for every level)
+  // plane offset of (part, level, mixture) in the per-map DT planes: parts in flat order, levels inside
   std::vector<size_t> part_scr(h->parts.size(), 0);
   { size_t o = 0; for (size_t fp = 0; fp < h->parts.size(); ++fp) if (h->parts[fp].p > 0) { part_scr[fp] = o; o += (size_t)h->parts[fp].K * act_cells; } }
   std::vector<size_t> lvl_scr(n, 0);  // prefix of active cells
@@ -457,102 +511,107 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   auto scr_of = [&](int fp, int l, int mm) {
     return part_scr[fp] + (size_t)h->parts[fp].K * lvl_scr[l] + (size_t)mm * h->lv[l].cw * h->lv[l].ch;
   };
-  // level groups: walk levels fine -> coarse, start a new group whenever the x-pass of the busiest
-  // round would exceed ~800 blocks (one wave of 4 blocks per CU on 256 CUs)
-  {
-    size_t maxK = 1;
-    for (auto& rnd : h->rounds) { size_t k = 0; for (int fp : rnd) k += h->parts[fp].K; maxK = std::max(maxK, k); }
-    int gcur = 0; size_t blocks = 0;
-    for (int l = 0; l < n; ++l) {
-      const Level& L = h->lv[l];
-      if (L.active && L.cw > 0 && L.ch > 0) {
-        const DtGroup gx = dt_group(0, (int)maxK, L.ch, L.cw, dt_budget, h->ts, h->dt_nt, h->dt_seg);
-        const size_t b = ((size_t)maxK * L.ch + gx.lpb - 1) / gx.lpb;
-        if (blocks + b > 800 && blocks > 0 && gcur < h->ngroups - 1) { gcur++; blocks = 0; }
-        blocks += b;
-      }
-      h->level_group[l] = gcur;
+  auto resp_plane = [&](int l, int fid) { return h->d_resp + (h->lv[l].cell_off * m.nfilters + (size_t)fid * h->lv[l].cw * h->lv[l].ch) * ts; };
+  auto sdt_plane = [&](int fp, int l, int mm) { return h->d_dt_sdt + scr_of(fp, l, mm) * ts; };
+  // children of every part, descending flat index (the order their messages are added in, src/DynamicProgram.cpp:95)
+  std::vector<std::vector<int>> children(h->parts.size());
+  for (int fp = (int)h->parts.size() - 1; fp >= 0; --fp)
+    if (h->parts[fp].p > 0) children[h->part_offset[h->parts[fp].comp] + h->parts[fp].parent].push_back(fp);
+  auto make_fold = [&](int fp, int l) {   // FoldJob of part fp at level l (its children's messages); -1 without children
+    if (children[fp].empty()) return -1;
+    const Level& L = h->lv[l];
+    const size_t HW = (size_t)L.cw * L.ch;
+    FoldJob J{};
+    for (int c : children[fp]) {
+      const PartInfo& C = h->parts[c];
+      FoldChild& F = J.ch[J.nch++];
+      F.K = C.K;
+      for (int k = 0; k < PBD_FOLD_MAXMIX; ++k) F.sdt[k] = sdt_plane(c, l, std::min(k, C.K - 1));
+      for (int k = 0; k < C.K; ++k) F.bias_off[k] = C.biasid[k];
+      F.ok = h->d_pk + L.cell_off * h->nplanes + (size_t)C.plane0 * HW;
     }
-  }
-  for (int gi_ = 0; gi_ < PBD_NGROUPS; ++gi_) h->grl[gi_].clear();
+    folds.push_back(J);
+    return (int)folds.size() - 1;
+  };
+  // Workgroup b runs on XCD b % 8, each with its own L2.  A block writes its lines transposed, i.e. runs of a few
+  // elements — a fraction of a 128-byte line; the neighbouring runs belong to the next tasks of the same map.
+  // Order a launch's table so that `xcd_chunk` consecutive tasks share an XCD and the partial lines merge in one
+  // L2 instead of going out to HBM from several.
+  int xchunk = h->xcd_chunk;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_XCD_CHUNK")) xchunk = atoi(e);
+  auto xcd_order = [xchunk](std::vector<DtTask>& v) {
+    const int c = xchunk;
+    if (c <= 0) return;
+    const size_t win = (size_t)8 * c, full = v.size() / win * win;
+    std::vector<DtTask> o(v);
+    for (size_t b = 0; b < full; ++b) {
+      const size_t xcd = b & 7, idx = b >> 3;
+      o[b] = v[((idx / c) * 8 + xcd) * c + idx % c];
+    }
+    v.swap(o);
+  };
+  auto launch_lds = [&](const std::vector<DtTask>& v) {
+    size_t lds = 0;
+    for (const DtTask& t : v) lds = std::max(lds, dt_lds_bytes(t.g.stride, t.g.lpb, h->ts, h->dt_nt));
+    if (const char* e = PBD_PROBE_ENV("PBD_DT_LDS_REQUEST_KB")) lds = std::max(lds, (size_t)atoi(e) * 1024);   // occupancy probe
+    return lds;
+  };
+  const bool dbg_plan = PBD_PROBE_ENV("PBD_DEBUG_PLAN") != nullptr;
   for (size_t r = 0; r < h->rounds.size(); ++r) {
     const std::vector<int>& rnd = h->rounds[r];
-    for (int grp = 0; grp < h->ngroups; ++grp) {
     pbd_handle::RoundLaunch R{};
+    const size_t budget = launch_budget(roundK[r]);
+    const bool fold_x = fold && r > 0;   // round 0 = the leaves: their lines are their raw responses
     std::vector<DtTask> xt, yt;
     for (int l = 0; l < n && !rnd.empty(); ++l) {
       const Level& L = h->lv[l];
-      if (!L.active || L.cw == 0 || L.ch == 0 || h->level_group[l] != grp) continue;
+      if (!L.active || L.cw == 0 || L.ch == 0) continue;
       const size_t HW = (size_t)L.cw * L.ch;
       const int gx_map0 = (int)maps.size();
       int gx_nmaps = 0;
       std::vector<DtMap> ymaps;
+      size_t tmp_round = 0;   // fold: offset of the part's block in the round's x-pass output
       for (int fp : rnd) {
         const PartInfo& P = h->parts[fp];
+        const int part_map0 = (int)maps.size();
         for (int mm = 0; mm < P.K; ++mm) {
           const int fid = P.filterid[mm], did = P.defid[mm];
           const size_t so = scr_of(fp, l, mm);
-          const char* src = slot_init[P.slot[mm]] ? h->d_acc + (L.cell_off * h->nslots + (size_t)P.slot[mm] * HW) * ts
-                                                  : h->d_resp + (L.cell_off * m.nfilters + (size_t)fid * HW) * ts;
+          const size_t to = fold ? tmp_round + (size_t)P.K * lvl_scr[l] + (size_t)mm * HW : so;
+          const char* src = (!fold && slot_init[P.slot[mm]]) ? h->d_acc + (L.cell_off * h->nslots + (size_t)P.slot[mm] * HW) * ts
+                                                            : resp_plane(l, fid);
           const float* wv = &h->defw[(size_t)did * 4];
-          DtMap mx{src, h->d_dt_tmpT + so * ts, h->d_dt_ixT + so, -(double)wv[0], -(double)wv[1], h->anchors[did * 2], 1};
-          DtMap my{h->d_dt_tmpT + so * ts, h->d_dt_sdt + so * ts, h->d_dt_iy + so, -(double)wv[2], -(double)wv[3],
-                   h->anchors[did * 2 + 1], 0};
-          maps.push_back(mx);
-          ymaps.push_back(my);
+          maps.push_back(dt_map(src, h->d_dt_tmpT + to * ts, h->d_dt_ixT + so, wv[0], wv[1], h->anchors[did * 2], 1));
+          ymaps.push_back(dt_map(h->d_dt_tmpT + to * ts, sdt_plane(fp, l, mm), h->d_dt_iy + so, wv[2], wv[3], h->anchors[did * 2 + 1], 0));
           gx_nmaps++;
         }
+        tmp_round += (size_t)P.K * act_cells;
+        if (fold_x) dt_add_tasks(dt_group(part_map0, P.K, L.ch, L.cw, budget, h->ts, h->dt_nt, h->dt_seg, make_fold(fp, l)), xt);
       }
-      const DtGroup gx = dt_group(gx_map0, gx_nmaps, L.ch, L.cw, dt_budget, h->ts, h->dt_nt, h->dt_seg);
-      const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, dt_budget, h->ts, h->dt_nt, h->dt_seg);
+      if (!fold_x) dt_add_tasks(dt_group(gx_map0, gx_nmaps, L.ch, L.cw, budget, h->ts, h->dt_nt, h->dt_seg), xt);
+      const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, budget, h->ts, h->dt_nt, h->dt_seg);
       for (auto& my : ymaps) maps.push_back(my);
-      const int gxi = (int)groups.size();
-      groups.push_back(gx);
-      const int gyi = (int)groups.size();
-      groups.push_back(gy);
-      auto add_tasks = [&](const DtGroup& g, int gidx, std::vector<DtTask>& lane_t) {
-        for (int g0 = 0; g0 < g.nmaps * g.nlines; g0 += g.lpb) lane_t.push_back(DtTask{gidx, g0, g});
-      };
-      if (PBD_PROBE_ENV("PBD_DEBUG_PLAN") && r == 0)
-        fprintf(stderr, "plan: level %d  x: len %d lines %d maps %d lpb %d P %d tasks %zu..  y: len %d lines %d lpb %d P %d tasks %zu..\n", l,
-                gx.len, gx.nlines, gx.nmaps, gx.lpb, std::max(1, std::min(h->dt_nt / gx.lpb, gx.len / 8)), xt.size(),
-                gy.len, gy.nlines, gy.lpb, std::max(1, std::min(h->dt_nt / gy.lpb, gy.len / 8)), yt.size());
-      add_tasks(gx, gxi, xt);
-      add_tasks(gy, gyi, yt);
+      dt_add_tasks(gy, yt);
+      if (dbg_plan)
+        fprintf(stderr, "plan: round %zu level %d  x: len %d lines %d maps %d lpb %d  y: len %d lines %d lpb %d  (budget %zu)\n", r, l,
+                L.cw, L.ch, gx_nmaps, xt.empty() ? 0 : xt.back().g.lpb, gy.len, gy.nlines, gy.lpb, budget);
     }
     if (const char* e = PBD_PROBE_ENV("PBD_DEBUG_DUP")) {   // scaling probe: every DT block issued n times (identical outputs)
       const int ndup = atoi(e);
       const std::vector<DtTask> x0 = xt, y0 = yt;
       for (int i = 1; i < ndup; ++i) { xt.insert(xt.end(), x0.begin(), x0.end()); yt.insert(yt.end(), y0.begin(), y0.end()); }
     }
-    // Workgroup b runs on XCD b % 8, each with its own L2.  A block writes its lpb lines transposed, i.e. runs of
-    // 4 * lpb bytes — a fraction of a 128-byte line; the neighbouring runs belong to the next tasks of the same
-    // map.  Order the table so that `xcd_chunk` consecutive tasks share an XCD and the partial lines merge in
-    // one L2 instead of going out to HBM from several.
-    {
-      int c = h->xcd_chunk;
-      if (const char* e = PBD_PROBE_ENV("PBD_DT_XCD_CHUNK")) c = atoi(e);
-      auto xcd_order = [c](std::vector<DtTask>& v) {
-        if (c <= 0) return;
-        const size_t win = (size_t)8 * c, full = v.size() / win * win;
-        std::vector<DtTask> o(v);
-        for (size_t b = 0; b < full; ++b) {
-          const size_t xcd = b & 7, idx = b >> 3;
-          o[b] = v[((idx / c) * 8 + xcd) * c + idx % c];
-        }
-        v.swap(o);
-      };
-      xcd_order(xt);
-      xcd_order(yt);
-    }
-    if (PBD_PROBE_ENV("PBD_DEBUG_PLAN")) fprintf(stderr, "plan: round %zu group %d: %zu x blocks, %zu y blocks\n", r, grp, xt.size(), yt.size());
+    xcd_order(xt);
+    xcd_order(yt);
+    R.lds_x = launch_lds(xt); R.lds_y = launch_lds(yt); R.fold_x = fold_x ? 1 : 0;
+    if (dbg_plan) fprintf(stderr, "plan: round %zu: %zu x blocks (%zu B LDS%s), %zu y blocks (%zu B)\n", r, xt.size(), R.lds_x, fold_x ? ", fold" : "", yt.size(), R.lds_y);
     R.xtask0 = (int)tasks.size(); R.nxtasks = (int)xt.size();
     tasks.insert(tasks.end(), xt.begin(), xt.end());
     R.ytask0 = (int)tasks.size(); R.nytasks = (int)yt.size();
     tasks.insert(tasks.end(), yt.begin(), yt.end());
-    // reduce waves of this round (slot state is advanced once per wave, after the last group)
-    std::vector<char> slot_w = slot_init;
-    for (const std::vector<int>& wave : h->red_rounds[r]) {
+    // legacy: reduce waves of this round (slot state is advanced once per wave)
+    for (size_t wi = 0; !fold && wi < h->red_rounds[r].size(); ++wi) {
+      const std::vector<int>& wave = h->red_rounds[r][wi];
       pbd_handle::ReduceWave Wv{(int)redblk.size(), 0};
       std::vector<int> parents;  // distinct parents, in first-appearance order
       for (int fp : wave) {
@@ -561,7 +620,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       }
       for (int l = 0; l < n; ++l) {
         const Level& L = h->lv[l];
-        if (!L.active || L.cw == 0 || L.ch == 0 || h->level_group[l] != grp) continue;
+        if (!L.active || L.cw == 0 || L.ch == 0) continue;
         const size_t HW = (size_t)L.cw * L.ch;
         for (int pf : parents) {
           const PartInfo& Par = h->parts[pf];
@@ -569,15 +628,14 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
           J.H = L.ch; J.W = L.cw; J.L = Par.K;
           for (int pm = 0; pm < Par.K; ++pm) {
             char* accp = h->d_acc + (L.cell_off * h->nslots + (size_t)Par.slot[pm] * HW) * ts;
-            J.par_in[pm] = slot_w[Par.slot[pm]] ? accp : h->d_resp + (L.cell_off * m.nfilters + (size_t)Par.filterid[pm] * HW) * ts;
+            J.par_in[pm] = slot_init[Par.slot[pm]] ? accp : resp_plane(l, Par.filterid[pm]);
             J.par_out[pm] = accp;
           }
           for (int fp : wave) {  // `wave` is in descending child order
             const PartInfo& P = h->parts[fp];
             if (h->part_offset[P.comp] + P.parent != pf) continue;
             ReduceChild& C = J.ch[J.nch++];
-            const size_t so = scr_of(fp, l, 0);
-            C.sdt = h->d_dt_sdt + so * ts;
+            C.sdt = sdt_plane(fp, l, 0);
             C.ok = h->d_pk + L.cell_off * h->nplanes + (size_t)P.plane0 * HW;
             C.K = P.K;
             for (int mm = 0; mm < P.K; ++mm) C.bias_off[mm] = P.biasid[mm];
@@ -587,18 +645,12 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
         }
       }
       for (int pf : parents)
-        for (int pm = 0; pm < h->parts[pf].K; ++pm) slot_w[h->parts[pf].slot[pm]] = 1;
+        for (int pm = 0; pm < h->parts[pf].K; ++pm) slot_init[h->parts[pf].slot[pm]] = 1;
       Wv.nblks = (int)redblk.size() - Wv.blk0;
       R.waves.push_back(Wv);
     }
-    h->grl[grp].push_back(R);
-    if (grp == h->ngroups - 1) slot_init = slot_w;
-    }  // groups
+    h->rl.push_back(R);
   }
-  if ((rc = dev_upload(h, &h->d_dtmaps, maps))) return rc;
-  if ((rc = dev_upload(h, &h->d_dttasks, tasks))) return rc;
-  if ((rc = dev_upload(h, &h->d_redjobs, red))) return rc;
-  if ((rc = dev_upload(h, &h->d_redblocks, redblk))) return rc;
 
   // root jobs + backtracking info
   std::vector<RootJob> rj;
@@ -618,16 +670,22 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       const PartInfo& R0 = h->parts[h->part_offset[c]];
       RootJob J{};
       for (int k = 0; k < R0.K; ++k)
-        J.score[k] = slot_init[R0.slot[k]] ? h->d_acc + (L.cell_off * h->nslots + (size_t)R0.slot[k] * HW) * ts
-                                           : h->d_resp + (L.cell_off * m.nfilters + (size_t)R0.filterid[k] * HW) * ts;
+        J.score[k] = (!fold && slot_init[R0.slot[k]]) ? h->d_acc + (L.cell_off * h->nslots + (size_t)R0.slot[k] * HW) * ts
+                                                      : resp_plane(l, R0.filterid[k]);
       J.rootv = (void*)B.rootv; J.rooti = (int*)B.rooti;
       J.H = L.ch; J.W = L.cw; J.K = R0.K; J.level = l; J.comp = c;
       J.bias = h->biasw[R0.biasid[0]];  // root.bias(0)[0], DynamicProgram.cpp:165
       J.cell0 = rcells;
+      J.fold = fold ? make_fold(h->part_offset[c], l) : -1;   // fold: the root's messages are folded by k_root
       rcells += (unsigned)HW;
       rj.push_back(J);
     }
   }
+  if ((rc = dev_upload(h, &h->d_dtmaps, maps))) return rc;
+  if ((rc = dev_upload(h, &h->d_dttasks, tasks))) return rc;
+  if ((rc = dev_upload(h, &h->d_foldjobs, folds))) return rc;
+  if ((rc = dev_upload(h, &h->d_redjobs, red))) return rc;
+  if ((rc = dev_upload(h, &h->d_redblocks, redblk))) return rc;
   h->n_rootjobs = (int)rj.size();
   h->root_cells = rcells;
   if ((rc = dev_upload(h, &h->d_rootjobs, rj))) return rc;
@@ -697,31 +755,18 @@ static int run_pdf(pbd_handle* h) {
 static int run_dp_min(pbd_handle* h) {
   const bool dpt = h->profiling && h->dp_timer_on;
   if (dpt) hipEventRecord(h->ev_dp0, h->stream);
-  // optional fork: every level group runs its chain of rounds on its own stream
-  if (h->ngroups > 1) hipEventRecord(h->ev_fork, h->stream);
-  if (h->ngroups == 1) {  // default: one chain of rounds on the handle's stream
-    for (auto& R : h->grl[0]) {
-      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, h->stream);
-      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, h->stream);
-      for (auto& Wv : R.waves)
-        launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
-    }
-  }
-  for (int g = 0; g < h->ngroups && h->ngroups > 1; ++g) {
-    hipStream_t s = h->gstream[g];
-    hipStreamWaitEvent(s, h->ev_fork, 0);
-    for (auto& R : h->grl[g]) {
-      launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, s);
-      launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, h->dt_lds, h->ts, h->dt_nt, s);
-      for (auto& Wv : R.waves)
-        launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, s);
-    }
-    hipEventRecord(h->ev_join[g], s);
-    hipStreamWaitEvent(h->stream, h->ev_join[g], 0);  // join
+  // one chain of rounds on the handle's stream.  fold: x pass (from round 1 on its loader folds the children's
+  // messages) + y pass per round, the root's messages folded by k_root: 2 * rounds + 1 launches; legacy (models that
+  // alias a filter id inside a component, or more than 8 mixtures): + the round's reduce launches.
+  for (auto& R : h->rl) {
+    launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, R.fold_x ? h->d_foldjobs : nullptr, h->d_biasw, R.lds_x, h->ts, h->dt_nt, h->stream);
+    launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, nullptr, h->d_biasw, R.lds_y, h->ts, h->dt_nt, h->stream);
+    for (auto& Wv : R.waves)
+      launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
   }
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
   launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
-              h->opt.max_candidates, h->ts, h->stream);
+              h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, h->stream);
   if (dpt) hipEventRecord(h->ev_dp1, h->stream);
   h->dp_timed = dpt;
   LAUNCHCHK(h, "DP min");
@@ -839,7 +884,7 @@ static int enqueue_stages(pbd_handle* h, const uint8_t* d_src, int stride) {
 // an image that lives elsewhere in HBM is copied there first (0.9 MB, on the same stream).  Profiling runs (stage
 // events) and level groups on extra streams use the eager path.
 static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
-  const bool graphable = h->opt.graph && !h->profiling && h->ngroups == 1;
+  const bool graphable = h->opt.graph && !h->profiling;
   if (!graphable || h->frames_on_plan == 0) {
     h->frames_on_plan++;
     return enqueue_stages(h, d_src, stride);
@@ -894,7 +939,6 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   h->ts = (o.scalar_type == PBD_SCALAR_F64) ? 8 : 4;
   int rc = ingest_model(h, model);
   if (rc) return rc;
-  h->ngroups = std::min(std::max(o.reserved[0], 1), PBD_NGROUPS);
   h->conv_mode = o.conv_mode;
   if (h->conv_mode == PBD_CONV_AUTO)
     // measured on MI355X for N = 26 .. 312 5x5x32 filters at 640x480 (profiles/r02b_conv_modes.json): the fp32 MFMA
@@ -911,11 +955,6 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   for (int i = 0; i < 8; ++i) HIPCHK(h, hipEventCreate(&h->ev[i]));
   HIPCHK(h, hipEventCreate(&h->ev_dp0));
   HIPCHK(h, hipEventCreate(&h->ev_dp1));
-  HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-  for (int g = 0; g < PBD_NGROUPS && h->ngroups > 1; ++g) {  // extra streams only when asked for: streams share a few HW queues
-    HIPCHK(h, hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
-  }
   return upload_model(h);
 }
 
@@ -931,11 +970,6 @@ int pbd_destroy(pbd_handle* h) {
   for (int i = 0; i < 8; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
   if (h->ev_dp0) hipEventDestroy(h->ev_dp0);
   if (h->ev_dp1) hipEventDestroy(h->ev_dp1);
-  if (h->ev_fork) hipEventDestroy(h->ev_fork);
-  for (int g = 0; g < PBD_NGROUPS; ++g) {
-    if (h->gstream[g]) { hipStreamSynchronize(h->gstream[g]); hipStreamDestroy(h->gstream[g]); }
-    if (h->ev_join[g]) hipEventDestroy(h->ev_join[g]);
-  }
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return PBD_OK;
@@ -1224,27 +1258,29 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMalloc(&d_in, HW * ts)); HIPCHK(h, hipMalloc(&d_tmp, HW * ts)); HIPCHK(h, hipMalloc(&d_sdt, HW * ts));
   HIPCHK(h, hipMalloc(&d_ixT, HW * 2)); HIPCHK(h, hipMalloc(&d_iy, HW * 2));
   HIPCHK(h, hipMemcpyAsync(d_in, in, HW * ts, hipMemcpyHostToDevice, h->stream));
-  DtMap maps[2] = {{d_in, d_tmp, d_ixT, ax, bx, osx, 1}, {d_tmp, d_sdt, d_iy, ay, by, osy, 0}};
+  DtMap maps[2] = {dt_map(d_in, d_tmp, d_ixT, 0.f, 0.f, osx, 1), dt_map(d_tmp, d_sdt, d_iy, 0.f, 0.f, osy, 0)};
+  maps[0].a = ax; maps[0].b = bx; maps[0].r2a = 1.0 / (2.0 * ax);   // the caller's quadratics (not the model's -w)
+  maps[1].a = ay; maps[1].b = by; maps[1].r2a = 1.0 / (2.0 * ay);
   h->dt_nt = tsz == 8 ? 64 : PBD_DT_NT_DEFAULT;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
   size_t dt_base = 40 * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
-  const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 4, 1, tsz, h->dt_nt));
+  const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 4, tsz, h->dt_nt));
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
   DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz, h->dt_nt, h->dt_seg), dt_group(1, 1, cols, rows, budget, tsz, h->dt_nt, h->dt_seg)};
   std::vector<DtTask> tasks;
-  for (int g0 = 0; g0 < rows; g0 += groups[0].lpb) tasks.push_back(DtTask{0, g0, groups[0]});
+  dt_add_tasks(groups[0], tasks);
   const int nx = (int)tasks.size();
-  for (int g0 = 0; g0 < cols; g0 += groups[1].lpb) tasks.push_back(DtTask{1, g0, groups[1]});
+  dt_add_tasks(groups[1], tasks);
   DtMap* d_maps; DtTask* d_tasks;
   HIPCHK(h, hipMalloc(&d_maps, sizeof(maps)));
   HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size()));
   HIPCHK(h, hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
-  launch_dt_pass(d_tasks, nx, d_maps, budget, tsz, h->dt_nt, h->stream);
+  launch_dt_pass(d_tasks, nx, d_maps, nullptr, h->d_biasw, budget, tsz, h->dt_nt, h->stream);
   if (PBD_PROBE_ENV("PBD_DEBUG_SKIP_Y")) { hipMemsetAsync(d_sdt, 0, HW * ts, h->stream); hipMemsetAsync(d_iy, 0, HW * 2, h->stream); }   // probe build: leave the x pass as the last DT launch (its stamps are then readable)
-  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_maps, budget, tsz, h->dt_nt, h->stream);
+  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_maps, nullptr, h->d_biasw, budget, tsz, h->dt_nt, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_sdt, HW * ts, hipMemcpyDeviceToHost, h->stream));   // the y pass's scores, untouched
   HIPCHK(h, hipMemcpyAsync(hx.data(), d_ixT, HW * 2, hipMemcpyDeviceToHost, h->stream));   // the passes' own pointers

@@ -59,10 +59,16 @@ struct DtMap {       // one 1-D pass over one score map
   void* dst;         // T: transposed out: element q of line i at dst + q*nlines + i
   int16_t* ptr;      // same layout as dst
   double a, b;       // Quadratic(a, b)
+  double r2a;        // RN(1 / (2a)), IEEE division on the host (dt_core.hpp: the reciprocal of an intersection's denominator)
   int os, ptr_natural;  // ptr_natural: write ptr row-major [line][q] instead of transposed
 };
-struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, nmb, pad; };  // stride: LDS elements per line (even); lpb: lines per block; nmb: max maps a block touches
-struct DtTask { int group, g0; DtGroup g; };   // the block's group travels with the task: one dependent global load less at block start
+// One group = the maps of one launch that share a geometry: nmaps maps of nlines lines of len elements.
+//   plain:  line gi of the group = line gi % nlines of map gi / nlines (map-major); a block = lpb consecutive lines.
+//   fold:   the group is ONE part at one level (nmaps = its K mixtures, the lines of a row are its K mixtures): a
+//           block = nrows consecutive rows x K mixtures, and its loader builds the lines on the fly from the part's raw
+//           responses and its children's distance-transformed scores (FoldJob).
+struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, fold, pad; };  // stride: LDS elements per line (odd); lpb: lines per block; fold: FoldJob index or -1
+struct DtTask { int g0, nl; DtGroup g; };   // g0: first line (plain) / first row (fold); nl: lines of this block; the group travels with the task
 #ifndef PBD_DT_NT_DEFAULT
 #define PBD_DT_NT_DEFAULT 128   // lanes of a k_dt_pass block
 #endif
@@ -76,6 +82,17 @@ struct ReduceChild {     // one child part's distance-transformed mixtures
   int K, pad;
   int bias_off[PBD_MAX_MIX];  // biasw index of bias(mm)[0] for each child mixture mm
 };
+// fold mode: the children of one (level, part), descending child index (src/DynamicProgram.cpp:95); read by the loader
+// of the part's x pass (k_dt_pass<T, true>) and, for a root, by k_root
+#define PBD_FOLD_MAXMIX 8   // fold mode keeps one value per parent mixture / child mixture in registers: K, L <= 8
+struct FoldChild {
+  const void* sdt[PBD_FOLD_MAXMIX];   // T [H][W]: distance-transformed scores of child mixture k (one pointer per plane: the planes may
+                                      // be the child's own response planes, overwritten in place by its y pass)
+  uint8_t* ok;                        // output Ik: best child mixture per parent mixture, [L][H][W]
+  int K, pad;
+  int bias_off[PBD_FOLD_MAXMIX];      // biasw index of bias(k)[0]
+};
+struct FoldJob { int nch, pad; FoldChild ch[PBD_MAX_CH]; };
 struct ReduceJob {       // one (level, parent): fold the messages of nch children, in the reference's order
   int H, W, L, nch;
   const void* par_in[PBD_MAX_MIX];   // T: parent mixture m: current score (resp plane or acc slot)
@@ -89,6 +106,7 @@ struct RootJob {
   int H, W, K, level, comp;
   float bias;
   unsigned cell0;
+  int fold, pad;                   // FoldJob of the root part (score[] are then its raw responses) or -1
 };
 struct BackLevel {   // per (level, comp) info for backtracking
   const uint8_t* pk;   // best-mixture plane 0 of this comp at this level
@@ -157,17 +175,10 @@ struct pbd_handle {
   DtMap* d_dtmaps = nullptr; DtTask* d_dttasks = nullptr;   // a task carries its group descriptor
   ReduceJob* d_redjobs = nullptr; ReduceBlock* d_redblocks = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
   struct ReduceWave { int blk0, nblks; };
-  struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; std::vector<ReduceWave> waves; };
-  // Pyramid levels never interact in the DP (src/DynamicProgram.cpp:83-87), so levels are split into
-  // PBD_NGROUPS size classes, each running its own chain of rounds on its own stream: a launch then
-  // only waits for the longest line of ITS levels, and the big-level group fits one wave of blocks.
-  #define PBD_NGROUPS 3
-  std::vector<RoundLaunch> grl[PBD_NGROUPS];          // [group][round]
-  hipStream_t gstream[PBD_NGROUPS] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[PBD_NGROUPS] = {};
-  int level_group[PBD_MAX_LEVELS] = {};
-  int ngroups = 1;   // pbd_options.reserved[0]: 1 (default) .. PBD_NGROUPS; measured slower than one chain on MI355X
-  size_t dt_lds = 0;                                 // dynamic LDS of every k_dt_pass launch
+  struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; size_t lds_x, lds_y; int fold_x; std::vector<ReduceWave> waves; };
+  size_t dt_lds = 0;                                 // LDS budget of a k_dt_pass block in the fullest launch of a frame (thinner launches get less)
+  bool fold = false;                                 // DP structure of this handle: messages folded by the parent's x pass (no k_reduce, no acc planes)
+  FoldJob* d_foldjobs = nullptr;
   int dt_nt = PBD_DT_NT_DEFAULT;                                   // lanes of a k_dt_pass block (64 or 128)
   int dt_seg = 0;                                    // target segment length of the DT scans (0: as many lines per block as fit)
   int xcd_chunk = 16;                                // consecutive k_dt_pass tasks kept on one XCD (0: table order)
@@ -256,12 +267,13 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
                           const double* wT, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                             const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s);
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, size_t lds, int ts, int nt, hipStream_t s);
-size_t dt_lds_bytes(int stride, int lpb, int nmb, int ts, int nt);
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw, size_t lds,
+                    int ts, int nt, hipStream_t s);
+size_t dt_lds_bytes(int stride, int lpb, int ts, int nt);
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
                    int ts, hipStream_t s);
 void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
-                 int capacity, int ts, hipStream_t s);
+                 int capacity, int ts, const FoldJob* folds, const float* biasw, hipStream_t s);
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
                       char* out, size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,

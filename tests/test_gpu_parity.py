@@ -166,8 +166,8 @@ def test_dt2d_is_max_plus_transform(small_handle):
 
 
 # ---------------------------------------------------------------- DP min / argmin
-def _dp_case(orc, model, w, h, seed, inject=True):
-    hd = capi.Handle(model, conv_mode=capi.PBD_CONV_EXACT)
+def _dp_case(orc, model, w, h, seed, inject=True, dp_mode=0):
+    hd = capi.Handle(model, conv_mode=capi.PBD_CONV_EXACT, dp_mode=dp_mode)
     hd.begin_frame(w, h, 3)
     g = hd._geo
     rng = np.random.default_rng(seed)
@@ -205,6 +205,33 @@ def test_dp_min_bit_exact_single_mixture(gpu_required, orc):
 
 def test_dp_min_bit_exact_multi_component(gpu_required, orc):
     _dp_case(orc, make_face_like_model(seed=5, ncomp=3, nfilters=20, part_counts=(5, 9)), 80, 60, 3)
+
+
+def test_dp_min_three_kernel_structure(gpu_required, orc):
+    """dp_mode = 1: x pass / y pass / k_reduce with accumulated planes (the structure of models the fold cannot
+    take) gives the same tables as the fold on models it can."""
+    _dp_case(orc, make_tree_model([-1, 0, 1, 1, 0, 4, 4, 2], 3, seed=9), 120, 90, 1, dp_mode=1)
+    _dp_case(orc, make_face_like_model(seed=5, ncomp=3, nfilters=20, part_counts=(5, 9)), 80, 60, 3, dp_mode=1)
+
+
+def test_dp_min_shared_filter_inside_component(gpu_required, orc):
+    """Two parts of one component with the same filter ids share ONE accumulator in the reference (ncscores is indexed
+    by filter id, src/DynamicProgram.cpp:93,115,155): the library keeps the reference's strictly sequential order."""
+    m = make_tree_model([-1, 0, 1, 1, 0, 4], 2, seed=12)
+    m.filterid[0][3] = list(m.filterid[0][2])
+    _dp_case(orc, m, 100, 80, 4)
+
+
+def test_dp_min_many_mixtures(gpu_required, orc):
+    """More than 8 mixtures per part: beyond the fold's register arrays, three-kernel structure."""
+    _dp_case(orc, make_tree_model([-1, 0, 1, 0], 9, seed=13), 80, 60, 5)
+
+
+@pytest.mark.parametrize("parents,K", [([-1, 0, 0, 0, 0, 0, 0, 0, 0, 0], 2), ([-1, 0, 1, 2, 3, 4, 5], 4), ([-1, 0, 0, 1, 1, 2, 2], 1),
+                                       ([-1, 0, 1, 1, 1, 2, 2, 5, 5, 5], 3)])
+def test_dp_min_fold_tree_shapes(gpu_required, orc, parents, K):
+    """The fold on stars (nine children of the root), chains, binary trees and mixed fan-outs."""
+    _dp_case(orc, make_tree_model(parents, K, seed=20 + K), 110, 80, 6 + K)
 
 
 # ---------------------------------------------------------------- detect() end to end

@@ -28,13 +28,14 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
   std::vector<double> R(S);
   constexpr bool EX = sizeof(T) == 8;
   for (int i = 0; i < len; ++i) YZ[i].x = src[i];
-  if (!EX) for (int dx = 0; dx < len; ++dx) R[dx] = 1.0 / ((2 * a) * (double)dx);
+  if (!EX) for (int dx = 1; dx < len; ++dx) R[dx] = 1.0 / (double)dx;   // the block-wide 1/dx table of k_dt_pass
+  const double i2a = 1.0 / (2 * a);                                      // DtMap::r2a (host, IEEE)
   int P = dt_segments(lanes, len);
   std::vector<int> seg(P + 1);
   for (int p = 0; p <= P; ++p) seg[p] = dt_seg_start(p, P, len);
   bool flag = false;
   for (int p = 0; p < P; ++p)
-    flag |= dt_seg_scan<EX, T, IT>(YZ.data(), B.data(), R.data(), seg[p], seg[p + 1], a, b);
+    flag |= dt_seg_scan<EX, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[p], seg[p + 1], a, b);
   if (flag) st.suspect++;
   if (!flag && P > 1) {
     // the kernel stitches all boundaries concurrently (speculation); any interleaving must give the same result:
@@ -49,14 +50,14 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
     for (int p : order) {
       int f, dmin, bs;
       T zs;
-      bad |= dt_stitch1<EX, T, IT>(YZ.data(), B.data(), R.data(), seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
+      bad |= dt_stitch1<EX, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
       F[p] = (IT)f; DM[p] = (IT)dmin; ZS[p] = zs; BS[p] = (IT)bs;
     }
     bool fix = false;                // every lane checks its own stitch (k_dt_pass); only then the sequential fix-up
     for (int p = 2; p < P; ++p) if ((int)DM[p] <= (int)F[p - 1]) fix = true;
     if (fix) {
       st.events++;
-      bad |= dt_stitch_validate<EX, T, IT>(YZ.data(), B.data(), R.data(), seg.data(), P, a, b, F.data(), DM.data(), ZS.data(), BS.data(), 1);
+      bad |= dt_stitch_validate<EX, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg.data(), P, a, b, F.data(), DM.data(), ZS.data(), BS.data(), 1);
     }
     if (bad) st.inconsistent++;
     flag |= bad;
@@ -64,7 +65,7 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
   if (flag) {                      // fallback: the whole line sequentially, IEEE divisions
     P = 1;
     seg[1] = len;
-    dt_seg_scan<true, T, IT>(YZ.data(), B.data(), R.data(), 0, len, a, b);
+    dt_seg_scan<true, T, IT>(YZ.data(), B.data(), R.data(), i2a, 0, len, a, b);
   }
   F[0] = 0;
   for (int p = 0; p < P; ++p) { BELOW[p] = B[F[p]]; ZLO[p] = YZ[F[p]].y; }   // one lane per segment in the kernel
