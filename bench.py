@@ -19,7 +19,10 @@ Protocol:
   * `cpu_baseline`: the oracle (reference-structured OpenMP restatement) on the box's host cores — 2 warm-ups +
     median of 5 frames on all cores, and a one-thread leg on a bounded sample.
 Frames are independent, so ranks shard frames with no data-path collective ("weak" scaling: one frame per rank
-per step); the only collective is the RCCL all_gather of the candidate buffers.
+per step); the only collective is the gather of the candidate buffers to rank 0 (RCCL over xGMI with backend
+nccl) — done for EVERY step, inside the timed region ("multi-GPU wall time includes the RCCL
+candidate gather").  `python bench.py --gpus N` without a torchrun environment spawns its own N ranks
+(torch.distributed.run on 127.0.0.1); `--group` is the one-process alternative (pbd_group).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -75,6 +78,17 @@ def cpu_info():
         pass
     nthreads = os.cpu_count() or 1
     return model, (len(cores) or nthreads), nthreads
+
+
+def respawn_command(argv, n, port=None):
+    """`python bench.py --gpus N` outside torchrun: the command that runs the same arguments as N ranks on this node."""
+    import socket
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def main_group(args):
@@ -149,11 +163,19 @@ def main():
 
     if args.group:
         return main_group(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torchrun environment: become the launcher of our own N ranks (one process per GPU, rendezvous on 127.0.0.1)
+        import subprocess
+        if args.backend == "nccl" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible "
+                             f"(RCCL wants one GPU per rank; --backend gloo oversubscribes a GPU for smoke runs)")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+        raise SystemExit(subprocess.call(respawn_command(sys.argv[1:], args.gpus), env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % max(1, torch.cuda.device_count())  # (gloo smoke runs may oversubscribe one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -187,11 +209,22 @@ def main():
         for hd in handles:
             hd.set_levels(my_levels)
 
+    gcap = 192 if W * H <= 640 * 480 else 2048      # records per rank in the fixed-size gather block (more raises, never truncates)
+    gathered_last = [None]
+
+    def gather(out):
+        """The one collective of the path: this step's candidates of every rank -> rank 0 (N = 1: nothing to do)."""
+        if world > 1:
+            gathered_last[0] = gather_candidates(out, handles[0].max_parts, capacity=gcap, device=cdev, dst=0)
+
     def run(nsteps, collect_out=None, stamps=None, host=False):
-        """S frames in flight; host=True hands over pinned host images (H2D inside every step)."""
+        """S frames in flight; host=True hands over pinned host images (H2D inside every step).  N > 1: every
+        step's candidates are gathered to rank 0 — after the next frame has been enqueued, so the collective
+        overlaps the GPU's work on the frames in flight."""
         pending = []
         for i in range(nsteps):
             hd = handles[i % S]
+            out = None
             if len(pending) == S:
                 out = pending.pop(0).collect(cap)
                 if stamps is not None:
@@ -203,12 +236,15 @@ def main():
             else:
                 hd.enqueue_dev(frames[i % nimg].data_ptr(), W, H, 3)
             pending.append(hd)
+            if out is not None:
+                gather(out)
         for hd in pending:
             out = hd.collect(cap)
             if stamps is not None:
                 stamps.append(time.perf_counter())
             if collect_out is not None:
                 collect_out.append(out)
+            gather(out)
 
     def timed(nsteps, host):
         torch.cuda.synchronize()
@@ -247,9 +283,7 @@ def main():
     # ---- the same K steps handing over pinned host images: H2D inside every step ----
     dt_h2d, outs_h2d, per_frame_ms_h2d = timed(args.steps, host=True)
     if world > 1:
-        # the one collective of the path: candidates of the last frame of every rank -> rank 0
-        gathered = gather_candidates(outs[-1], handles[0].max_parts, capacity=cap, device=cdev)
-        ncand_all = sum(len(g[0]) for g in gathered)
+        ncand_all = sum(len(g[0]) for g in gathered_last[0]) if rank == 0 else 0   # the last step's gather (inside the timed region)
     else:
         ncand_all = len(outs[-1][0])
 
@@ -286,14 +320,18 @@ def main():
         # with HIP events on the handle's stream in the sequential leg.
         dp_gbs = work["B_dp"] / (dp_ms * 1e-3) / 1e9
         pdf_tf = work["F_pdf"] / (stage["pdf"] * 1e-3) / 1e12 if stage["pdf"] > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_dp.json")
         if os.path.exists(tpath) and (W, H, args.mixtures, args.dtype) == (640, 480, 6, "f32"):
-            traffic = json.load(open(tpath))["hbm_bytes_per_frame_corrected"]
+            tj = json.load(open(tpath))
+            traffic = tj["hbm_bytes_per_frame_corrected"]
+            traffic_source = (f"profiles/traffic_dp.json ({tj.get('tag', '?')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              f"command, FETCH x2 per MI355X_MICROARCH.md; committed file, not measured in this run)")
         if stage["dp_min"] >= stage["pdf"]:
             roof = {"kernel": "dp_min stage (distance-transform passes + mixture reduce + root) per frame", "bound": "hbm",
                     "achieved": round(dp_gbs, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(dp_gbs / 8000.0, 5),
-                    "traffic": traffic, "launch_ms": round(float(dp_ms), 4), "algorithmic_bytes": work["B_dp"],
+                    "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(float(dp_ms), 4),
+                    "algorithmic_bytes": work["B_dp"], "launch_mode": "eager launches, per-stage HIP events on (the timed loop replays a hipGraph)",
                     "timing": f"HIP events around the stage, mean of {nseq} sequential frames after the timed loop"}
         else:
             peak = 78.6 if args.dtype == "f64" else 157.3     # dense vector/matrix FMA peak of the dtype (MI355X_MICROARCH.md)
@@ -313,10 +351,14 @@ def main():
                        "frames_per_step_per_gpu": 1, "inflight": S, "conv": args.conv, "input": "frames resident in HBM",
                        "launch": "hipGraph replay (one hipGraphLaunch per frame)" if args.graph else "eager (~40 launches per frame)",
                        "prewarm_s": 0.0 if args.no_prewarm else PREWARM_S, "prewarm_frames": prewarm_frames,
-                       "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}")},
+                       "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}"),
+                       "gather": (f"every step, inside the timed region: torch.distributed gather to rank 0, backend {args.backend}, "
+                                  f"{gcap} records per rank" if world > 1 else "none (one rank)")},
             "frame_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),
                          "what": "completion-to-completion wall time per frame in the timed loop (rank 0)"},
-            "value_incl_h2d": round(value_h2d, 3),
+            "value_resident": round(value, 3), "value_incl_h2d": round(value_h2d, 3),
+            "value_is": "frames resident in HBM when the timed region starts (this tier's contract for `value`); the H2D-inclusive "
+                        "figure of SURVEY 8d is value_incl_h2d",
             "incl_h2d": {"value": round(value_h2d, 3), "unit": "frames/s", "ms_per_step": round(dt_h2d / args.steps * 1e3, 4),
                          "frame_ms": {"median": pct(per_frame_ms_h2d, 50), "p10": pct(per_frame_ms_h2d, 10), "p90": pct(per_frame_ms_h2d, 90)},
                          "what": "the same K steps with every frame handed over as a pinned host image (pbd_detect_enqueue_u8: "
@@ -353,7 +395,8 @@ def main():
             line["cpu_baseline"] = {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": ncores, "threads": ncores,
                                     "hw_threads": nhw, "kind": "port", "cpu": cpu_name,
                                     "sample": f"median of 5 frames {W}x{H} after 2 warm-ups, same model, oracle/pbd_oracle.c "
-                                              f"(OpenMP at the reference's five loops), one thread on each of the {ncores} physical cores",
+                                              f"(OpenMP at the reference's five loops: the filter bank is `omp for` over its {len(model.filtersw)} filters on "
+                                              f"{ncores} threads), one thread on each of the {ncores} physical cores",
                                     "frame_s": {"median": round(med, 4), "min": round(min(times), 4), "max": round(max(times), 4)},
                                     "stage_ms": [round(x, 1) for x in stage_ms],
                                     "single_thread": {"value": round(1.0 / t1, 4), "unit": "frames/s", "threads": 1,

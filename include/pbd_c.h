@@ -105,8 +105,17 @@ typedef struct pbd_options {
                             instead of the float ones                          */
   int32_t graph;         /* 1: capture the ~40 launches of a frame into a hipGraph once per frame geometry and
                             replay it (one hipGraphLaunch per frame instead of ~40 launches); 0: eager launches */
-  int32_t reserved[2];   /* [0]: DP level groups on separate streams (0/1 = one chain, max 3); [1]: unused     */
+  int32_t reserved[2];   /* [0]: ignored (rounds 1-2: DP level groups on separate streams, removed);
+                            [1]: dp_mode — 0: a part's messages are folded by its own x pass wherever the model allows it
+                                 (no filter id shared inside a component, <= 8 mixtures per part, <= 8 children per part),
+                                 1: the three-kernel structure (x pass, y pass, reduce + accumulated planes) for every model */
 } pbd_options;
+/* The layout of pbd_options and pbd_model_desc is frozen from PBD_ABI_VERSION 3 on: new options take a reserved slot
+ * or a new entry point, fields are never inserted.  pbd_abi_version() returns the version the LIBRARY was built with;
+ * a binding compares it with the header it was compiled against (round 2 inserted `graph` in front of reserved[],
+ * which nothing could detect).                                                                                       */
+#define PBD_ABI_VERSION 3
+int pbd_abi_version(void);
 
 /* ---- output record: include/Candidate.hpp:56-111 --------------------------
  * One candidate = head + max_parts boxes (x, y, width, height as cv::Rect)
@@ -233,6 +242,14 @@ int pbd_get_dp_pointers(pbd_handle* h, int level, int component, int part, int p
                         int32_t* ix, int32_t* iy, int32_t* ik);
 int pbd_get_root(pbd_handle* h, int level, int component, float* rootv, int32_t* rooti);
 int pbd_get_root_f64(pbd_handle* h, int level, int component, double* rootv, int32_t* rooti);
+/* DynamicProgram<T>::argmin takes rootv / rooti / Ix / Iy / Ik as arguments (include/DynamicProgram.hpp:75).  A caller
+ * whose tables are not the ones this handle's min() left on the device (another engine's min(), edited tables) hands
+ * them over here before pbd_dp_argmin; the next pbd_dp_min / detect goes back to the handle's own tables.  The first
+ * pbd_set_dp_pointers after a min() materialises all composed planes once (the planes not handed in keep min()'s).  */
+int pbd_set_root(pbd_handle* h, int level, int component, const float* rootv, const int32_t* rooti);
+int pbd_set_root_f64(pbd_handle* h, int level, int component, const double* rootv, const int32_t* rooti);
+int pbd_set_dp_pointers(pbd_handle* h, int level, int component, int part, int parent_mix,
+                        const int32_t* ix, const int32_t* iy, const int32_t* ik);
 /* DynamicProgram<T>::argmin (src/DynamicProgram.cpp:189-255)                  */
 int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
                   int capacity, int* count);
@@ -276,6 +293,9 @@ int pbd_set_profiling(pbd_handle* h, int on);
 /* algorithmic bytes / flops of the last frame geometry (SURVEY §8d formulas):
  * [0] B_hog [1] B_pdf [2] F_pdf [3] B_dp [4] cells [5] dt_elements            */
 int pbd_get_work(const pbd_handle* h, double work[6]);
+/* device memory held by the handle: the buffers and work tables of the current frame geometry (everything a
+ * re-plan frees) and the model-sized allocations made at create.  Either pointer may be NULL.                     */
+int pbd_get_footprint(const pbd_handle* h, size_t* frame_bytes, size_t* model_bytes);
 /* average GPU ms of the DP-min kernels alone over frames since the last reset
  * (HIP events on the handle's stream around the DP stage)                    */
 int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes);

@@ -36,7 +36,9 @@ EXPORTS = [
     "pbd_detect_enqueue_u8", "pbd_group_create", "pbd_group_destroy", "pbd_group_last_error", "pbd_group_size",
     "pbd_group_gather_mode", "pbd_group_member", "pbd_group_detect_batch_u8", "pbd_group_detect_u8",
     "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps",
+    "pbd_set_root", "pbd_set_root_f64", "pbd_set_dp_pointers", "pbd_get_footprint", "pbd_abi_version",
 ]
+PBD_ABI_VERSION = 3
 
 
 class pbd_options(C.Structure):
@@ -76,6 +78,8 @@ def lib() -> C.CDLL:
         L.pbd_group_member.argtypes = [C.c_void_p, C.c_int]
         for name in EXPORTS:
             getattr(L, name)  # every declared symbol must be exported
+        if L.pbd_abi_version() != PBD_ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {L.pbd_abi_version()}, this binding is for {PBD_ABI_VERSION}")
         _lib = L
     return _lib
 
@@ -261,6 +265,21 @@ class Handle:
         rv, ri = np.zeros(sh, self.dtype), np.zeros(sh, np.int32)
         self._chk(self._fn("pbd_get_root")(self.h, l, c, _p(rv, self._ct), _p(ri, C.c_int32)))
         return rv, ri
+
+    def set_root(self, l, c, rootv, rooti):
+        rv, ri = np.ascontiguousarray(rootv, self.dtype), np.ascontiguousarray(rooti, np.int32)
+        self._chk(self._fn("pbd_set_root")(self.h, l, c, _p(rv, self._ct), _p(ri, C.c_int32)))
+
+    def set_dp_pointers(self, l, c, p, m, ix, iy, ik):
+        """hand DynamicProgram::argmin pointer tables that this handle's min() did not produce"""
+        a = [np.ascontiguousarray(t, np.int32) for t in (ix, iy, ik)]
+        self._chk(self.L.pbd_set_dp_pointers(self.h, l, c, p, m, *[_p(t, C.c_int32) for t in a]))
+
+    def footprint(self):
+        """(frame_bytes, model_bytes) of device memory held by the handle"""
+        fb, mb = C.c_size_t(0), C.c_size_t(0)
+        self._chk(self.L.pbd_get_footprint(self.h, C.byref(fb), C.byref(mb)))
+        return fb.value, mb.value
 
     def dp_argmin(self, capacity=4096):
         heads, boxes, locs = self._bufs(capacity)

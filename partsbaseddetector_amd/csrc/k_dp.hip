@@ -88,10 +88,10 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // reduction), so the fold is done by the consumer: acc[m] enters with the parent's raw response at the cell and
 // leaves as ((raw + msg_c1) + msg_c2) ... — the same float operations in the same order — and the accumulated
 // planes are never stored.  The K child values of a cell are loaded once for all L parent mixtures.
-template <typename T>
+// M = upper bound of the mixture counts involved (register arrays; a launch is instantiated for the bound of its model)
+template <typename T, int M>
 __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ biasw, size_t off,
-                                              size_t HW, int L, bool valid, T (&acc)[PBD_FOLD_MAXMIX]) {
-  constexpr int M = PBD_FOLD_MAXMIX;
+                                              size_t HW, int L, bool valid, T (&acc)[M]) {
   const int nch = J->nch;
   for (int c = 0; c < nch; ++c) {
     const FoldChild& C = J->ch[c];
@@ -140,9 +140,10 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
 // FOLD: the block's lines are nrows consecutive rows x the K mixtures of one part (line = mixture * nrows + row, so
 // that neighbouring lanes write neighbouring rows of one transposed plane) and the loader builds them from the part's
 // raw responses and its children's messages (fold_children).
-template <typename T, typename IT, bool FOLD>
+template <typename T, typename IT, int FM>   // FM: 0 = plain lines, else fold with at most FM mixtures per part
 __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps,
                                          const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
+  constexpr bool FOLD = FM > 0;
   const int lane = threadIdx.x, NT = blockDim.x;
   const int len = g.len, S = g.stride, lpb = g.lpb;
   typedef DtPair<T> P2;
@@ -179,31 +180,43 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   if (!FOLD) __syncthreads();
   DT_STAMP(1);
   if constexpr (FOLD) {
-    // ---- fold loader: one (row, element) per lane and step, all mixtures of the part at once ----
+    // ---- fold loader: U (row, element) cells per lane and step, all mixtures of the part at once; the loads of the U
+    // cells are issued back to back (one memory round trip per step, like the plain loader's batches) ----
+    constexpr int M = FM > 0 ? FM : 1;
+    constexpr int U = sizeof(T) == 8 ? 2 : 3;
     const FoldJob* J = folds + g.fold;
     const int L = g.nmaps;
     const size_t HW = (size_t)g.nlines * len;
-    const void* srcp[PBD_FOLD_MAXMIX];
+    const void* srcp[M];
 #pragma unroll
-    for (int m = 0; m < PBD_FOLD_MAXMIX; ++m) srcp[m] = maps[g.map0 + (m < L ? m : L - 1)].src;   // the part's raw response planes
+    for (int m = 0; m < M; ++m) srcp[m] = maps[g.map0 + (m < L ? m : L - 1)].src;   // the part's raw response planes
     const int n = nrows * len;
-    for (int e0 = 0; e0 < n; e0 += NT) {
-      const int e = e0 + lane, ec = min(e, n - 1);
-      const int j = (int)((unsigned)ec / (unsigned)len), q = ec - j * len;
-      const size_t off = (size_t)(t.g0 + j) * len + q;
-      T acc[PBD_FOLD_MAXMIX];
+    for (int e0 = 0; e0 < n; e0 += NT * U) {
+      T acc[U][M];
+      size_t off[U];
+      int jj[U], qq[U];
 #pragma unroll
-      for (int m = 0; m < PBD_FOLD_MAXMIX; ++m) acc[m] = ((GP(T))srcp[m])[off];
+      for (int u = 0; u < U; ++u) {
+        const int ec = min(e0 + u * NT + lane, n - 1);
+        jj[u] = (int)((unsigned)ec / (unsigned)len); qq[u] = ec - jj[u] * len;
+        off[u] = (size_t)(t.g0 + jj[u]) * len + qq[u];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[u][m] = ((GP(T))srcp[m])[off[u]];
+      }
       // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
       if constexpr (!EX) {
         if (e0 == 0)
           for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
-      fold_children<T>(J, biasw, off, HW, L, e < n, acc);
-      if (e < n) {
 #pragma unroll
-        for (int m = 0; m < PBD_FOLD_MAXMIX; ++m)
-          if (m < L) YZ[(m * nrows + j) * S + q].x = acc[m];
+      for (int u = 0; u < U; ++u) {
+        const bool valid = e0 + u * NT + lane < n;
+        fold_children<T, M>(J, biasw, off[u], HW, L, valid, acc[u]);
+        if (valid) {
+#pragma unroll
+          for (int m = 0; m < M; ++m)
+            if (m < L) YZ[(m * nrows + jj[u]) * S + qq[u]].x = acc[u][m];
+        }
       }
     }
   } else {
@@ -346,7 +359,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   DT_STAMP(5);
 }
 
-template <typename T, bool FOLD>
+template <typename T, int FM>
 __global__ __launch_bounds__(256, 4) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
                                                     const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -354,33 +367,39 @@ __global__ __launch_bounds__(256, 4) void k_dt_pass(const DtTask* __restrict__ t
   DT_TRACE(0);
   const DtTask t = tasks[blockIdx.x];
   const DtGroup& g = t.g;
-  if (g.stride <= 256) dt_block<T, unsigned char, FOLD>(smem, t, g, maps, folds, biasw);    // stack indices < 255 fit a byte
-  else dt_block<T, unsigned short, FOLD>(smem, t, g, maps, folds, biasw);
+  if (g.stride <= 256) dt_block<T, unsigned char, FM>(smem, t, g, maps, folds, biasw);    // stack indices < 255 fit a byte
+  else dt_block<T, unsigned short, FM>(smem, t, g, maps, folds, biasw);
   DT_TRACE(1);
 }
 
-template <typename T, bool FOLD>
+template <typename T, int FM>
 static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw,
                              size_t lds, int nt, hipStream_t s) {
   static LdsOptIn optin;   // one per instantiation, per-device state inside
-  optin.ensure((const void*)k_dt_pass<T, FOLD>, lds);
+  optin.ensure((const void*)k_dt_pass<T, FM>, lds);
 #ifdef PBD_PROBES
   static const bool tracing = getenv("PBD_DT_TRACE") != nullptr;
   if (tracing) { static int seqs[4096]; const int seq = g_dt_trace_seq++; seqs[seq & 4095] = seq; hipMemcpyToSymbolAsync(HIP_SYMBOL(pbd_dt_trace_launch), &seqs[seq & 4095], sizeof(int), 0, hipMemcpyHostToDevice, s); }
 #endif
-  hipLaunchKernelGGL((k_dt_pass<T, FOLD>), dim3(ntasks), dim3(nt), lds, s, tasks, maps, folds, biasw);
+  hipLaunchKernelGGL((k_dt_pass<T, FM>), dim3(ntasks), dim3(nt), lds, s, tasks, maps, folds, biasw);
 }
-// ts = sizeof(T): DistanceTransform<float> / DistanceTransform<double>; folds != nullptr: the tasks are fold blocks
+template <typename T>
+static void launch_dt_pass_m(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw,
+                             size_t lds, int nt, int fm, hipStream_t s) {
+  // fold launches are instantiated for the smallest register-array bound that holds the model's mixture counts
+  if (!folds) launch_dt_pass_t<T, 0>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+  else if (fm <= 1) launch_dt_pass_t<T, 1>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+  else if (fm <= 4) launch_dt_pass_t<T, 4>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+  else if (fm <= 6) launch_dt_pass_t<T, 6>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+  else launch_dt_pass_t<T, PBD_FOLD_MAXMIX>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+}
+// ts = sizeof(T): DistanceTransform<float> / DistanceTransform<double>; folds != nullptr: the tasks are fold blocks of a
+// model whose parts have at most fm mixtures
 void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw, size_t lds,
-                    int ts, int nt, hipStream_t s) {
+                    int ts, int nt, int fm, hipStream_t s) {
   if (ntasks <= 0) return;
-  if (folds) {
-    if (ts == 8) launch_dt_pass_t<double, true>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
-    else launch_dt_pass_t<float, true>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
-  } else {
-    if (ts == 8) launch_dt_pass_t<double, false>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
-    else launch_dt_pass_t<float, false>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
-  }
+  if (ts == 8) launch_dt_pass_m<double>(tasks, ntasks, maps, folds, biasw, lds, nt, fm, s);
+  else launch_dt_pass_m<float>(tasks, ntasks, maps, folds, biasw, lds, nt, fm, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -500,7 +519,7 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
     T acc[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[m] = ((GP(T))J.score[m < J.K ? m : J.K - 1])[cell];
-    fold_children<T>(folds + J.fold, biasw, cell, (size_t)J.H * J.W, J.K, true, acc);
+    fold_children<T, M>(folds + J.fold, biasw, cell, (size_t)J.H * J.W, J.K, true, acc);
     if (J.K == 1) {
       v = acc[0] + bias;
     } else {
@@ -560,7 +579,8 @@ __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count,
                                                   const int* __restrict__ flat, const int* __restrict__ depth, int max_depth,
                                                   int nflat, const unsigned long long* __restrict__ scr_base,
                                                   const int16_t* __restrict__ ixs, const int16_t* __restrict__ iys,
-                                                  int correct_ptr) {
+                                                  int correct_ptr, const int16_t* __restrict__ extx,
+                                                  const int16_t* __restrict__ exty, const unsigned long long* __restrict__ ext_base) {
   __shared__ int lx[BT_MAXP], ly[BT_MAXP], lm[BT_MAXP];
   const int idx = blockIdx.x, lane = threadIdx.x;
   const int n = min(*count, capacity);
@@ -588,10 +608,15 @@ __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count,
       const int px = lx[par], py = ly[par], pm = lm[par];
       const size_t off = (size_t)py * B.W + px;
       const int mm = B.pk[(size_t)(plane0[r.comp * max_parts + p] + pm) * HW + off];           // Ik
-      const size_t so = (size_t)scr_base[(size_t)r.level * nflat + flat[r.comp * max_parts + p]] + (size_t)mm * HW;
       int x, y;
-      if (!correct_ptr) { x = ixs[so + off]; y = iys[so + (size_t)py * B.W + x]; }
-      else { y = iys[so + off]; x = ixs[so + (size_t)y * B.W + px]; }
+      if (extx) {   // tables handed in by the caller (pbd_set_dp_pointers): Ix / Iy are stored composed, per (part, parent mixture)
+        const size_t eo = (size_t)ext_base[r.level * ncomp + r.comp] + (size_t)(plane0[r.comp * max_parts + p] + pm) * HW + off;
+        x = extx[eo]; y = exty[eo];
+      } else {
+        const size_t so = (size_t)scr_base[(size_t)r.level * nflat + flat[r.comp * max_parts + p]] + (size_t)mm * HW;
+        if (!correct_ptr) { x = ixs[so + off]; y = iys[so + (size_t)py * B.W + x]; }
+        else { y = iys[so + off]; x = ixs[so + (size_t)y * B.W + px]; }
+      }
       lx[p] = x; ly[p] = y; lm[p] = mm;
     }
     __syncthreads();
@@ -617,9 +642,9 @@ void launch_backtrack(const int* count, const CandRec* rec, int capacity, const 
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh, char* out,
                       size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,
                       const unsigned long long* scr_base, const int16_t* ix, const int16_t* iy, int correct_ptr,
-                      hipStream_t s) {
-  if (ts == 8) hipLaunchKernelGGL(k_backtrack<double>, dim3(capacity), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr);
-  else hipLaunchKernelGGL(k_backtrack<float>, dim3(capacity), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr);
+                      const int16_t* extx, const int16_t* exty, const unsigned long long* ext_base, hipStream_t s) {
+  if (ts == 8) hipLaunchKernelGGL(k_backtrack<double>, dim3(capacity), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base);
+  else hipLaunchKernelGGL(k_backtrack<float>, dim3(capacity), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base);
 }
 
 // ---------------------------------------------------------------------------

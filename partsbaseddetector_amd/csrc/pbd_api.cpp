@@ -38,8 +38,12 @@ static int fail(pbd_handle* h, int code, const std::string& msg) {
       return PBD_ERR_HIP;                                                                \
     }                                                                                    \
   } while (0)
+// hipGetLastError() is the calling THREAD's sticky last error: an unrelated HIP call of the caller that failed
+// earlier (or one of ours whose result was deliberately ignored) would be reported as this frame's launch failure.
+// Every entry point that launches clears it first, so LAUNCHCHK only ever sees the library's own launches.
+#define CLEAR_STICKY() ((void)hipGetLastError())
 // every ABI entry that launches or copies runs on the handle's device, whatever the caller's current device is
-#define ON_DEVICE(h) HIPCHK(h, hipSetDevice((h)->opt.device))
+#define ON_DEVICE(h) do { HIPCHK(h, hipSetDevice((h)->opt.device)); CLEAR_STICKY(); } while (0)
 
 // ---------------------------------------------------------------------------
 // pyramid geometry — HOGFeatures<T>::pyramid, src/HOGFeatures.cpp:98-127,174-175
@@ -181,10 +185,12 @@ static int ingest_model(pbd_handle* h, const pbd_model_desc* m) {
   // (no filter id shared inside a component: the reference's ncscores is indexed by FILTER id, so two parts with
   // one id would share an accumulator) and its mixtures / its children's to fit the register arrays of the fold
   h->fold = !aliasing && h->opt.reserved[1] != 1;
+  if (const char* e = PBD_PROBE_ENV("PBD_DP_MODE")) h->fold = h->fold && atoi(e) != 1;   // A/B: the three-kernel structure
   {
     std::vector<int> nchild_flat(np, 0);
     for (int fp = 0; fp < np; ++fp) {
       if (h->parts[fp].K > PBD_FOLD_MAXMIX) h->fold = false;
+      h->fold_mix = std::max(h->fold_mix, h->parts[fp].K);
       if (h->parts[fp].p > 0 && ++nchild_flat[h->part_offset[h->parts[fp].comp] + h->parts[fp].parent] > PBD_MAX_CH) h->fold = false;
     }
   }
@@ -301,6 +307,8 @@ static int upload_model(pbd_handle* h) {
   HIPCHK(h, hipMalloc(&h->d_cand_out, h->cand_stride * cap));
   HIPCHK(h, hipHostMalloc((void**)&h->h_cand_out, h->cand_stride * cap));
   HIPCHK(h, hipHostMalloc((void**)&h->h_cand_count, sizeof(int) * 4));
+  h->model_bytes = wT.size() * h->ts + bw.size() * sizeof(float) + (par.size() * 4 + npv.size()) * sizeof(int) + sizeof(int) +
+                   sizeof(CandRec) * cap + h->cand_stride * cap;
   return PBD_OK;
 }
 
@@ -313,6 +321,7 @@ static int dev_alloc(pbd_handle* h, T** p, size_t n) {
   hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
   if (e != hipSuccess) { h->err = std::string("hipMalloc: ") + hipGetErrorString(e); return PBD_ERR_HIP; }
   h->frame_allocs.push_back(q);
+  h->frame_bytes += std::max<size_t>(n, 1) * sizeof(T);
   *p = (T*)q;
   return PBD_OK;
 }
@@ -329,6 +338,8 @@ static void free_frame(pbd_handle* h) {
   h->frames_on_plan = 0;
   for (void* p : h->frame_allocs) hipFree(p);
   h->frame_allocs.clear();
+  h->frame_bytes = 0;
+  h->d_extx = h->d_exty = nullptr; h->d_ext_base = nullptr; h->ext_ptr = false;
   h->fw = h->fh = h->fcn = 0;
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
 }
@@ -487,7 +498,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   // parts) would leave LDS — and lanes — idle at the full budget, while every launch lasts as long as its blocks'
   // segments are: its blocks get proportionally FEWER lines (about the same number of blocks as the fullest launch),
   // i.e. more lanes per line and shorter segments.
-  bool thin = true;
+  bool thin = false;
   size_t thin_min = 10 * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_THIN")) thin = atoi(e) != 0;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_THIN_MIN_KB")) thin_min = (size_t)atoi(e) * 1024;
@@ -759,8 +770,8 @@ static int run_dp_min(pbd_handle* h) {
   // messages) + y pass per round, the root's messages folded by k_root: 2 * rounds + 1 launches; legacy (models that
   // alias a filter id inside a component, or more than 8 mixtures): + the round's reduce launches.
   for (auto& R : h->rl) {
-    launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, R.fold_x ? h->d_foldjobs : nullptr, h->d_biasw, R.lds_x, h->ts, h->dt_nt, h->stream);
-    launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, nullptr, h->d_biasw, R.lds_y, h->ts, h->dt_nt, h->stream);
+    launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, R.fold_x ? h->d_foldjobs : nullptr, h->d_biasw, R.lds_x, h->ts, h->dt_nt, h->fold_mix, h->stream);
+    launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, nullptr, h->d_biasw, R.lds_y, h->ts, h->dt_nt, 0, h->stream);
     for (auto& Wv : R.waves)
       launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
   }
@@ -771,6 +782,7 @@ static int run_dp_min(pbd_handle* h) {
   h->dp_timed = dpt;
   LAUNCHCHK(h, "DP min");
   h->have_dp = true;
+  h->ext_ptr = false;   // back-tracking reads this min()'s own tables again
   return PBD_OK;
 }
 
@@ -780,7 +792,7 @@ static int run_argmin_enqueue(pbd_handle* h) {
   launch_backtrack(h->d_cand_count, h->d_cand_rec, h->opt.max_candidates, h->d_back, h->md.ncomponents, h->d_parent,
                    h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, h->d_cand_out, h->cand_stride, h->ts, h->d_flat,
                    h->d_depth, h->max_depth, (int)h->parts.size(), h->d_scr_base, h->d_dt_ixT, h->d_dt_iy,
-                   h->opt.dt_correct_ptr, h->stream);
+                   h->opt.dt_correct_ptr, h->ext_ptr ? h->d_extx : nullptr, h->d_exty, h->d_ext_base, h->stream);
   LAUNCHCHK(h, "argmin");
   const int first = std::min(kFirstCopy, h->opt.max_candidates);
   if (h->d_gsend) {   // member of an RCCL-gathering pbd_group: pack {count, first records} for the all-gather instead of the D2H
@@ -908,6 +920,7 @@ static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
   HIPCHK(h, hipGraphLaunch(h->gexec, h->stream));
   h->frames_on_plan++;
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = true;
+  h->ext_ptr = false;
   h->dp_timed = false;
   h->pending = true;
   return PBD_OK;
@@ -1006,7 +1019,7 @@ int pbd_detect_enqueue_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, i
   if (!h || !d_im) return PBD_ERR_ARG;
   if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
   if (stride < w * cn) return fail(h, PBD_ERR_ARG, "stride < w*cn");
-  HIPCHK(h, hipSetDevice(h->opt.device));
+  ON_DEVICE(h);
   int rc = plan_frame(h, w, hgt, cn);
   if (rc) return rc;
   return enqueue_all(h, (const uint8_t*)d_im, stride);
@@ -1031,7 +1044,7 @@ static int upload_image(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn
 extern "C++" int pbd_i_upload_image(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride) { return upload_image(h, im, w, hgt, cn, stride); }
 static int upload_image(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride) {
   if (stride < w * cn) return fail(h, PBD_ERR_ARG, "stride < w*cn");
-  HIPCHK(h, hipSetDevice(h->opt.device));
+  ON_DEVICE(h);
   int rc = plan_frame(h, w, hgt, cn);
   if (rc) return rc;
   // tightly packed rows: one linear copy (a DMA-engine transfer when `im` is pinned); strided rows: a 2-D copy
@@ -1075,7 +1088,7 @@ int pbd_pyramid_geometry(const pbd_handle* h, int w, int hgt, int* nlevels, int3
 
 int pbd_begin_frame(pbd_handle* h, int w, int hgt, int cn) {
   if (!h) return PBD_ERR_ARG;
-  HIPCHK(h, hipSetDevice(h->opt.device));
+  ON_DEVICE(h);
   int rc = plan_frame(h, w, hgt, cn);
   if (rc) return rc;
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
@@ -1235,6 +1248,94 @@ static int get_root_(pbd_handle* h, int level, int component, void* rootv, int32
 }
 int pbd_get_root(pbd_handle* h, int level, int component, float* rootv, int32_t* rooti) { return get_root_(h, level, component, rootv, rooti, 4); }
 int pbd_get_root_f64(pbd_handle* h, int level, int component, double* rootv, int32_t* rooti) { return get_root_(h, level, component, rootv, rooti, 8); }
+// DynamicProgram<T>::argmin takes rootv / rooti / Ix / Iy / Ik as ARGUMENTS (include/DynamicProgram.hpp:75): a caller
+// that hands it tables other than the ones this handle's min() left on the device injects them here.
+static int set_root_(pbd_handle* h, int level, int component, const void* rootv, const int32_t* rooti, int ts) {
+  CHECK_LEVEL(h, level);
+  CHECK_SCALAR(h, ts);
+  if (component < 0 || component >= h->md.ncomponents) return fail(h, PBD_ERR_ARG, "component out of range");
+  const Level& L = h->lv[level];
+  if (!L.active) return fail(h, PBD_ERR_STATE, "level is not processed by this handle (pbd_set_levels / level_begin..level_end)");
+  const size_t HW = (size_t)L.cw * L.ch;
+  ON_DEVICE(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (rootv) HIPCHK(h, hipMemcpy(h->d_rootv + (L.cell_off * h->md.ncomponents + component * HW) * ts, rootv, HW * ts, hipMemcpyHostToDevice));
+  if (rooti) HIPCHK(h, hipMemcpy(h->d_rooti + L.cell_off * h->md.ncomponents + component * HW, rooti, HW * 4, hipMemcpyHostToDevice));
+  return PBD_OK;
+}
+int pbd_set_root(pbd_handle* h, int level, int component, const float* rootv, const int32_t* rooti) { return set_root_(h, level, component, rootv, rooti, 4); }
+int pbd_set_root_f64(pbd_handle* h, int level, int component, const double* rootv, const int32_t* rooti) { return set_root_(h, level, component, rootv, rooti, 8); }
+int pbd_set_dp_pointers(pbd_handle* h, int level, int component, int part, int parent_mix, const int32_t* ix, const int32_t* iy, const int32_t* ik) {
+  CHECK_LEVEL(h, level);
+  if (!ix || !iy || !ik) return fail(h, PBD_ERR_ARG, "null table");
+  if (component < 0 || component >= h->md.ncomponents) return fail(h, PBD_ERR_ARG, "component out of range");
+  const int p0 = h->part_offset[component], cnp = h->part_offset[component + 1] - p0;
+  if (part < 1 || part >= cnp) return fail(h, PBD_ERR_ARG, "part out of range (1..nparts-1)");
+  const PartInfo& P = h->parts[p0 + part];
+  if (parent_mix < 0 || parent_mix >= h->parts[p0 + P.parent].K) return fail(h, PBD_ERR_ARG, "parent mixture out of range");
+  const Level& L = h->lv[level];
+  if (!L.active) return fail(h, PBD_ERR_STATE, "level is not processed by this handle");
+  const size_t HW = (size_t)L.cw * L.ch;
+  ON_DEVICE(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!h->d_extx) {   // first use on this frame plan: composed planes for every (level, plane), 2 x int16
+    const size_t n = h->cells * (size_t)std::max(h->nplanes, 1);
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_extx, n))) return rc;
+    if ((rc = dev_alloc(h, &h->d_exty, n))) return rc;
+    std::vector<unsigned long long> base((size_t)h->nlevels * h->md.ncomponents);
+    for (int l = 0; l < h->nlevels; ++l)
+      for (int c = 0; c < h->md.ncomponents; ++c)
+        base[(size_t)l * h->md.ncomponents + c] = h->lv[l].cell_off * h->nplanes + (size_t)h->comp_plane0[c] * h->lv[l].cw * h->lv[l].ch;
+    if ((rc = dev_upload(h, &h->d_ext_base, base))) return rc;
+  }
+  if (!h->ext_ptr && h->have_dp) {
+    // the planes the caller does NOT hand in keep this handle's own tables: materialise all of them once, composed
+    // (costly, but this is the compatibility path of a mixed-engine caller, not detect())
+    std::vector<int32_t> x, y, k;
+    std::vector<int16_t> xs, ys;
+    for (int l = 0; l < h->nlevels; ++l) {
+      const Level& LL = h->lv[l];
+      const size_t hw = (size_t)LL.cw * LL.ch;
+      if (!LL.active || hw == 0) continue;
+      x.resize(hw); y.resize(hw); k.resize(hw); xs.resize(hw); ys.resize(hw);
+      for (int c = 0; c < h->md.ncomponents; ++c) {
+        const int q0 = h->part_offset[c], qn = h->part_offset[c + 1] - q0;
+        for (int pp = 1; pp < qn; ++pp)
+          for (int m2 = 0; m2 < h->parts[q0 + h->parts[q0 + pp].parent].K; ++m2) {
+            int rc = pbd_get_dp_pointers(h, l, c, pp, m2, x.data(), y.data(), k.data());
+            if (rc) return rc;
+            for (size_t i = 0; i < hw; ++i) { xs[i] = (int16_t)x[i]; ys[i] = (int16_t)y[i]; }
+            const size_t eo = LL.cell_off * h->nplanes + (size_t)(h->parts[q0 + pp].plane0 + m2) * hw;
+            HIPCHK(h, hipMemcpy(h->d_extx + eo, xs.data(), hw * 2, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(h->d_exty + eo, ys.data(), hw * 2, hipMemcpyHostToDevice));
+          }
+      }
+    }
+  }
+  std::vector<int16_t> xs(HW), ys(HW);
+  std::vector<uint8_t> ks(HW);
+  for (size_t i = 0; i < HW; ++i) {
+    if (ix[i] < 0 || ix[i] >= L.cw || iy[i] < 0 || iy[i] >= L.ch || ik[i] < 0 || ik[i] >= P.K)
+      return fail(h, PBD_ERR_ARG, "pointer table entry out of range");
+    xs[i] = (int16_t)ix[i]; ys[i] = (int16_t)iy[i]; ks[i] = (uint8_t)ik[i];
+  }
+  const size_t eo = L.cell_off * h->nplanes + (size_t)(P.plane0 + parent_mix) * HW;
+  HIPCHK(h, hipMemcpy(h->d_extx + eo, xs.data(), HW * 2, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_exty + eo, ys.data(), HW * 2, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_pk + eo, ks.data(), HW, hipMemcpyHostToDevice));
+  h->ext_ptr = true;
+  h->have_dp = true;
+  return PBD_OK;
+}
+int pbd_get_footprint(const pbd_handle* h, size_t* frame_bytes, size_t* model_bytes) {
+  if (!h) return PBD_ERR_ARG;
+  if (frame_bytes) *frame_bytes = h->frame_bytes;
+  if (model_bytes) *model_bytes = h->model_bytes;
+  return PBD_OK;
+}
+int pbd_abi_version(void) { return PBD_ABI_VERSION; }
+
 int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
   if (!h) return PBD_ERR_ARG;
   if (!h->have_dp) return fail(h, PBD_ERR_STATE, "argmin() before min()");
@@ -1250,7 +1351,7 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   if (!h || !in || rows <= 0 || cols <= 0 || rows > 32767 || cols > 32767) return PBD_ERR_ARG;
   CHECK_SCALAR(h, tsz);
   if (ax == 0 || ay == 0) return fail(h, PBD_ERR_ARG, "a must be non-zero");
-  HIPCHK(h, hipSetDevice(h->opt.device));
+  ON_DEVICE(h);
   const size_t HW = (size_t)rows * cols;
   const size_t ts = (size_t)tsz;
   char *d_in, *d_tmp, *d_sdt;
@@ -1278,9 +1379,9 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
-  launch_dt_pass(d_tasks, nx, d_maps, nullptr, h->d_biasw, budget, tsz, h->dt_nt, h->stream);
+  launch_dt_pass(d_tasks, nx, d_maps, nullptr, h->d_biasw, budget, tsz, h->dt_nt, 0, h->stream);
   if (PBD_PROBE_ENV("PBD_DEBUG_SKIP_Y")) { hipMemsetAsync(d_sdt, 0, HW * ts, h->stream); hipMemsetAsync(d_iy, 0, HW * 2, h->stream); }   // probe build: leave the x pass as the last DT launch (its stamps are then readable)
-  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_maps, nullptr, h->d_biasw, budget, tsz, h->dt_nt, h->stream);
+  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_maps, nullptr, h->d_biasw, budget, tsz, h->dt_nt, 0, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_sdt, HW * ts, hipMemcpyDeviceToHost, h->stream));   // the y pass's scores, untouched
   HIPCHK(h, hipMemcpyAsync(hx.data(), d_ixT, HW * 2, hipMemcpyDeviceToHost, h->stream));   // the passes' own pointers
@@ -1310,7 +1411,7 @@ int pbd_dt2d_f64(pbd_handle* h, const double* in, int rows, int cols, double ax,
 static int hog_u8_(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, void* out, int* cell_w, int* cell_h, int ts) {
   if (!h || !im || w < 3 || hgt < 3 || (cn != 1 && cn != 3) || stride < w * cn) return PBD_ERR_ARG;
   CHECK_SCALAR(h, ts);
-  HIPCHK(h, hipSetDevice(h->opt.device));
+  ON_DEVICE(h);
   const int sbin = h->md.sbin;
   LevelDev L{};
   L.iw = w; L.ih = hgt;
@@ -1344,7 +1445,7 @@ int pbd_hog_u8_f64(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
 
 int pbd_resize_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, uint8_t* out, int ow, int oh) {
   if (!h || !im || !out || w <= 0 || hgt <= 0 || ow <= 0 || oh <= 0 || (cn != 1 && cn != 3) || stride < w * cn) return PBD_ERR_ARG;
-  HIPCHK(h, hipSetDevice(h->opt.device));
+  ON_DEVICE(h);
   uint8_t *d_im, *d_out;
   HIPCHK(h, hipMalloc(&d_im, (size_t)w * hgt * cn)); HIPCHK(h, hipMalloc(&d_out, (size_t)ow * oh * cn));
   HIPCHK(h, hipMemcpy2D(d_im, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
@@ -1359,7 +1460,7 @@ int pbd_resize_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int 
 
 int pbd_pyrdown_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, uint8_t* out) {
   if (!h || !im || !out || w <= 0 || hgt <= 0 || (cn != 1 && cn != 3) || stride < w * cn) return PBD_ERR_ARG;
-  HIPCHK(h, hipSetDevice(h->opt.device));
+  ON_DEVICE(h);
   const size_t sb = (size_t)w * hgt * cn, db = (size_t)((w + 1) / 2) * ((hgt + 1) / 2) * cn;
   uint8_t* d_buf;
   HIPCHK(h, hipMalloc(&d_buf, sb + db));
@@ -1375,7 +1476,7 @@ int pbd_pyrdown_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
 
 int pbd_nms_map(pbd_handle* h, const float* src, int rows, int cols, int sz, uint8_t* dst) {
   if (!h || !src || !dst || rows <= 0 || cols <= 0 || sz < 0) return PBD_ERR_ARG;
-  HIPCHK(h, hipSetDevice(h->opt.device));
+  ON_DEVICE(h);
   float* d_src; uint8_t* d_dst;
   const size_t n = (size_t)rows * cols;
   HIPCHK(h, hipMalloc(&d_src, n * 4)); HIPCHK(h, hipMalloc(&d_dst, n));

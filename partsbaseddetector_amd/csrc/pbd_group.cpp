@@ -129,6 +129,25 @@ static const char* rec_ptr(const pbd_group* g, int i, int j) {
   return h->h_cand_out + h->cand_stride * j;   // host mode, or the remainder pbd_i_finish_frame fetched
 }
 
+// An error in the middle of a batch or a gather (a member over its candidate capacity, a failed enqueue, an RCCL
+// error) must not leave the OTHER members with a frame in flight: they would answer every later call with "previous
+// frame not collected", and in RCCL mode a member cannot be collected on its own.  Every failing group call ends
+// here: wait for whatever the members still have enqueued and drop it; the first error stays in g->err.
+static void drain(pbd_group* g) {
+  for (size_t i = 0; i < g->m.size(); ++i) {
+    pbd_handle* h = g->m[i];
+    if (!h->pending) continue;
+    hipSetDevice(g->dev[i]);
+    hipStreamSynchronize(h->stream);
+    h->pending = false;
+  }
+  (void)hipGetLastError();
+}
+static int batch_impl(pbd_group* g, const uint8_t* const* ims, int nframes, int w, int hgt, int cn, int stride,
+                      pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* counts);
+static int frame_impl(pbd_group* g, const uint8_t* im, int w, int hgt, int cn, int stride, pbd_candidate_head* heads,
+                      int32_t* boxes, int32_t* locs, int capacity, int* count);
+
 #pragma GCC visibility push(default)
 extern "C" {
 
@@ -227,6 +246,24 @@ static int all_levels(pbd_group* g) {   // undo a level sharding left behind by 
 int pbd_group_detect_batch_u8(pbd_group* g, const uint8_t* const* ims, int nframes, int w, int hgt, int cn, int stride,
                               pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* counts) {
   if (!g || !ims || nframes < 0 || !heads || !counts || capacity < 0) return PBD_ERR_ARG;
+  const int rc = batch_impl(g, ims, nframes, w, hgt, cn, stride, heads, boxes, locs, capacity, counts);
+  if (rc != PBD_OK) drain(g);
+  return rc;
+}
+
+int pbd_group_detect_u8(pbd_group* g, const uint8_t* im, int w, int hgt, int cn, int stride, pbd_candidate_head* heads,
+                        int32_t* boxes, int32_t* locs, int capacity, int* count) {
+  if (!g || !im || !heads || capacity < 0) return PBD_ERR_ARG;
+  const int rc = frame_impl(g, im, w, hgt, cn, stride, heads, boxes, locs, capacity, count);
+  if (rc != PBD_OK) drain(g);
+  return rc;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop
+
+static int batch_impl(pbd_group* g, const uint8_t* const* ims, int nframes, int w, int hgt, int cn, int stride,
+                      pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* counts) {
   const int n = (int)g->m.size();
   int rc = all_levels(g);
   if (rc) return rc;
@@ -283,9 +320,8 @@ int pbd_group_detect_batch_u8(pbd_group* g, const uint8_t* const* ims, int nfram
   return status;
 }
 
-int pbd_group_detect_u8(pbd_group* g, const uint8_t* im, int w, int hgt, int cn, int stride, pbd_candidate_head* heads,
-                        int32_t* boxes, int32_t* locs, int capacity, int* count) {
-  if (!g || !im || !heads || capacity < 0) return PBD_ERR_ARG;
+static int frame_impl(pbd_group* g, const uint8_t* im, int w, int hgt, int cn, int stride, pbd_candidate_head* heads,
+                      int32_t* boxes, int32_t* locs, int capacity, int* count) {
   const int n = (int)g->m.size();
   int rc;
   if (g->shard_w != w || g->shard_h != hgt || g->shard_cn != cn) {
@@ -331,6 +367,3 @@ int pbd_group_detect_u8(pbd_group* g, const uint8_t* im, int w, int hgt, int cn,
   if (rc) return gfail(g, rc, pbd_last_error(g->m[0]));
   return PBD_OK;
 }
-
-}  // extern "C"
-#pragma GCC visibility pop

@@ -179,6 +179,7 @@ struct pbd_handle {
   size_t dt_lds = 0;                                 // LDS budget of a k_dt_pass block in the fullest launch of a frame (thinner launches get less)
   bool fold = false;                                 // DP structure of this handle: messages folded by the parent's x pass (no k_reduce, no acc planes)
   FoldJob* d_foldjobs = nullptr;
+  int fold_mix = 0;                                  // largest mixture count of a part (the fold kernels' register-array bound)
   int dt_nt = PBD_DT_NT_DEFAULT;                                   // lanes of a k_dt_pass block (64 or 128)
   int dt_seg = 0;                                    // target segment length of the DT scans (0: as many lines per block as fit)
   int xcd_chunk = 16;                                // consecutive k_dt_pass tasks kept on one XCD (0: table order)
@@ -201,6 +202,12 @@ struct pbd_handle {
   hipGraphExec_t gexec = nullptr;   // pbd_options.graph: the frame's launches, captured once per geometry
   int frames_on_plan = 0;           // frames enqueued since the last plan_frame
   std::vector<void*> frame_allocs;  // everything freed on re-plan
+  size_t frame_bytes = 0, model_bytes = 0;   // device memory held for the frame plan / the model (pbd_get_footprint)
+  // pointer tables handed in by the caller (pbd_set_dp_pointers: a DynamicProgram::argmin fed tables that this handle's
+  // min() did not produce): composed Ix / Iy per (level, component, plane), allocated on first use; back-tracking
+  // reads them instead of the DT planes until the next min()
+  int16_t* d_extx = nullptr; int16_t* d_exty = nullptr; unsigned long long* d_ext_base = nullptr;
+  bool ext_ptr = false;
 };
 
 // ---- scalar helpers: the reference's std:: overloads resolve on T ---------------
@@ -268,7 +275,7 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                             const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s);
 void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw, size_t lds,
-                    int ts, int nt, hipStream_t s);
+                    int ts, int nt, int fm, hipStream_t s);
 size_t dt_lds_bytes(int stride, int lpb, int ts, int nt);
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
                    int ts, hipStream_t s);
@@ -278,7 +285,7 @@ void launch_backtrack(const int* count, const CandRec* rec, int capacity, const 
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
                       char* out, size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,
                       const unsigned long long* scr_base, const int16_t* ix, const int16_t* iy, int correct_ptr,
-                      hipStream_t s);
+                      const int16_t* extx, const int16_t* exty, const unsigned long long* ext_base, hipStream_t s);
 void dt_debug_read(unsigned long long* out);
 int dt_debug_trace(unsigned long long* t, unsigned* hw, int* nlaunch);   // probe build only
 void hog_debug_read(unsigned long long* out);

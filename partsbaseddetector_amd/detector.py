@@ -179,9 +179,21 @@ class DynamicProgram:
             Ix.append(lx); Iy.append(ly); Ik.append(lk); rootv.append(rv); rooti.append(ri)
         return Ix, Iy, Ik, rootv, rooti
 
-    def argmin(self, capacity=4096) -> List[Candidate]:
-        """argmin(...): walks the resident pointer tables."""
-        return Candidate._unpack(*self._h.dp_argmin(capacity))
+    def argmin(self, rootv=None, rooti=None, Ix=None, Iy=None, Ik=None, capacity=4096) -> List[Candidate]:
+        """argmin(parts, rootv, rooti, scales, Ix, Iy, Ik, candidates).  With no arguments it walks the tables min() left
+        on the device; tables passed in (another engine's, or edited ones) are uploaded first and honoured."""
+        h, g, m = self._h, self._h._geo, self._h.model
+        if rootv is not None:
+            for l in range(g["nlevels"]):
+                for c in range(m.ncomponents):
+                    h.set_root(l, c, rootv[l][c], rooti[l][c])
+        if Ix is not None:
+            for l in range(g["nlevels"]):
+                for c in range(m.ncomponents):
+                    for p in range(1, m.nparts(c)):
+                        for pm in range(len(Ix[l][c][p])):
+                            h.set_dp_pointers(l, c, p, pm, Ix[l][c][p][pm], Iy[l][c][p][pm], Ik[l][c][p][pm])
+        return Candidate._unpack(*h.dp_argmin(capacity))
 
 
 class PartsBasedDetector:

@@ -92,10 +92,12 @@ def unpack_candidates(buf: np.ndarray, max_parts: int):
     return heads, boxes, locs
 
 
-def gather_candidates(cands, max_parts: int, capacity: int = 4096, device=None):
-    """all_gather of every rank's candidates; returns a list (one entry per rank) of
-    (heads, boxes, locs).  Works with any initialised torch.distributed backend.  `capacity` (records per rank in
-    the fixed-size exchange buffer) defaults to the handles' default max_candidates; a rank holding more raises."""
+def gather_candidates(cands, max_parts: int, capacity: int = 4096, device=None, dst=None):
+    """Gather of every rank's candidates; returns a list (one entry per rank) of (heads, boxes, locs).
+    dst=None: all_gather (every rank gets the list); dst=r: gather to rank r only (the others return None) — what a
+    detector host needs, and 1/world of the traffic.  Works with any initialised torch.distributed backend.
+    `capacity` (records per rank in the fixed-size exchange buffer) defaults to the handles' default
+    max_candidates; a rank holding more raises."""
     import torch
     import torch.distributed as dist
 
@@ -103,9 +105,17 @@ def gather_candidates(cands, max_parts: int, capacity: int = 4096, device=None):
     if device is not None:
         buf = buf.to(device)
     world = dist.get_world_size()
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf)
-    return [unpack_candidates(o.cpu().numpy(), max_parts) for o in outs]
+    # one contiguous receive buffer (the per-rank blocks are views of it): ONE device-to-host copy afterwards
+    big = torch.empty(world * buf.numel(), dtype=buf.dtype, device=buf.device) if (dst is None or dist.get_rank() == dst) else None
+    outs = list(big.chunk(world)) if big is not None else None
+    if dst is None:
+        dist.all_gather(outs, buf)
+    else:
+        dist.gather(buf, outs, dst=dst)
+        if outs is None:
+            return None
+    host = big.cpu().numpy().reshape(world, -1)
+    return [unpack_candidates(host[r], max_parts) for r in range(world)]
 
 
 def merge_candidates(per_rank):

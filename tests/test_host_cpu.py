@@ -181,6 +181,13 @@ if rank == 0:
     for a, b in zip(allc, ref):
         assert np.array_equal(a, b)
     print("GATHER_OK", len(allc[0]))
+# gather to rank 0 only (what bench.py does every step inside the timed region)
+g0 = parallel.gather_candidates(merged_local, 3, capacity=2048, dst=0)
+assert (g0 is None) == (rank != 0)
+if rank == 0:
+    for a, b in zip(parallel.merge_candidates(g0), allc):
+        assert np.array_equal(a, b)
+    print("GATHER_DST_OK")
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -195,7 +202,17 @@ def test_gloo_world2_frame_sharding_and_gather(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "GATHER_OK" in out.stdout
+    assert "GATHER_OK" in out.stdout and "GATHER_DST_OK" in out.stdout
+
+
+def test_bench_respawns_itself_for_n_ranks():
+    """`python bench.py --gpus N` outside torchrun launches its own N ranks on 127.0.0.1 with the same arguments."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.respawn_command(["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
 
 
 def test_bench_line_schema_fields():
