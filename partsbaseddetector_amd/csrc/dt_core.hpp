@@ -224,32 +224,29 @@ DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const doub
   return bad || suspect != 0;
 }
 
-// Validation of the speculative stitches of one line, left to right (one lane per line): stitch p is kept iff
-// every element it tested below its segment lies strictly above F[p-1], the final lowest survivor of the
-// segment to its left (boundary 1 is always valid: segment 0's local scan IS the global run).  Otherwise it is
-// redone now, with everything to its left final — and so is EVERY stitch to its right: a redone stitch p moves
-// F[p] and un-patches / re-patches z and the link of the old and the new F[p], which the speculative stitch p + 1
-// (possibly running in another wavefront at the time) may have read in either state without going below the NEW
-// F[p]; comparing DMIN[p + 1] with the new F[p] alone would not see that.  Lines that come here are rare (a few
-// per thousand), so redoing the tail costs nothing.  F / DMIN / ZSAVE / BSAVE: per-segment tables (stride tstride).
+// Validation of the speculative stitches of one line, left to right (one lane per line).  The only elements whose
+// (z, link) ever change after the local scans are the F of each segment: patched by its speculative stitch, and —
+// if that stitch is redone here — un-patched again and a (possibly different) F patched instead.  A speculative
+// stitch p read elements >= DMIN[p] only, so what it read was final iff DMIN[p] lies strictly above BOTH the F its
+// left neighbour's speculative stitch patched (F_spec[p-1]: the patch may have been written, by another wavefront,
+// while p was reading) and the F the neighbour finally has (F_new[p-1]); the F of segments further left are lower
+// still.  Otherwise p is redone now, with everything to its left final (boundary 1 is always valid: segment 0's
+// local scan IS the global run).  F / DMIN / ZSAVE / BSAVE: per-segment tables (stride tstride).
 template <bool EXACT, typename T, typename IT>
 DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a,
                               const int* __restrict__ seg, int P, double a, double b, IT* __restrict__ F,
                               const IT* __restrict__ DMIN, const T* __restrict__ ZSAVE, const IT* __restrict__ BSAVE, int tstride) {
-  bool bad = false, redo = false;
+  bool bad = false;
   F[0] = (IT)0;
-  // undo every speculative patch from the first failed check on (right to left: a patch only touches its own F),
-  // then stitch those boundaries again in order
-  int p0 = P;
-  for (int p = 2; p < P; ++p)
-    if ((int)DMIN[p * tstride] <= (int)F[(p - 1) * tstride]) { p0 = p; break; }
-  for (int p = P - 1; p >= p0; --p) {
+  int fspec_prev = P > 1 ? (int)F[tstride] : 0;     // F_spec[p - 1]
+  for (int p = 2; p < P; ++p) {
+    const int fnew_prev = (int)F[(p - 1) * tstride];
     const int fo = (int)F[p * tstride];
-    YZ[fo].y = ZSAVE[p * tstride];
+    const int lim = fspec_prev > fnew_prev ? fspec_prev : fnew_prev;
+    fspec_prev = fo;
+    if ((int)DMIN[p * tstride] > lim) continue;
+    YZ[fo].y = ZSAVE[p * tstride];           // undo the speculative patch, then stitch again
     B[fo] = BSAVE[p * tstride];
-    redo = true;
-  }
-  for (int p = p0; p < P && redo; ++p) {
     int f, dmin, bs;
     T zs;
     bad |= dt_stitch1<EXACT, T, IT>(YZ, B, RDX, i2a, seg[p], seg[p + 1], a, b, f, dmin, zs, bs);

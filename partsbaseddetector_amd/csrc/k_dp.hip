@@ -88,45 +88,60 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // reduction), so the fold is done by the consumer: acc[m] enters with the parent's raw response at the cell and
 // leaves as ((raw + msg_c1) + msg_c2) ... — the same float operations in the same order — and the accumulated
 // planes are never stored.  The K child values of a cell are loaded once for all L parent mixtures.
-// M = upper bound of the mixture counts involved (register arrays; a launch is instantiated for the bound of its model)
-template <typename T, int M>
-__device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ biasw, size_t off,
-                                              size_t HW, int L, bool valid, T (&acc)[M]) {
+// M = upper bound of the mixture counts involved (register arrays; a launch is instantiated for the bound of its model).
+// U cells per lane at once: all child loads of the U cells are issued before the first use, and the K x L bias
+// block of the child (wave-uniform: scalar loads) is fetched in one straight-line batch — a load inside a (uniform)
+// branch costs one full scalar-memory round trip per branch, which is what made a first version's loader 5x slower
+// than the plain one.  Everything below is branch-free except the loop over the children.
+template <typename T, int M, int U>
+__device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ biasw, const size_t (&off)[U],
+                                              size_t HW, int L, const bool (&valid)[U], T (&acc)[U][M]) {
   const int nch = J->nch;
   for (int c = 0; c < nch; ++c) {
     const FoldChild& C = J->ch[c];
     const int K = C.K;
-    T sd[M];
+    T sd[U][M];
 #pragma unroll
-    for (int k = 0; k < M; ++k) sd[k] = ((GP(T))C.sdt[k < K ? k : K - 1])[off];   // clamped, never predicated: all K loads in flight
-    T v[M];
-    int bi[M];
-    if (K == 1) {   // Math::reduceMax K == 1 shortcut: copy (Math.hpp:154-158)
-      const int bo = C.bias_off[0];
+    for (int k = 0; k < M; ++k) {
+      GP(T) pl = (GP(T))C.sdt[k];                      // entries beyond K repeat plane K - 1 (plan): never predicated
 #pragma unroll
-      for (int m = 0; m < M; ++m) { bi[m] = 0; v[m] = (m < L) ? sd[0] + biasw[bo + m] : (T)0; }
-    } else {
+      for (int u = 0; u < U; ++u) sd[u][k] = pl[off[u]];
+    }
+    float bias[M][M];
 #pragma unroll
-      for (int m = 0; m < M; ++m) { bi[m] = 0; v[m] = -INFINITY; }
+    for (int k = 0; k < M; ++k) {
+      const int bo = C.bias_off[k < K ? k : K - 1];
 #pragma unroll
-      for (int k = 0; k < M; ++k) {
-        if (k < K) {
-          const int bo = C.bias_off[k];
-#pragma unroll
-          for (int m = 0; m < M; ++m) {
-            if (m < L) {
-              const T wv = sd[k] + biasw[bo + m];             // DynamicProgram.cpp:139
-              if (wv > v[m]) { bi[m] = k; v[m] = wv; }          // strict >: first max wins
-            }
-          }
-        }
-      }
+      for (int m = 0; m < M; ++m) bias[k][m] = biasw[bo + (m < L ? m : L - 1)];
     }
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      if (m < L) {
-        if (valid) ((GPW(uint8_t))C.ok)[(size_t)m * HW + off] = (uint8_t)bi[m];   // Ik (:150)
-        acc[m] = acc[m] + v[m];                                                  // parent.score += maxv (:156), child order kept
+    for (int u = 0; u < U; ++u) {
+      T v[M];
+      int bi[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        // k = 0 first: Math::reduceMax starts from -inf and takes strict > (first maximum wins); its K == 1 shortcut
+        // copies (Math.hpp:154-158), which differs from the loop only for a NaN / -inf score: keep the copy
+        const T w0 = sd[u][0] + bias[0][m];               // DynamicProgram.cpp:139
+        v[m] = (K == 1 || w0 > (T)-INFINITY) ? w0 : (T)-INFINITY;
+        bi[m] = 0;
+      }
+#pragma unroll
+      for (int k = 1; k < M; ++k) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const T wv = sd[u][k] + bias[k][m];
+          const bool take = (k < K) && (wv > v[m]);     // strict >: first max wins
+          bi[m] = take ? k : bi[m];
+          v[m] = take ? wv : v[m];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if (m < L) {
+          if (valid[u]) ((GPW(uint8_t))C.ok)[(size_t)m * HW + off[u]] = (uint8_t)bi[m];   // Ik (:150)
+          acc[u][m] = acc[u][m] + v[m];                                                  // parent.score += maxv (:156), child order kept
+        }
       }
     }
   }
@@ -183,7 +198,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     // ---- fold loader: U (row, element) cells per lane and step, all mixtures of the part at once; the loads of the U
     // cells are issued back to back (one memory round trip per step, like the plain loader's batches) ----
     constexpr int M = FM > 0 ? FM : 1;
-    constexpr int U = sizeof(T) == 8 ? 2 : 3;
+    constexpr int U = sizeof(T) == 8 ? 1 : 3;
     const FoldJob* J = folds + g.fold;
     const int L = g.nmaps;
     const size_t HW = (size_t)g.nlines * len;
@@ -208,11 +223,13 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         if (e0 == 0)
           for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
+      bool valid[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) valid[u] = e0 + u * NT + lane < n;
+      fold_children<T, M, U>(J, biasw, off, HW, L, valid, acc);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool valid = e0 + u * NT + lane < n;
-        fold_children<T, M>(J, biasw, off[u], HW, L, valid, acc[u]);
-        if (valid) {
+        if (valid[u]) {
 #pragma unroll
           for (int m = 0; m < M; ++m)
             if (m < L) YZ[(m * nrows + jj[u]) * S + qq[u]].x = acc[u][m];
@@ -220,36 +237,32 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       }
     }
   } else {
-    // coalesced load of the nl lines.  Batches of LB independent loads are issued before the first
-    // wait (addresses are clamped instead of predicated: a predicated load makes hipcc branch and
-    // wait per element, which serialises one full memory round trip per 256 B).
-    const int CH = (len + 63) >> 6;          // 64-element chunks per line
-    const int nch = nl * CH;
-    // chunk -> (line, chunk of line) by a reciprocal multiply: an integer division per load and per store
-    // costs more VALU time than the loads take (c * CH < 2^20 here: c < 64 * CH, CH <= 512)
-    const unsigned inv = (1u << 20) / (unsigned)CH + 1u;
-    constexpr int LB = sizeof(T) == 8 ? 18 : 36;   // loads in flight per lane (float: one round trip covers a whole 11-12 line block)
-    const int W = NT >> 6, wv = __builtin_amdgcn_readfirstlane(lane >> 6), l64 = lane & 63;   // chunks are dealt to the wavefronts in turn
-    for (int c0 = 0; c0 * W < nch; c0 += LB) {
+    // coalesced load of the nl lines: lane-linear over the block's elements, line after line (consecutive lines of a
+    // map are contiguous in memory, so the loads stay coalesced across line ends and short lines — 100+ lines of
+    // 6-20 elements on the small levels — fill the lanes like long ones).  Batches of LB independent loads are
+    // issued before the first wait (addresses are clamped instead of predicated: a predicated load makes hipcc
+    // branch and wait per element, which serialises one full memory round trip per 256 B).
+    const int n = nl * len;
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)len - 1) / (unsigned)len);   // f / len = umulhi(f, magic): exact for f * len < 2^32
+    constexpr int LB = sizeof(T) == 8 ? 12 : 24;   // loads in flight per lane (a 25 KB block of float lines: <= 22 elements per lane)
+    for (int f0 = 0; f0 < n; f0 += LB * NT) {
       T r[LB];
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
-        const int c = min((c0 + j) * W + wv, nch - 1);
-        const int i = (int)(((unsigned)c * inv) >> 20);
-        const int q = min((c - i * CH) * 64 + l64, len - 1);
-        r[j] = ((GP(T))lptr[i])[q];
+        const int f = min(f0 + j * NT + lane, n - 1);
+        const int i = (int)__umulhi((unsigned)f, magic);
+        r[j] = ((GP(T))lptr[i])[f - i * len];
       }
       // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
       if constexpr (!EX) {
-        if (c0 == 0)
+        if (f0 == 0)
           for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
-        const int c = (c0 + j) * W + wv, cc = min(c, nch - 1);
-        const int i = (int)(((unsigned)cc * inv) >> 20);
-        const int q = (cc - i * CH) * 64 + l64;
-        if (c < nch && q < len) YZ[i * S + q].x = r[j];
+        const int f = f0 + j * NT + lane, fc = min(f, n - 1);
+        const int i = (int)__umulhi((unsigned)fc, magic);
+        if (f < n) YZ[i * S + (fc - i * len)].x = r[j];
       }
     }
   }
@@ -360,7 +373,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 }
 
 template <typename T, int FM>
-__global__ __launch_bounds__(256, 4) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
+__global__ __launch_bounds__(256, 3) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
                                                     const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   DT_STAMP(0);
@@ -516,18 +529,21 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
   if (J.fold >= 0) {
     // fold mode: the root's accumulated score is built here from its raw responses and its children's messages
     constexpr int M = PBD_FOLD_MAXMIX;
-    T acc[M];
+    T acc[1][M];
+    const size_t offs[1] = {cell};
+    const bool valids[1] = {true};
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = ((GP(T))J.score[m < J.K ? m : J.K - 1])[cell];
-    fold_children<T, M>(folds + J.fold, biasw, cell, (size_t)J.H * J.W, J.K, true, acc);
+    for (int m = 0; m < M; ++m) acc[0][m] = ((GP(T))J.score[m < J.K ? m : J.K - 1])[cell];
+    // (acc is [1][M]: one cell per lane)
+    fold_children<T, M, 1>(folds + J.fold, biasw, offs, (size_t)J.H * J.W, J.K, valids, acc);
     if (J.K == 1) {
-      v = acc[0] + bias;
+      v = acc[0][0] + bias;
     } else {
       v = -INFINITY;
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         if (m < J.K) {
-          const T wv = acc[m] + bias;                      // DynamicProgram.cpp:169
+          const T wv = acc[0][m] + bias;                   // DynamicProgram.cpp:169
           if (wv > v) { bi = m; v = wv; }
         }
       }

@@ -355,6 +355,9 @@ static int dt_lpb_for(int stride, int len, int unit, size_t budget, int ts, int 
   int lpb = std::min(nt, 128);   // at most one line per lane
   if (unit > 1) lpb = std::max(unit, lpb / unit * unit);
   while (lpb > lmin && dt_lds_bytes(stride, lpb, ts, nt) > budget) lpb -= (unit > 1 ? unit : 1);
+  // plain: the nt / lpb lanes of a line are a whole number, so 45 lines that fit would leave 128 - 2 * 45 lanes idle and
+  // every line with two segments where 42 lines get three: the largest lpb <= the fit that uses all lanes
+  if (unit <= 1 && lpb > lmin) lpb = std::max(lmin, nt / ((nt + lpb - 1) / lpb));
   // The nt / lpb lanes that share a line scan one segment of it each (dt_core.hpp), and a block lasts as long as
   // its segments are: with a target segment length, lines are given up for lanes per line where the budget
   // would put so many lines into a block that each is left with one or two lanes.
@@ -568,11 +571,54 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     return lds;
   };
   const bool dbg_plan = PBD_PROBE_ENV("PBD_DEBUG_PLAN") != nullptr;
+  // A launch whose blocks do not all fit on the chip at once lasts two block times instead of one (measured: the
+  // fold x pass of the 4-part rounds, 1772 blocks for 1536 slots at 25 KB: 100 us instead of 45).  Blocks that hold
+  // whole rows of all mixtures quantise badly (12 lines where 15 would fit), so such a launch gets the smallest
+  // larger budget at which its blocks are resident together (fewer, larger blocks; fewer blocks per CU).
+  int ncu = 256;
+  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, h->opt.device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+  auto count_blocks = [&](const std::vector<int>& rnd, size_t budget, bool fold_x, bool ypass, size_t* lds_out) {
+    size_t nb = 0, lds = 0;
+    for (int l = 0; l < n; ++l) {
+      const Level& L = h->lv[l];
+      if (!L.active || L.cw == 0 || L.ch == 0) continue;
+      const int len = ypass ? L.ch : L.cw, nlines = ypass ? L.cw : L.ch;
+      if (fold_x) {
+        for (int fp : rnd) {
+          const DtGroup g = dt_group(0, h->parts[fp].K, nlines, len, budget, h->ts, h->dt_nt, h->dt_seg, 0);
+          nb += (size_t)(nlines + g.lpb / g.nmaps - 1) / (g.lpb / g.nmaps);
+          lds = std::max(lds, dt_lds_bytes(g.stride, g.lpb, h->ts, h->dt_nt));
+        }
+      } else {
+        int nm = 0;
+        for (int fp : rnd) nm += h->parts[fp].K;
+        const DtGroup g = dt_group(0, nm, nlines, len, budget, h->ts, h->dt_nt, h->dt_seg);
+        nb += ((size_t)nm * nlines + g.lpb - 1) / g.lpb;
+        lds = std::max(lds, dt_lds_bytes(g.stride, g.lpb, h->ts, h->dt_nt));
+      }
+    }
+    *lds_out = lds;
+    return nb;
+  };
+  auto resident_budget = [&](const std::vector<int>& rnd, size_t budget, bool fold_x, bool ypass) {
+    if (PBD_PROBE_ENV("PBD_DT_NO_RESIDENT")) return budget;
+    const int waves_blk = std::max(1, h->dt_nt / 64);
+    for (size_t b = budget; b <= budget * 8 / 5 && b <= 150 * 1024; b += 1024) {
+      size_t lds = 0;
+      const size_t nb = count_blocks(rnd, b, fold_x, ypass, &lds);
+      const size_t per_cu = std::min<size_t>(160 * 1024 / std::max<size_t>(lds, 1), 24 / waves_blk);
+      if (nb <= per_cu * ncu) return b;
+    }
+    return budget;
+  };
   for (size_t r = 0; r < h->rounds.size(); ++r) {
     const std::vector<int>& rnd = h->rounds[r];
     pbd_handle::RoundLaunch R{};
-    const size_t budget = launch_budget(roundK[r]);
     const bool fold_x = fold && r > 0;   // round 0 = the leaves: their lines are their raw responses
+    size_t budget_x = launch_budget(roundK[r]), budget = budget_x;
+    if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_X_KB")) { if (fold_x) budget_x = std::max(dt_need, (size_t)atoi(e) * 1024); }
+    else budget_x = resident_budget(rnd, budget_x, fold_x, false);
+    budget = resident_budget(rnd, budget, false, true);
     std::vector<DtTask> xt, yt;
     for (int l = 0; l < n && !rnd.empty(); ++l) {
       const Level& L = h->lv[l];
@@ -597,9 +643,9 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
           gx_nmaps++;
         }
         tmp_round += (size_t)P.K * act_cells;
-        if (fold_x) dt_add_tasks(dt_group(part_map0, P.K, L.ch, L.cw, budget, h->ts, h->dt_nt, h->dt_seg, make_fold(fp, l)), xt);
+        if (fold_x) dt_add_tasks(dt_group(part_map0, P.K, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg, make_fold(fp, l)), xt);
       }
-      if (!fold_x) dt_add_tasks(dt_group(gx_map0, gx_nmaps, L.ch, L.cw, budget, h->ts, h->dt_nt, h->dt_seg), xt);
+      if (!fold_x) dt_add_tasks(dt_group(gx_map0, gx_nmaps, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg), xt);
       const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, budget, h->ts, h->dt_nt, h->dt_seg);
       for (auto& my : ymaps) maps.push_back(my);
       dt_add_tasks(gy, yt);
