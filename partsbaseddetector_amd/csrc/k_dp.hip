@@ -94,12 +94,16 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // branch costs one full scalar-memory round trip per branch, which is what made a first version's loader 5x slower
 // than the plain one.  Everything below is branch-free except the loop over the children.
 template <typename T, int M, int U>
-__device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ biasw, const size_t (&off)[U],
+__device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ /*biasw*/, const size_t (&off)[U],
                                               size_t HW, int L, const bool (&valid)[U], T (&acc)[U][M]) {
   const int nch = J->nch;
   for (int c = 0; c < nch; ++c) {
     const FoldChild& C = J->ch[c];
+    // everything the child contributes is fetched up front, in straight-line code: the K planes' values of the U
+    // cells (vector loads), the plane pointers, the Ik plane and the dense K x L bias block (wave-uniform: wide
+    // scalar loads, one wait)
     const int K = C.K;
+    GPW(uint8_t) okp = (GPW(uint8_t))C.ok;
     T sd[U][M];
 #pragma unroll
     for (int k = 0; k < M; ++k) {
@@ -109,11 +113,9 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
     }
     float bias[M][M];
 #pragma unroll
-    for (int k = 0; k < M; ++k) {
-      const int bo = C.bias_off[k < K ? k : K - 1];
+    for (int k = 0; k < M; ++k)
 #pragma unroll
-      for (int m = 0; m < M; ++m) bias[k][m] = biasw[bo + (m < L ? m : L - 1)];
-    }
+      for (int m = 0; m < M; ++m) bias[k][m] = C.bias[k][m];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       T v[M];
@@ -139,7 +141,7 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         if (m < L) {
-          if (valid[u]) ((GPW(uint8_t))C.ok)[(size_t)m * HW + off[u]] = (uint8_t)bi[m];   // Ik (:150)
+          if (valid[u]) okp[(size_t)m * HW + off[u]] = (uint8_t)bi[m];   // Ik (:150)
           acc[u][m] = acc[u][m] + v[m];                                                  // parent.score += maxv (:156), child order kept
         }
       }
@@ -243,14 +245,15 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     // issued before the first wait (addresses are clamped instead of predicated: a predicated load makes hipcc
     // branch and wait per element, which serialises one full memory round trip per 256 B).
     const int n = nl * len;
-    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)len - 1) / (unsigned)len);   // f / len = umulhi(f, magic): exact for f * len < 2^32
+    // f / len = umulhi(f, magic), magic = ceil(2^32 / len): exact for f * len < 2^32 (len = 1: the quotient is f itself)
+    const unsigned magic = len > 1 ? (0xFFFFFFFFu / (unsigned)len + 1u) : 0u;
     constexpr int LB = sizeof(T) == 8 ? 12 : 24;   // loads in flight per lane (a 25 KB block of float lines: <= 22 elements per lane)
     for (int f0 = 0; f0 < n; f0 += LB * NT) {
       T r[LB];
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
         const int f = min(f0 + j * NT + lane, n - 1);
-        const int i = (int)__umulhi((unsigned)f, magic);
+        const int i = len > 1 ? (int)__umulhi((unsigned)f, magic) : f;
         r[j] = ((GP(T))lptr[i])[f - i * len];
       }
       // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
@@ -261,7 +264,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
         const int f = f0 + j * NT + lane, fc = min(f, n - 1);
-        const int i = (int)__umulhi((unsigned)fc, magic);
+        const int i = len > 1 ? (int)__umulhi((unsigned)fc, magic) : fc;
         if (f < n) YZ[i * S + (fc - i * len)].x = r[j];
       }
     }

@@ -350,6 +350,7 @@ static void free_frame(pbd_handle* h) {
 // of the scan was an lpb-way bank conflict); lpb = lines per block: 4 .. lanes of the block (plain), or a whole
 // number of rows x the K mixtures of the part (fold: unit = K).
 static int dt_stride_for(int len) { return (len + 1) | 1; }
+static bool g_dt_round = true;   // plan-time switch of the search in plan_frame (single-threaded per handle; set before every use)
 static int dt_lpb_for(int stride, int len, int unit, size_t budget, int ts, int nt, int seg) {
   const int lmin = unit > 1 ? unit : 4;
   int lpb = std::min(nt, 128);   // at most one line per lane
@@ -357,7 +358,7 @@ static int dt_lpb_for(int stride, int len, int unit, size_t budget, int ts, int 
   while (lpb > lmin && dt_lds_bytes(stride, lpb, ts, nt) > budget) lpb -= (unit > 1 ? unit : 1);
   // plain: the nt / lpb lanes of a line are a whole number, so 45 lines that fit would leave 128 - 2 * 45 lanes idle and
   // every line with two segments where 42 lines get three: the largest lpb <= the fit that uses all lanes
-  if (unit <= 1 && lpb > lmin) lpb = std::max(lmin, nt / ((nt + lpb - 1) / lpb));
+  if (g_dt_round && unit <= 1 && lpb > lmin) lpb = std::max(lmin, nt / ((nt + lpb - 1) / lpb));
   // The nt / lpb lanes that share a line scan one segment of it each (dt_core.hpp), and a block lasts as long as
   // its segments are: with a target segment length, lines are given up for lanes per line where the budget
   // would put so many lines into a block that each is left with one or two lanes.
@@ -541,7 +542,10 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       FoldChild& F = J.ch[J.nch++];
       F.K = C.K;
       for (int k = 0; k < PBD_FOLD_MAXMIX; ++k) F.sdt[k] = sdt_plane(c, l, std::min(k, C.K - 1));
-      for (int k = 0; k < C.K; ++k) F.bias_off[k] = C.biasid[k];
+      const int Lp = h->parts[fp].K;
+      for (int k = 0; k < PBD_FOLD_MAXMIX; ++k)
+        for (int mm = 0; mm < PBD_FOLD_MAXMIX; ++mm)
+          F.bias[k][mm] = h->biasw[C.biasid[std::min(k, C.K - 1)] + std::min(mm, Lp - 1)];
       F.ok = h->d_pk + L.cell_off * h->nplanes + (size_t)C.plane0 * HW;
     }
     folds.push_back(J);
@@ -575,6 +579,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   // fold x pass of the 4-part rounds, 1772 blocks for 1536 slots at 25 KB: 100 us instead of 45).  Blocks that hold
   // whole rows of all mixtures quantise badly (12 lines where 15 would fit), so such a launch gets the smallest
   // larger budget at which its blocks are resident together (fewer, larger blocks; fewer blocks per CU).
+  int first_active = 0;
+  for (int l = 0; l < n; ++l) if (h->lv[l].active && h->lv[l].cw > 0 && h->lv[l].ch > 0) { first_active = l; break; }
   int ncu = 256;
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, h->opt.device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
   auto count_blocks = [&](const std::vector<int>& rnd, size_t budget, bool fold_x, bool ypass, size_t* lds_out) {
@@ -600,25 +606,47 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     *lds_out = lds;
     return nb;
   };
-  auto resident_budget = [&](const std::vector<int>& rnd, size_t budget, bool fold_x, bool ypass) {
-    if (PBD_PROBE_ENV("PBD_DT_NO_RESIDENT")) return budget;
+  // Launch geometry: among the budgets around the base one (and, for plain lines, with or without the full-lane
+  // rounding of the lines per block) take the one whose blocks are all resident at once and whose longest segment
+  // (elements per lane) is the shortest; no candidate resident: the base budget.
+  struct Geo { size_t budget; bool round; };
+  auto launch_geometry = [&](const std::vector<int>& rnd, size_t base, bool fold_x, bool ypass) {
+    Geo best{base, true};
+    if (PBD_PROBE_ENV("PBD_DT_NO_RESIDENT")) return best;
     const int waves_blk = std::max(1, h->dt_nt / 64);
-    for (size_t b = budget; b <= budget * 8 / 5 && b <= 150 * 1024; b += 1024) {
-      size_t lds = 0;
-      const size_t nb = count_blocks(rnd, b, fold_x, ypass, &lds);
-      const size_t per_cu = std::min<size_t>(160 * 1024 / std::max<size_t>(lds, 1), 24 / waves_blk);
-      if (nb <= per_cu * ncu) return b;
+    double best_cost = 1e30;
+    for (int rr = 1; rr >= 0; --rr) {
+      if (fold_x && !rr) break;          // rounding only concerns plain lines
+      g_dt_round = rr != 0;
+      for (size_t b = std::max(dt_need, base * 4 / 5); b <= base * 8 / 5 && b <= 150 * 1024; b += 1024) {
+        size_t lds = 0;
+        const size_t nb = count_blocks(rnd, b, fold_x, ypass, &lds);
+        const size_t per_cu = std::min<size_t>(160 * 1024 / std::max<size_t>(lds, 1), 24 / waves_blk);
+        if (nb > per_cu * ncu) continue;
+        // cost ~ the longest segment of the launch's largest level (its blocks are the bulk), a mild preference for
+        // the base budget (co-residency with the other kernels of the frames in flight was tuned there)
+        const int len0 = ypass ? h->lv[first_active].ch : h->lv[first_active].cw;
+        int nm = 0;
+        for (int fp : rnd) nm += h->parts[fp].K;
+        const DtGroup g0 = fold_x ? dt_group(0, h->parts[rnd[0]].K, ypass ? h->lv[first_active].cw : h->lv[first_active].ch, len0, b, h->ts, h->dt_nt, h->dt_seg, 0)
+                                  : dt_group(0, nm, ypass ? h->lv[first_active].cw : h->lv[first_active].ch, len0, b, h->ts, h->dt_nt, h->dt_seg);
+        const int P = std::max(1, std::min(h->dt_nt / g0.lpb, len0 / 8));
+        const double cost = (double)len0 / P + 0.15 * std::abs((double)b - (double)base) / 1024.0;
+        if (cost < best_cost) { best_cost = cost; best = Geo{b, rr != 0}; }
+      }
     }
-    return budget;
+    g_dt_round = true;
+    return best;
   };
   for (size_t r = 0; r < h->rounds.size(); ++r) {
     const std::vector<int>& rnd = h->rounds[r];
     pbd_handle::RoundLaunch R{};
     const bool fold_x = fold && r > 0;   // round 0 = the leaves: their lines are their raw responses
+    if (rnd.empty()) { h->rl.push_back(R); continue; }
     size_t budget_x = launch_budget(roundK[r]), budget = budget_x;
-    if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_X_KB")) { if (fold_x) budget_x = std::max(dt_need, (size_t)atoi(e) * 1024); }
-    else budget_x = resident_budget(rnd, budget_x, fold_x, false);
-    budget = resident_budget(rnd, budget, false, true);
+    Geo geox = launch_geometry(rnd, budget_x, fold_x, false), geoy = launch_geometry(rnd, budget, false, true);
+    if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_X_KB")) { if (fold_x) geox = Geo{std::max(dt_need, (size_t)atoi(e) * 1024), true}; }
+    budget_x = geox.budget; budget = geoy.budget;
     std::vector<DtTask> xt, yt;
     for (int l = 0; l < n && !rnd.empty(); ++l) {
       const Level& L = h->lv[l];
@@ -645,8 +673,11 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
         tmp_round += (size_t)P.K * act_cells;
         if (fold_x) dt_add_tasks(dt_group(part_map0, P.K, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg, make_fold(fp, l)), xt);
       }
+      g_dt_round = geox.round;
       if (!fold_x) dt_add_tasks(dt_group(gx_map0, gx_nmaps, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg), xt);
+      g_dt_round = geoy.round;
       const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, budget, h->ts, h->dt_nt, h->dt_seg);
+      g_dt_round = true;
       for (auto& my : ymaps) maps.push_back(my);
       dt_add_tasks(gy, yt);
       if (dbg_plan)

@@ -90,7 +90,8 @@ struct FoldChild {
                                       // be the child's own response planes, overwritten in place by its y pass)
   uint8_t* ok;                        // output Ik: best child mixture per parent mixture, [L][H][W]
   int K, pad;
-  int bias_off[PBD_FOLD_MAXMIX];      // biasw index of bias(k)[0]
+  float bias[PBD_FOLD_MAXMIX][PBD_FOLD_MAXMIX];   // bias(k)[m] = biasw[biasid[k] + m] (include/Parts.hpp:172-175), dense: rows beyond K / columns
+                                                  // beyond L repeat the last valid one, so the kernel fetches whole rows with wide scalar loads
 };
 struct FoldJob { int nch, pad; FoldChild ch[PBD_MAX_CH]; };
 struct ReduceJob {       // one (level, parent): fold the messages of nch children, in the reference's order

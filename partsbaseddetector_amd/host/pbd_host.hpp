@@ -55,6 +55,7 @@ class Mat {
   int channels() const { return cn_; }
   size_t elem1() const { return depth_ == PBD_8U ? 1 : depth_ == PBD_64F ? 8 : 4; }
   size_t step() const { return (size_t)cols * cn_ * elem1(); }
+  size_t bytes() const { return buf_.size(); }
   template <typename T> T* ptr(int r = 0) { return (T*)(buf_.data() + (size_t)r * step()); }
   template <typename T> const T* ptr(int r = 0) const { return (const T*)(buf_.data() + (size_t)r * step()); }
   template <typename T> T& at(int r, int c) { return ptr<T>(r)[c]; }
@@ -221,14 +222,59 @@ class BinaryModel : public Model {
   }
 };
 
+// Content fingerprint of a host buffer (four independent multiply-add lanes over its 64-bit words).  The stage
+// adaptors below take their inputs as ARGUMENTS, like the reference's interfaces do (IConvolutionEngine::pdf(features,
+// ...), DynamicProgram::min(parts, scores, ...), argmin(..., rootv, rooti, ..., Ix, Iy, Ik, ...)): what the caller
+// passes is what is processed.  The device keeps the fingerprint of everything it handed out; an argument whose
+// bytes still match is already resident and is not uploaded again, anything else — another engine's output, a
+// buffer edited in place — is uploaded first.  Nothing is ever answered from stale resident buffers.
+static inline uint64_t fingerprint(const void* p, size_t bytes) {
+  const uint8_t* b = (const uint8_t*)p;
+  uint64_t a0 = 0x9E3779B97F4A7C15ull, a1 = 0xC2B2AE3D27D4EB4Full, a2 = 0x165667B19E3779F9ull, a3 = 0x27D4EB2F165667C5ull;
+  size_t i = 0;
+  for (; i + 32 <= bytes; i += 32) {
+    uint64_t w[4];
+    memcpy(w, b + i, 32);
+    a0 = (a0 ^ w[0]) * 0x100000001B3ull + 1; a1 = (a1 ^ w[1]) * 0x100000001B3ull + 3;
+    a2 = (a2 ^ w[2]) * 0x100000001B3ull + 5; a3 = (a3 ^ w[3]) * 0x100000001B3ull + 7;
+  }
+  for (; i < bytes; ++i) a0 = (a0 ^ b[i]) * 0x100000001B3ull + 11;
+  return (a0 ^ (a1 << 1) ^ (a2 << 2) ^ (a3 << 3)) + bytes;
+}
+
 // ---- shared device handle -------------------------------------------------------------------
 class Device {
  public:
   pbd_handle* h = nullptr;
   int scalar = PBD_SCALAR_F32;   // T of the detector that owns this device (cv::DataType<T>::type)
+  int max_candidates = 4096;     // pbd_options.max_candidates: device-side capacity, also the host arrays' size
+  // what the device holds, as fingerprints of the host copies handed out (0 = nothing resident / unknown)
+  std::vector<uint64_t> fp_feat;                 // [level]
+  std::vector<std::vector<uint64_t>> fp_resp;    // [level][filter]
+  std::vector<std::vector<uint64_t>> fp_root;    // [level][component]: rootv ^ rooti
+  std::vector<uint64_t> fp_tab;                  // per (level, component, part, parent mixture) in walk order: Ix ^ Iy ^ Ik
+  bool tables_resident = false;                  // min() of THIS device produced the tables on the device
+  std::vector<int32_t> cell_w, cell_h;           // level sizes of the current frame geometry
+  vectorf scales;
+  void geometry(int w, int hgt) {                // after pbd_pyramid_u8 / pbd_begin_frame
+    int n = 0;
+    check(pbd_pyramid_geometry(h, w, hgt, &n, 0, 0, 0, 0, 0));
+    cell_w.resize(n); cell_h.resize(n); scales.resize(n);
+    check(pbd_pyramid_geometry(h, w, hgt, &n, 0, 0, cell_w.data(), cell_h.data(), scales.data()));
+    fp_feat.assign(n, 0); fp_resp.clear(); fp_root.clear(); fp_tab.clear(); tables_resident = false;
+  }
+  // a caller that brings features from another IFeatures declares the frame first (the level sizes follow from it)
+  void beginFrame(int w, int hgt, int cn) { check(pbd_begin_frame(h, w, hgt, cn)); geometry(w, hgt); }
+  void checkLevels(const vectorMat& v, int per_cell, const char* what) const {
+    if (v.size() != cell_w.size()) throw Exception(PBD_ERR_STATE, std::string(what) + ": level count differs from the frame geometry of the device "
+                                                                  "(run HipHOGFeatures::pyramid or Device::beginFrame for this image first)");
+    for (size_t l = 0; l < v.size(); ++l)
+      if (v[l].rows != cell_h[l] || v[l].cols != cell_w[l] * per_cell)
+        throw Exception(PBD_ERR_ARG, std::string(what) + ": level " + std::to_string(l) + " has the wrong size for the frame geometry of the device");
+  }
   std::vector<float> filters, defw, biasw;
   std::vector<int32_t> anchors, part_offset, parentid, mix_offset, filterid, defid, biasid;
-  Device(Model& m, int device, int conv_mode, int scalar_type = PBD_SCALAR_F32) {
+  Device(Model& m, int device, int conv_mode, int scalar_type = PBD_SCALAR_F32, int max_cand = 4096) {
     pbd_model_desc d{};
     const int kh = m.filters()[0].rows, kw = m.filters()[0].cols / m.flen();
     for (Mat& f : m.filters()) filters.insert(filters.end(), f.ptr<float>(), f.ptr<float>() + (size_t)kh * kw * m.flen());
@@ -256,8 +302,9 @@ class Device {
     d.part_offset = part_offset.data(); d.parentid = parentid.data(); d.mix_offset = mix_offset.data();
     d.filterid = filterid.data(); d.defid = defid.data(); d.biasid = biasid.data();
     pbd_options opt{};
-    opt.device = device; opt.conv_mode = conv_mode; opt.scalar_type = scalar_type;
-    scalar = scalar_type;
+    opt.device = device; opt.conv_mode = conv_mode; opt.scalar_type = scalar_type; opt.max_candidates = max_cand;
+    scalar = scalar_type; max_candidates = max_cand > 0 ? max_cand : 4096;
+    if (pbd_abi_version() != PBD_ABI_VERSION) throw Exception(PBD_ERR_UNSUPPORTED, "libpbd_hip.so was built for another pbd_c.h (pbd_abi_version)");
     const int rc = pbd_create(&d, &opt, &h);
     if (rc != PBD_OK) { std::string msg = h ? pbd_last_error(h) : "pbd_create failed"; if (h) pbd_destroy(h); h = nullptr; throw Exception(rc, msg); }
   }
@@ -285,11 +332,10 @@ class HipHOGFeatures : public IFeatures {          // include/HOGFeatures.hpp:52
   void pyramid(const Mat& im, vectorMat& pyrafeatures) override {   // src/HOGFeatures.cpp:95-151
     if (im.depth() != PBD_8U) throw Exception(PBD_ERR_UNSUPPORTED, "Unsupported image type");  // :141-145
     dev_->check(pbd_pyramid_u8(dev_->h, im.ptr<uint8_t>(), im.cols, im.rows, im.channels(), (int)im.step()));
-    int n = 0;
-    dev_->check(pbd_pyramid_geometry(dev_->h, im.cols, im.rows, &n, 0, 0, 0, 0, 0));
-    std::vector<int32_t> cw(n), ch(n);
-    scales_.resize(n); nscales_ = n;
-    dev_->check(pbd_pyramid_geometry(dev_->h, im.cols, im.rows, &n, 0, 0, cw.data(), ch.data(), scales_.data()));
+    dev_->geometry(im.cols, im.rows);
+    const int n = (int)dev_->cell_w.size();
+    const std::vector<int32_t>&cw = dev_->cell_w, &ch = dev_->cell_h;
+    scales_ = dev_->scales; nscales_ = n;
     pyrafeatures.clear(); pyrafeatures.resize(n);
     for (int l = 0; l < n; ++l) {
       const bool f64 = dev_->scalar == PBD_SCALAR_F64;   // HOGFeatures<T>: Mat of DataType<T>::type
@@ -297,6 +343,7 @@ class HipHOGFeatures : public IFeatures {          // include/HOGFeatures.hpp:52
       if (ch[l] > 0 && cw[l] > 0)
         dev_->check(f64 ? pbd_get_level_features_f64(dev_->h, l, pyrafeatures[l].ptr<double>())
                         : pbd_get_level_features(dev_->h, l, pyrafeatures[l].ptr<float>()));
+      dev_->fp_feat[l] = fingerprint(pyrafeatures[l].ptr<uint8_t>(), pyrafeatures[l].bytes());
     }
   }
 };
@@ -315,15 +362,30 @@ class HipConvolutionEngine : public IConvolutionEngine {   // include/SpatialCon
   explicit HipConvolutionEngine(std::shared_ptr<Device> d) : dev_(d) {}
   void setFilters(const vectorMat& filters) override { nfilters_ = filters.size(); }  // uploaded by pbd_create
   void pdf(const vectorMat& features, vector2DMat& responses) override {  // src/SpatialConvolutionEngine.cpp:106-124
-    dev_->check(pbd_pdf(dev_->h));                 // consumes the pyramid resident on the device
+    const bool f64 = dev_->scalar == PBD_SCALAR_F64;   // SpatialConvolutionEngine(type_)
+    dev_->checkLevels(features, 32, "pdf(features)");
+    // the features that are processed are the ones passed in: levels whose bytes the device does not already hold
+    // (another IFeatures' pyramid, a pyramid edited after pyramid()) are uploaded first
+    for (size_t l = 0; l < features.size(); ++l) {
+      if (features[l].empty()) continue;
+      if (features[l].depth() != (f64 ? PBD_64F : PBD_32F)) throw Exception(PBD_ERR_ARG, "pdf(features): element type differs from the detector's T");
+      const uint64_t fp = fingerprint(features[l].ptr<uint8_t>(), features[l].bytes());
+      if (fp == dev_->fp_feat[l]) continue;
+      dev_->check(f64 ? pbd_set_level_features_f64(dev_->h, (int)l, features[l].ptr<double>())
+                      : pbd_set_level_features(dev_->h, (int)l, features[l].ptr<float>()));
+      dev_->fp_feat[l] = fp;
+    }
+    dev_->check(pbd_pdf(dev_->h));
     responses.assign(features.size(), vectorMat(nfilters_));
+    dev_->fp_resp.assign(features.size(), std::vector<uint64_t>(nfilters_, 0));
+    dev_->tables_resident = false;
     for (size_t l = 0; l < features.size(); ++l)
       for (size_t n = 0; n < nfilters_; ++n) {
-        const bool f64 = dev_->scalar == PBD_SCALAR_F64;   // SpatialConvolutionEngine(type_)
         responses[l][n].create(features[l].rows, features[l].cols / 32, f64 ? PBD_64F : PBD_32F);
         if (!responses[l][n].empty())
           dev_->check(f64 ? pbd_get_level_response_f64(dev_->h, (int)l, (int)n, responses[l][n].ptr<double>())
                           : pbd_get_level_response(dev_->h, (int)l, (int)n, responses[l][n].ptr<float>()));
+        dev_->fp_resp[l][n] = fingerprint(responses[l][n].ptr<uint8_t>(), responses[l][n].bytes());
       }
   }
 };
@@ -356,34 +418,64 @@ class Parts {
   int parent(int c, int p) const { return p ? parentid_[c][p] : -1; }        // ComponentPart::parent, :143
 };
 
-// DynamicProgram<T> with the reference's signatures (include/DynamicProgram.hpp:74-75).  The tables stay on the
-// device; min() additionally materialises them in the reference's shapes — rootv / rooti[level][component] and,
-// unless fetchPointerTables(false), Ix / Iy / Ik[level][component][part][parent mixture] as CV_32S-like maps
-// (src/DynamicProgram.cpp:72-76,147-151; 250 MB for the person model at 640x480, which is why a caller that only
-// goes on to argmin() may switch them off: argmin() back-tracks on the device from the resident tables, the
-// vectors passed back in are not re-uploaded).
+// DynamicProgram<T> with the reference's signatures (include/DynamicProgram.hpp:74-75).  min() transforms the SCORES
+// IT IS GIVEN (planes the device does not already hold are uploaded), leaves the tables on the device and materialises
+// them in the reference's shapes — rootv / rooti[level][component] and, unless fetchPointerTables(false), Ix / Iy /
+// Ik[level][component][part][parent mixture] as CV_32S-like maps (src/DynamicProgram.cpp:72-76,147-151; 250 MB for the
+// person model at 640x480, which is why a caller that only goes on to argmin() may switch them off).  argmin()
+// back-tracks on the device from THE TABLES IT IS GIVEN: tables whose bytes are the ones min() handed out are
+// already there, anything else (another engine's min(), tables edited in between) is uploaded first
+// (pbd_set_root / pbd_set_dp_pointers).  Empty pointer tables (fetchPointerTables(false)) stand for "the tables of
+// this object's last min()"; if there was none, argmin() throws instead of answering from whatever is resident.
 template <typename T>
 class DynamicProgram {
   std::shared_ptr<Device> dev_;
   bool fetch_ptr_ = true;
+  static int set_resp(pbd_handle* h, int l, int n, const float* p) { return pbd_set_level_response(h, l, n, p); }
+  static int set_resp(pbd_handle* h, int l, int n, const double* p) { return pbd_set_level_response_f64(h, l, n, p); }
+  static int set_root(pbd_handle* h, int l, int c, const float* v, const int32_t* i) { return pbd_set_root(h, l, c, v, i); }
+  static int set_root(pbd_handle* h, int l, int c, const double* v, const int32_t* i) { return pbd_set_root_f64(h, l, c, v, i); }
+  static uint64_t fp3(const Mat& a, const Mat& b, const Mat& c) {
+    return fingerprint(a.ptr<uint8_t>(), a.bytes()) ^ (fingerprint(b.ptr<uint8_t>(), b.bytes()) * 3) ^ (fingerprint(c.ptr<uint8_t>(), c.bytes()) * 5);
+  }
  public:
   DynamicProgram() {}
   explicit DynamicProgram(std::shared_ptr<Device> d) : dev_(d) {}
   void fetchPointerTables(bool on) { fetch_ptr_ = on; }
   void min(Parts& parts, vector2DMat& scores, vector4DMat& Ix, vector4DMat& Iy, vector4DMat& Ik, vector2DMat& rootv,
            vector2DMat& rooti) {
-    dev_->check(pbd_dp_min(dev_->h));
     const size_t nscales = scores.size();
     const int ncomponents = parts.ncomponents();
+    if (nscales != dev_->cell_w.size())
+      throw Exception(PBD_ERR_STATE, "min(scores): level count differs from the frame geometry of the device (run HipHOGFeatures::pyramid or Device::beginFrame first)");
+    if (dev_->fp_resp.size() != nscales) dev_->fp_resp.assign(nscales, std::vector<uint64_t>());
+    for (size_t n = 0; n < nscales; ++n) {                        // the scores that are transformed are the ones passed in
+      dev_->fp_resp[n].resize(scores[n].size(), 0);
+      for (size_t f = 0; f < scores[n].size(); ++f) {
+        const Mat& sc = scores[n][f];
+        if (sc.rows != dev_->cell_h[n] || sc.cols != dev_->cell_w[n]) throw Exception(PBD_ERR_ARG, "min(scores): a score map has the wrong size for the frame geometry of the device");
+        if (sc.empty()) continue;
+        if (sc.depth() != (int)DataType<T>::type) throw Exception(PBD_ERR_ARG, "min(scores): element type differs from the detector's T");
+        const uint64_t fp = fingerprint(sc.ptr<uint8_t>(), sc.bytes());
+        if (fp == dev_->fp_resp[n][f]) continue;
+        dev_->check(set_resp(dev_->h, (int)n, (int)f, sc.template ptr<T>()));
+        dev_->fp_resp[n][f] = fp;
+      }
+    }
+    dev_->check(pbd_dp_min(dev_->h));
     Ix.assign(nscales, vector3DMat(ncomponents)); Iy.assign(nscales, vector3DMat(ncomponents)); Ik.assign(nscales, vector3DMat(ncomponents));
     rootv.assign(nscales, vectorMat(ncomponents));
     rooti.assign(nscales, vectorMat(ncomponents));
+    dev_->fp_root.assign(nscales, std::vector<uint64_t>(ncomponents, 0));
+    dev_->fp_tab.clear();
+    dev_->tables_resident = true;
     for (size_t n = 0; n < nscales; ++n)
       for (int c = 0; c < ncomponents; ++c) {
-        const int rows = scores[n][0].rows, cols = scores[n][0].cols;
+        const int rows = dev_->cell_h[n], cols = dev_->cell_w[n];
         rootv[n][c].create(rows, cols, DataType<T>::type);
         rooti[n][c].create(rows, cols, PBD_32S);
         if (!rootv[n][c].empty()) dev_->check(get_root(dev_->h, (int)n, c, rootv[n][c].template ptr<T>(), rooti[n][c].ptr<int32_t>()));
+        dev_->fp_root[n][c] = fingerprint(rootv[n][c].template ptr<uint8_t>(), rootv[n][c].bytes()) ^ (fingerprint(rooti[n][c].ptr<uint8_t>(), rooti[n][c].bytes()) * 3);
         Ix[n][c].resize(parts.nparts(c)); Iy[n][c].resize(parts.nparts(c)); Ik[n][c].resize(parts.nparts(c));   // :89-91
         for (int p = 1; p < parts.nparts(c) && fetch_ptr_; ++p) {
           const int L = parts.nmixtures(c, parts.parent(c, p));
@@ -393,15 +485,57 @@ class DynamicProgram {
             if (rows > 0 && cols > 0)
               dev_->check(pbd_get_dp_pointers(dev_->h, (int)n, c, p, m, Ix[n][c][p][m].ptr<int32_t>(), Iy[n][c][p][m].ptr<int32_t>(),
                                               Ik[n][c][p][m].ptr<int32_t>()));
+            dev_->fp_tab.push_back(fp3(Ix[n][c][p][m], Iy[n][c][p][m], Ik[n][c][p][m]));
           }
         }
       }
   }
   static int get_root(pbd_handle* h, int l, int c, float* v, int32_t* i) { return pbd_get_root(h, l, c, v, i); }
   static int get_root(pbd_handle* h, int l, int c, double* v, int32_t* i) { return pbd_get_root_f64(h, l, c, v, i); }
-  void argmin(Parts& /*parts*/, const vector2DMat& /*rootv*/, const vector2DMat& /*rooti*/, const vectorf /*scales*/,
-              const vector4DMat& /*Ix*/, const vector4DMat& /*Iy*/, const vector4DMat& /*Ik*/, vectorCandidate& candidates) {
-    const int capacity = 4096, mp = pbd_max_parts(dev_->h);
+  void argmin(Parts& parts, const vector2DMat& rootv, const vector2DMat& rooti, const vectorf scales,
+              const vector4DMat& Ix, const vector4DMat& Iy, const vector4DMat& Ik, vectorCandidate& candidates) {
+    const size_t nscales = dev_->cell_w.size();
+    if (rootv.size() != nscales || rooti.size() != nscales || Ix.size() != nscales || Iy.size() != nscales || Ik.size() != nscales)
+      throw Exception(PBD_ERR_ARG, "argmin(): table level count differs from the frame geometry of the device");
+    // boxes are scaled by scales[n] (src/DynamicProgram.cpp:198,238): the device scales them by its pyramid's
+    if (scales.size() != nscales || memcmp(scales.data(), dev_->scales.data(), nscales * sizeof(float)))
+      throw Exception(PBD_ERR_UNSUPPORTED, "argmin(): `scales` differ from the scales of the device's pyramid geometry");
+    if (dev_->fp_root.size() != nscales) dev_->fp_root.assign(nscales, std::vector<uint64_t>(parts.ncomponents(), 0));
+    size_t t = 0;
+    for (size_t n = 0; n < nscales; ++n)
+      for (int c = 0; c < parts.ncomponents(); ++c) {
+        const Mat &rv = rootv[n][c], &ri = rooti[n][c];
+        if (rv.rows != dev_->cell_h[n] || rv.cols != dev_->cell_w[n] || ri.rows != rv.rows || ri.cols != rv.cols)
+          throw Exception(PBD_ERR_ARG, "argmin(): a root table has the wrong size for the frame geometry of the device");
+        if (!rv.empty()) {
+          if (rv.depth() != (int)DataType<T>::type || ri.depth() != PBD_32S) throw Exception(PBD_ERR_ARG, "argmin(): root table element types");
+          const uint64_t fp = fingerprint(rv.template ptr<uint8_t>(), rv.bytes()) ^ (fingerprint(ri.ptr<uint8_t>(), ri.bytes()) * 3);
+          if (fp != dev_->fp_root[n][c]) {
+            dev_->check(set_root(dev_->h, (int)n, c, rv.template ptr<T>(), ri.ptr<int32_t>()));
+            dev_->fp_root[n][c] = fp;
+          }
+        }
+        for (int p = 1; p < parts.nparts(c); ++p) {
+          const int L = parts.nmixtures(c, parts.parent(c, p));
+          const bool given = (int)Ix[n][c].size() > p && (int)Ix[n][c][p].size() == L && (int)Iy[n][c][p].size() == L && (int)Ik[n][c][p].size() == L;
+          if (!given) {   // no table passed for this part: only legitimate for the tables this object's min() left on the device
+            if (!dev_->tables_resident) throw Exception(PBD_ERR_STATE, "argmin(): empty pointer tables and no min() of this engine to take them from");
+            continue;
+          }
+          for (int m = 0; m < L; ++m, ++t) {
+            const Mat &x = Ix[n][c][p][m], &y = Iy[n][c][p][m], &k = Ik[n][c][p][m];
+            if (x.rows != dev_->cell_h[n] || x.cols != dev_->cell_w[n] || y.rows != x.rows || y.cols != x.cols || k.rows != x.rows || k.cols != x.cols)
+              throw Exception(PBD_ERR_ARG, "argmin(): a pointer table has the wrong size for the frame geometry of the device");
+            if (x.empty()) continue;
+            const uint64_t fp = fp3(x, y, k);
+            if (t < dev_->fp_tab.size() && dev_->fp_tab[t] == fp) continue;
+            dev_->check(pbd_set_dp_pointers(dev_->h, (int)n, c, p, m, x.ptr<int32_t>(), y.ptr<int32_t>(), k.ptr<int32_t>()));
+            if (dev_->fp_tab.size() <= t) dev_->fp_tab.resize(t + 1, 0);
+            dev_->fp_tab[t] = fp;
+          }
+        }
+      }
+    const int capacity = dev_->max_candidates, mp = pbd_max_parts(dev_->h);
     std::vector<pbd_candidate_head> heads(capacity);
     std::vector<int32_t> boxes((size_t)capacity * mp * 4), locs((size_t)capacity * mp * 3);
     int n = 0;
@@ -421,7 +555,10 @@ class PartsBasedDetector {
   Parts parts_;
   int device_, conv_mode_, ncomponents_ = 0;
  public:
-  explicit PartsBasedDetector(int device = 0, int conv_mode = PBD_CONV_AUTO) : device_(device), conv_mode_(conv_mode) {}
+  int max_candidates_ = 4096;
+  explicit PartsBasedDetector(int device = 0, int conv_mode = PBD_CONV_AUTO, int max_candidates = 4096)
+      : device_(device), conv_mode_(conv_mode), max_candidates_(max_candidates) {}
+  Device& device() { return *dev_; }
   const std::string& name() const { return name_; }
   IFeatures& features() { return *features_; }
   IConvolutionEngine& convolutionEngine() { return *convolution_engine_; }
@@ -432,7 +569,7 @@ class PartsBasedDetector {
     name_ = model.name();
     ncomponents_ = model.ncomponents();
     // DataType<T>::type selects the instantiation (:110,113-117)
-    dev_ = std::make_shared<Device>(model, device_, conv_mode_, (int)DataType<T>::scalar);
+    dev_ = std::make_shared<Device>(model, device_, conv_mode_, (int)DataType<T>::scalar, max_candidates_);
     features_.reset(new HipHOGFeatures(dev_, model.binsize(), model.nscales()));
     convolution_engine_.reset(new HipConvolutionEngine(dev_));
     convolution_engine_->setFilters(model.filters());
@@ -444,7 +581,7 @@ class PartsBasedDetector {
   void detect(const Mat& im, const Mat& /*depth*/, vectorCandidate& candidates) {
     if (!dev_) throw Exception(PBD_ERR_STATE, "detect() before distributeModel()");
     if (im.depth() != PBD_8U) throw Exception(PBD_ERR_UNSUPPORTED, "Unsupported image type");
-    const int cap = 4096, mp = pbd_max_parts(dev_->h);
+    const int cap = dev_->max_candidates, mp = pbd_max_parts(dev_->h);
     std::vector<pbd_candidate_head> heads(cap);
     std::vector<int32_t> boxes((size_t)cap * mp * 4), locs((size_t)cap * mp * 3);
     int n = 0;

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3, GPU session 3: fold loader without scalar-load chains, targeted validation, flat plain loader, full-lane lpb,
+# round 3, GPU session 4: fold loader without scalar-load chains, targeted validation, flat plain loader, full-lane lpb,
 # residency-aware budgets: parity + traces + A/B
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/r03c
+OUT=$REPO/gpurun_out/r03d
 mkdir -p $OUT
 cd $REPO
 timeout 600 python -m pytest tests -m gpu -q -x -k "dp_min or dt2d or detect_exact or stagewise or f64" > $OUT/pytest_dp.log 2>&1
@@ -24,7 +24,7 @@ runtp() {
 runtp "fold auto"
 PBD_DP_MODE=1 runtp "legacy auto"
 PBD_DT_NO_RESIDENT=1 run "fold no-resident"
-for kb in 25 30 36 40; do PBD_DT_BUDGET_X_KB=$kb run "fold x budget ${kb}k"; done
+for kb in 25 32; do PBD_DT_BUDGET_X_KB=$kb run "fold x budget ${kb}k"; done
 for kb in 22 28; do PBD_DT_BUDGET_KB=$kb run "fold base ${kb}k"; PBD_DP_MODE=1 PBD_DT_BUDGET_KB=$kb run "legacy base ${kb}k"; done
 PBD_DT_SEG=20 run "fold seg20"
 PBD_DP_MODE=1 PBD_DT_SEG=20 run "legacy seg20"
