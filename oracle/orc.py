@@ -146,6 +146,23 @@ def dp_min_level(desc, comp, resp, correct_ptr=0, dtype=np.float32):
     return Ix, Iy, Ik, rv, ri
 
 
+def dp_argmin_level(desc, comp, level, scale, rootv, rooti, Ix, Iy, Ik, capacity=8192, dtype=np.float32):
+    """DynamicProgram<T>::argmin for one (level, component) on GIVEN tables (src/DynamicProgram.cpp:189-255):
+    rootv/rooti [H, W], Ix/Iy/Ik [planes, H, W] -> (heads, boxes, locs) in row-major root order."""
+    rootv = np.ascontiguousarray(rootv, dtype)
+    rooti, Ix, Iy, Ik = (np.ascontiguousarray(a, np.int32) for a in (rooti, Ix, Iy, Ik))
+    H, W = rootv.shape
+    mp = lib().orc_max_parts(C.byref(desc))
+    heads = np.zeros(capacity, HEAD_DTYPE)
+    boxes = np.zeros((capacity, mp, 4), np.int32)
+    locs = np.zeros((capacity, mp, 3), np.int32)
+    cnt = C.c_int(0)
+    _fn("orc_dp_argmin_level", dtype)(C.byref(desc), comp, level, C.c_float(scale), _p(rootv), _p(rooti), _p(Ix), _p(Iy), _p(Ik),
+                                      H, W, mp, _p(heads), _p(boxes), _p(locs), capacity, C.byref(cnt))
+    n = min(cnt.value, capacity)
+    return heads[:n].copy(), boxes[:n].copy(), locs[:n].copy()
+
+
 class Frame:
     """Intermediates of one orc_detect_u8 run."""
 

@@ -461,6 +461,9 @@ void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels,
 // whole tap loaded from the L2-resident [tap][channel][nfpad] array one tap ahead, ping-pong registers.
 // Accumulation is a k-ordered fma chain (half, tap, channel): not the reference's order, tolerance-based.
 // ---------------------------------------------------------------------------
+#ifndef PBD_CONV_STAGGER_TICKS
+#define PBD_CONV_STAGGER_TICKS 0   // product default (set from the measurement)
+#endif
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Mfma16;
@@ -479,9 +482,22 @@ template <typename T, int KH, int KW, int NHALF, int WPE, int NTW = 1>   // WPE:
 __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __restrict__ tiles,
                                                      const LevelDev* __restrict__ levels,
                                                      const T* __restrict__ feat, const T* __restrict__ wT,
-                                                     T* __restrict__ resp, int nf, int nfpad, int ntiles_total) {
+                                                     T* __restrict__ resp, int nf, int nfpad, int ntiles_total, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Mfma16<T> MM;
+  // Every workgroup does the same work, so the workgroups that start together on a CU (the first generation: one per
+  // residency slot, all dispatched at t = 0) stage, multiply and store IN PHASE, and so does every later generation:
+  // the MFMA pipe idles while all of them stage / store (measured: 69 % busy, 25 % of a workgroup's life is outside
+  // the K loops).  The first generation is started `stagger` wall-clock ticks (10 ns) apart per residency slot, once;
+  // from then on slots free up at different times and the phases interleave.
+  if (stagger > 0) {
+    const unsigned lin0 = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned slot = lin0 >> 8;                       // workgroups 256 s .. 256 s + 255: the s-th workgroup of each CU (observed dispatch order)
+    if (slot >= 1 && slot < 5) {
+      const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)stagger * slot;
+      while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   constexpr int TW = CT + KW - 1, TH = CT + KH - 1, NTAP = KH * KW;
   // channels per pass, LDS cell stride, k-steps per tap.  Float: stride CH + 2 = 18 dwords: the 32 lanes of one LDS
   // access group (16 cells x 2 channels) then hit 32 different banks (16 * 18 mod 32 are the 16 even residues); with
@@ -629,6 +645,10 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   CONV_STAMP(6);
 }
 
+static int conv_stagger_ticks() {   // wall-clock ticks (10 ns) between the starts of a CU's first-generation workgroups
+  static const int v = PBD_PROBE_ENV("PBD_CONV_STAGGER_US") ? (int)(atof(PBD_PROBE_ENV("PBD_CONV_STAGGER_US")) * 100.0) : PBD_CONV_STAGGER_TICKS;
+  return v;
+}
 template <typename T, int NHALF, int WPE, int NTW = 1>
 static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
                                  const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
@@ -637,7 +657,8 @@ static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelD
   optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>, lds);
   dim3 grid((ntiles + 7) / 8 * 8, (nf + 16 * NTW - 1) / (16 * NTW));   // tiles padded to a multiple of 8 (XCD-aware mapping in the kernel)
   static const int prio_mode = PBD_PROBE_ENV("PBD_CONV_PRIO") ? atoi(PBD_PROBE_ENV("PBD_CONV_PRIO")) : 0;   // probe build only
-  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles);
+  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles,
+                     (int)((size_t)grid.x * grid.y > 1280 ? conv_stagger_ticks() : 0));
 }
 
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,

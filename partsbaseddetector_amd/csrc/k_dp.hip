@@ -516,7 +516,7 @@ void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks
 template <typename T>
 __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, int njobs, double thresh,
                                               int* __restrict__ count, CandRec* __restrict__ rec, int capacity,
-                                              const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
+                                              const FoldJob* __restrict__ folds, const float* __restrict__ biasw, int rescan) {
   const unsigned gid = blockIdx.x * 256u + threadIdx.x;
   int lo = 0, hi = njobs - 1;
   while (lo < hi) {
@@ -529,6 +529,15 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
   T v;
   int bi = 0;
   const T bias = J.bias;                             // `T bias = root.bias(0)[0]` (:165)
+  if (rescan) {
+    // root tables handed in by the caller (pbd_set_root): only the threshold and the compaction are redone
+    v = ((const T*)J.rootv)[cell];
+    if ((double)v > thresh) {
+      const int idx = atomicAdd(count, 1);
+      if (idx < capacity) { CandRec r; r.level = J.level; r.comp = J.comp; r.y = cell / J.W; r.x = cell - r.y * J.W; rec[idx] = r; }
+    }
+    return;
+  }
   if (J.fold >= 0) {
     // fold mode: the root's accumulated score is built here from its raw responses and its children's messages
     constexpr int M = PBD_FOLD_MAXMIX;
@@ -573,10 +582,10 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
 }
 
 void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
-                 int capacity, int ts, const FoldJob* folds, const float* biasw, hipStream_t s) {
+                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, hipStream_t s) {
   if (njobs <= 0 || total_cells == 0) return;
-  if (ts == 8) hipLaunchKernelGGL(k_root<double>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity, folds, biasw);
-  else hipLaunchKernelGGL(k_root<float>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity, folds, biasw);
+  if (ts == 8) hipLaunchKernelGGL(k_root<double>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity, folds, biasw, rescan);
+  else hipLaunchKernelGGL(k_root<float>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity, folds, biasw, rescan);
 }
 
 // ---------------------------------------------------------------------------

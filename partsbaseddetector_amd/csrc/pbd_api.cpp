@@ -579,8 +579,6 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   // fold x pass of the 4-part rounds, 1772 blocks for 1536 slots at 25 KB: 100 us instead of 45).  Blocks that hold
   // whole rows of all mixtures quantise badly (12 lines where 15 would fit), so such a launch gets the smallest
   // larger budget at which its blocks are resident together (fewer, larger blocks; fewer blocks per CU).
-  int first_active = 0;
-  for (int l = 0; l < n; ++l) if (h->lv[l].active && h->lv[l].cw > 0 && h->lv[l].ch > 0) { first_active = l; break; }
   int ncu = 256;
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, h->opt.device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
   auto count_blocks = [&](const std::vector<int>& rnd, size_t budget, bool fold_x, bool ypass, size_t* lds_out) {
@@ -606,37 +604,30 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     *lds_out = lds;
     return nb;
   };
-  // Launch geometry: among the budgets around the base one (and, for plain lines, with or without the full-lane
-  // rounding of the lines per block) take the one whose blocks are all resident at once and whose longest segment
-  // (elements per lane) is the shortest; no candidate resident: the base budget.
+  // Launch geometry: the base budget with full-lane lines per block if all blocks of the launch are then resident at
+  // once; else the same without the rounding; else the smallest larger budget that makes them resident (fewer, larger
+  // blocks; up to 1.6 x); else the base.  (Measured: budgets BELOW the base — more, shorter blocks, 8 per CU — are
+  // slower: dp_min 0.79 / 0.82 ms fold / three-kernel against 0.72 / 0.76, more contention per CU.)
   struct Geo { size_t budget; bool round; };
   auto launch_geometry = [&](const std::vector<int>& rnd, size_t base, bool fold_x, bool ypass) {
-    Geo best{base, true};
-    if (PBD_PROBE_ENV("PBD_DT_NO_RESIDENT")) return best;
+    const Geo dflt{base, true};
+    if (PBD_PROBE_ENV("PBD_DT_NO_RESIDENT")) return dflt;
     const int waves_blk = std::max(1, h->dt_nt / 64);
-    double best_cost = 1e30;
-    for (int rr = 1; rr >= 0; --rr) {
-      if (fold_x && !rr) break;          // rounding only concerns plain lines
-      g_dt_round = rr != 0;
-      for (size_t b = std::max(dt_need, base * 4 / 5); b <= base * 8 / 5 && b <= 150 * 1024; b += 1024) {
-        size_t lds = 0;
-        const size_t nb = count_blocks(rnd, b, fold_x, ypass, &lds);
-        const size_t per_cu = std::min<size_t>(160 * 1024 / std::max<size_t>(lds, 1), 24 / waves_blk);
-        if (nb > per_cu * ncu) continue;
-        // cost ~ the longest segment of the launch's largest level (its blocks are the bulk), a mild preference for
-        // the base budget (co-residency with the other kernels of the frames in flight was tuned there)
-        const int len0 = ypass ? h->lv[first_active].ch : h->lv[first_active].cw;
-        int nm = 0;
-        for (int fp : rnd) nm += h->parts[fp].K;
-        const DtGroup g0 = fold_x ? dt_group(0, h->parts[rnd[0]].K, ypass ? h->lv[first_active].cw : h->lv[first_active].ch, len0, b, h->ts, h->dt_nt, h->dt_seg, 0)
-                                  : dt_group(0, nm, ypass ? h->lv[first_active].cw : h->lv[first_active].ch, len0, b, h->ts, h->dt_nt, h->dt_seg);
-        const int P = std::max(1, std::min(h->dt_nt / g0.lpb, len0 / 8));
-        const double cost = (double)len0 / P + 0.15 * std::abs((double)b - (double)base) / 1024.0;
-        if (cost < best_cost) { best_cost = cost; best = Geo{b, rr != 0}; }
-      }
+    auto resident = [&](size_t b, bool rnd_lanes) {
+      g_dt_round = rnd_lanes;
+      size_t lds = 0;
+      const size_t nb = count_blocks(rnd, b, fold_x, ypass, &lds);
+      g_dt_round = true;
+      const size_t per_cu = std::min<size_t>(160 * 1024 / std::max<size_t>(lds, 1), 24 / waves_blk);
+      return nb <= per_cu * ncu;
+    };
+    if (resident(base, true)) return dflt;
+    if (!fold_x && resident(base, false)) return Geo{base, false};
+    for (size_t b = base + 1024; b <= base * 8 / 5 && b <= 150 * 1024; b += 1024) {
+      if (resident(b, true)) return Geo{b, true};
+      if (!fold_x && resident(b, false)) return Geo{b, false};
     }
-    g_dt_round = true;
-    return best;
+    return dflt;
   };
   for (size_t r = 0; r < h->rounds.size(); ++r) {
     const std::vector<int>& rnd = h->rounds[r];
@@ -854,18 +845,25 @@ static int run_dp_min(pbd_handle* h) {
   }
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
   launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
-              h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, h->stream);
+              h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 0, h->stream);
   if (dpt) hipEventRecord(h->ev_dp1, h->stream);
   h->dp_timed = dpt;
   LAUNCHCHK(h, "DP min");
   h->have_dp = true;
   h->ext_ptr = false;   // back-tracking reads this min()'s own tables again
+  h->root_dirty = false;
   return PBD_OK;
 }
 
 static const int kFirstCopy = PBD_FIRST_COPY;  // records fetched together with the count
 
 static int run_argmin_enqueue(pbd_handle* h) {
+  if (h->root_dirty) {   // root tables injected since min(): the hits are those of the tables now on the device
+    hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
+    launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
+                h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 1, h->stream);
+    h->root_dirty = false;
+  }
   launch_backtrack(h->d_cand_count, h->d_cand_rec, h->opt.max_candidates, h->d_back, h->md.ncomponents, h->d_parent,
                    h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, h->d_cand_out, h->cand_stride, h->ts, h->d_flat,
                    h->d_depth, h->max_depth, (int)h->parts.size(), h->d_scr_base, h->d_dt_ixT, h->d_dt_iy,
@@ -998,6 +996,7 @@ static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
   h->frames_on_plan++;
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = true;
   h->ext_ptr = false;
+  h->root_dirty = false;
   h->dp_timed = false;
   h->pending = true;
   return PBD_OK;
@@ -1338,6 +1337,7 @@ static int set_root_(pbd_handle* h, int level, int component, const void* rootv,
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (rootv) HIPCHK(h, hipMemcpy(h->d_rootv + (L.cell_off * h->md.ncomponents + component * HW) * ts, rootv, HW * ts, hipMemcpyHostToDevice));
   if (rooti) HIPCHK(h, hipMemcpy(h->d_rooti + L.cell_off * h->md.ncomponents + component * HW, rooti, HW * 4, hipMemcpyHostToDevice));
+  h->root_dirty = true;
   return PBD_OK;
 }
 int pbd_set_root(pbd_handle* h, int level, int component, const float* rootv, const int32_t* rooti) { return set_root_(h, level, component, rootv, rooti, 4); }

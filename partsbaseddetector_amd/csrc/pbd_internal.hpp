@@ -209,6 +209,7 @@ struct pbd_handle {
   // reads them instead of the DT planes until the next min()
   int16_t* d_extx = nullptr; int16_t* d_exty = nullptr; unsigned long long* d_ext_base = nullptr;
   bool ext_ptr = false;
+  bool root_dirty = false;   // pbd_set_root since the last min(): argmin re-thresholds the root tables first
 };
 
 // ---- scalar helpers: the reference's std:: overloads resolve on T ---------------
@@ -281,7 +282,7 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt);
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
                    int ts, hipStream_t s);
 void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
-                 int capacity, int ts, const FoldJob* folds, const float* biasw, hipStream_t s);
+                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, hipStream_t s);
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
                       char* out, size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,

@@ -1,5 +1,7 @@
 // demo.cpp — the reference's canonical caller (src/demo.cpp:55-118) against the MI355X path:
 //   pbd_demo model.bin image.raw width height channels [stagewise|double|stagewise-double]
+//   pbd_demo model.bin image.raw width height channels perturb-features <responses-out.bin>
+//   pbd_demo model.bin image.raw width height channels oracle-responses <responses-in.bin>
 // deserialize -> distributeModel -> detect -> Candidate::sort, then prints the candidates (the
 // reference shows them in a window; here they go to stdout so tests can compare them).
 // `stagewise` walks pyramid -> pdf -> min -> argmin through the interface classes instead of the
@@ -11,8 +13,14 @@
 #include "pbd_filestorage.hpp"
 using namespace pbd;
 
+// The stage interfaces process THEIR ARGUMENTS (include/IConvolutionEngine.hpp:56, include/DynamicProgram.hpp:74-75):
+//   perturb:  the feature pyramid is halved in place between pyramid() and pdf(); the responses of the first and the
+//             last level go to `io_file` (the test compares them with the oracle's filter bank on the halved features);
+//   oracle:   the scores min() transforms are read from `io_file` (random planes written by the test) instead of coming
+//             from pdf(), and the tables min() returns are edited before argmin() (a root score raised, part 1's x
+//             pointer at that cell redirected): the candidates must be those of the edited tables.
 template <typename T>
-static void run(Model& model, const Mat& im, bool stagewise) {
+static void run(Model& model, const Mat& im, bool stagewise, int special = 0, const char* io_file = nullptr) {
   PartsBasedDetector<T> pbd(0, PBD_CONV_EXACT);
   pbd.distributeModel(model);
   vectorCandidate candidates;
@@ -21,8 +29,33 @@ static void run(Model& model, const Mat& im, bool stagewise) {
     pbd.features().pyramid(im, pyramid);
     vector2DMat pdf, rootv, rooti;
     vector4DMat Ix, Iy, Ik;
-    pbd.convolutionEngine().pdf(pyramid, pdf);                                  // src/PartsBasedDetector.cpp:78
+    if (special == 1)
+      for (Mat& f : pyramid)
+        for (int i = 0; i < f.rows * f.cols; ++i) f.ptr<T>()[i] *= (T)0.5;
+    if (special == 2) {
+      FILE* f = fopen(io_file, "rb");
+      if (!f) { fprintf(stderr, "cannot open %s\n", io_file); exit(6); }
+      pdf.assign(pyramid.size(), vectorMat(model.filters().size()));
+      for (size_t l = 0; l < pyramid.size(); ++l)
+        for (Mat& r : pdf[l]) {
+          r.create(pyramid[l].rows, pyramid[l].cols / 32, DataType<T>::type);
+          if (!r.empty() && fread(r.ptr<T>(), sizeof(T), (size_t)r.rows * r.cols, f) != (size_t)r.rows * r.cols) { fprintf(stderr, "short read\n"); exit(6); }
+        }
+      fclose(f);
+    } else {
+      pbd.convolutionEngine().pdf(pyramid, pdf);                                // src/PartsBasedDetector.cpp:78
+    }
+    if (special == 1) {
+      FILE* f = fopen(io_file, "wb");
+      for (size_t l : {(size_t)0, pyramid.size() - 1})
+        for (const Mat& r : pdf[l]) fwrite(r.ptr<T>(), sizeof(T), (size_t)r.rows * r.cols, f);
+      fclose(f);
+    }
     pbd.dp().min(pbd.parts(), pdf, Ix, Iy, Ik, rootv, rooti);                   // :83, the reference's signature
+    if (special == 2) {
+      rootv[0][0].template at<T>(0, 0) = (T)1e6;
+      for (Mat& x : Ix[0][0][1]) x.at<int32_t>(0, 0) = x.cols - 1;
+    }
     // the tables came back in the reference's shapes: [level][component][part][parent mixture]
     if (Ix.size() != pyramid.size() || Ix[0][0].size() != (size_t)pbd.parts().nparts(0) || !Ix[0][0][0].empty() ||
         Ix[0][0][1].empty() || Ix[0][0][1][0].rows != pdf[0][0].rows || rootv[0][0].cols != pdf[0][0].cols) {
@@ -54,7 +87,7 @@ static void run(Model& model, const Mat& im, bool stagewise) {
 }
 
 int main(int argc, char** argv) {
-  if (argc != 6 && argc != 7) {
+  if (argc < 6 || argc > 8) {
     printf("Usage: pbd_demo model_file image.raw width height channels [stagewise|double|stagewise-double]\n");
     exit(-1);
   }
@@ -75,11 +108,13 @@ int main(int argc, char** argv) {
     exit(-4);
   }
   fclose(f);
-  const std::string mode = argc == 7 ? argv[6] : "";
-  const bool stagewise = mode.find("stagewise") != std::string::npos;
+  const std::string mode = argc >= 7 ? argv[6] : "";
+  const int special = mode == "perturb-features" ? 1 : mode == "oracle-responses" ? 2 : 0;
+  if (special && argc != 8) { printf("%s needs a file argument\n", mode.c_str()); exit(-1); }
+  const bool stagewise = special || mode.find("stagewise") != std::string::npos;
   try {
     if (mode.find("double") != std::string::npos) run<double>(model, im, stagewise);
-    else run<float>(model, im, stagewise);
+    else run<float>(model, im, stagewise, special, special ? argv[7] : nullptr);
   } catch (const Exception& e) {
     printf("error %d: %s\n", e.code, e.what());
     return 1;
