@@ -645,10 +645,7 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   CONV_STAMP(6);
 }
 
-static int conv_stagger_ticks() {   // wall-clock ticks (10 ns) between the starts of a CU's first-generation workgroups
-  static const int v = PBD_PROBE_ENV("PBD_CONV_STAGGER_US") ? (int)(atof(PBD_PROBE_ENV("PBD_CONV_STAGGER_US")) * 100.0) : PBD_CONV_STAGGER_TICKS;
-  return v;
-}
+int g_conv_stagger_ticks = PBD_CONV_STAGGER_TICKS;   // set by the host side (tuning knob PBD_CONV_STAGGER_US in the probe / tuning builds)
 template <typename T, int NHALF, int WPE, int NTW = 1>
 static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
                                  const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
@@ -658,7 +655,7 @@ static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelD
   dim3 grid((ntiles + 7) / 8 * 8, (nf + 16 * NTW - 1) / (16 * NTW));   // tiles padded to a multiple of 8 (XCD-aware mapping in the kernel)
   static const int prio_mode = PBD_PROBE_ENV("PBD_CONV_PRIO") ? atoi(PBD_PROBE_ENV("PBD_CONV_PRIO")) : 0;   // probe build only
   hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles,
-                     (int)((size_t)grid.x * grid.y > 1280 ? conv_stagger_ticks() : 0));
+                     (int)((size_t)grid.x * grid.y > 1280 ? g_conv_stagger_ticks : 0));
 }
 
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,

@@ -810,8 +810,10 @@ static int run_hog(pbd_handle* h) {
   return PBD_OK;
 }
 
+extern int g_conv_stagger_ticks;   // k_conv.hip
 static int run_pdf(pbd_handle* h) {
   const pbd_model_desc& m = h->md;
+  if (const char* e = PBD_PROBE_ENV("PBD_CONV_STAGGER_US")) g_conv_stagger_ticks = (int)(atof(e) * 100.0);
   if (h->conv_mode == PBD_CONV_MFMA)
     if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT, (double*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
     else {

@@ -530,6 +530,10 @@ def test_cpp_stage_adaptors_honour_their_arguments(gpu_required, orc, tmp_path):
     rng = np.random.default_rng(11)
     resp = [rng.normal(0, 1, (nf, g["cell_h"][l], g["cell_w"][l])).astype(np.float32) for l in range(nl)]
     np.concatenate([r.ravel() for r in resp]).tofile(str(tmp_path / "scores.bin"))
+    # a threshold that leaves a few dozen candidates on these scores (the 99.5th percentile of their root scores)
+    m.thresh = float(np.float32(np.percentile(np.concatenate([orc.dp_min_level(m.to_desc(), 0, resp[l])[3].ravel() for l in range(nl)]), 99.5)))
+    m.save(str(tmp_path / "model2.bin"))
+    base[1] = str(tmp_path / "model2.bin")
     desc = m.to_desc()
     allc = []
     for l in range(nl):
