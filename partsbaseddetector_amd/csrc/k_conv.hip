@@ -454,16 +454,16 @@ void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels,
 // Measured on MI355X (tests/tools/mfma64_probe.hip, mfma16_probe.hip): f64 64 cycles per instruction and
 // SIMD = 72 TFLOP/s; operand layout A[i = l&15][k = l>>4], B[k = l>>4][j = l&15] for both; result
 // D[i = 4*reg + (l>>4)][j = l&15] (f64) / D[i = 4*(l>>4) + reg][j = l&15] (f32).
-// Workgroup = 4 waves: 16x16 cells x ONE 16-filter n-tile, grid = (tiles, nfpad/16).  Wave w owns cell
-// rows 4w..4w+3 = four 16-cell M-tiles = four accumulators.  The 20x20-cell feature tile is staged in
+// Workgroup = 4 waves: 16x16 cells x ONE 16-filter n-tile, grid = (tiles, nfpad/16).  The VALID cells of the tile
+// (levels are ragged: the last tile of a row / column is cut by the level's edge) are numbered row-major and cut
+// into 16-cell M-tiles; wave w owns M-tiles w, w + 4, w + 8, w + 12 = up to four accumulators, and an M-tile beyond
+// the last valid cell issues no MFMAs (13 % of the MFMA work of a 640x480 pyramid was padding when an M-tile was a
+// fixed 16-cell row segment).  The 20x20-cell feature tile is staged in
 // NHALF channel groups (double: two 16-channel halves, 54 KB -> three workgroups per CU), cell stride
 // CH+1 elements (conflict-free across the 16 cells of an M-tile).  B: one element per lane and k-step, a
 // whole tap loaded from the L2-resident [tap][channel][nfpad] array one tap ahead, ping-pong registers.
 // Accumulation is a k-ordered fma chain (half, tap, channel): not the reference's order, tolerance-based.
 // ---------------------------------------------------------------------------
-#ifndef PBD_CONV_STAGGER_TICKS
-#define PBD_CONV_STAGGER_TICKS 0   // product default (set from the measurement)
-#endif
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Mfma16;
@@ -482,22 +482,9 @@ template <typename T, int KH, int KW, int NHALF, int WPE, int NTW = 1>   // WPE:
 __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __restrict__ tiles,
                                                      const LevelDev* __restrict__ levels,
                                                      const T* __restrict__ feat, const T* __restrict__ wT,
-                                                     T* __restrict__ resp, int nf, int nfpad, int ntiles_total, int stagger) {
+                                                     T* __restrict__ resp, int nf, int nfpad, int ntiles_total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Mfma16<T> MM;
-  // Every workgroup does the same work, so the workgroups that start together on a CU (the first generation: one per
-  // residency slot, all dispatched at t = 0) stage, multiply and store IN PHASE, and so does every later generation:
-  // the MFMA pipe idles while all of them stage / store (measured: 69 % busy, 25 % of a workgroup's life is outside
-  // the K loops).  The first generation is started `stagger` wall-clock ticks (10 ns) apart per residency slot, once;
-  // from then on slots free up at different times and the phases interleave.
-  if (stagger > 0) {
-    const unsigned lin0 = blockIdx.x + blockIdx.y * gridDim.x;
-    const unsigned slot = lin0 >> 8;                       // workgroups 256 s .. 256 s + 255: the s-th workgroup of each CU (observed dispatch order)
-    if (slot >= 1 && slot < 5) {
-      const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)stagger * slot;
-      while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   constexpr int TW = CT + KW - 1, TH = CT + KH - 1, NTAP = KH * KW;
   // channels per pass, LDS cell stride, k-steps per tap.  Float: stride CH + 2 = 18 dwords: the 32 lanes of one LDS
   // access group (16 cells x 2 channels) then hit 32 different banks (16 * 18 mod 32 are the 16 even residues); with
@@ -541,8 +528,18 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[nt][m][r] = (T)0;
-  const T* abase = ft + ((4 * wave) * TW + ai) * CS + ak;   // M-tile m adds m*TW*CS
-  const int mvalid = __builtin_amdgcn_readfirstlane(min(max(H - (t.y0 + 4 * wave), 0), 4));   // M-tiles (= cell rows) of this wave inside the level
+  // packed M-tiles: valid cell c = 16 * (wave + 4 m) + ai of the vh x vw valid region -> (c / vw, c % vw); cells past the
+  // last one repeat it (their products are never stored)
+  const int vw = min(CT, W - t.x0), vh = min(CT, H - t.y0), ncell = vw * vh;
+  const int nmt = (ncell + 15) >> 4;                                                        // M-tiles of the tile
+  const int mvalid = __builtin_amdgcn_readfirstlane(max(0, min(4, (nmt - wave + 3) >> 2)));   // M-tiles of this wave
+  int aoff[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int c = min(16 * (wave + 4 * m) + ai, ncell - 1);
+    const int cy = c / vw, cx = c - cy * vw;
+    aoff[m] = (cy * TW + cx) * CS + ak;
+  }
 
 #pragma unroll 1
   for (int half = 0; half < NHALF; ++half) {
@@ -592,12 +589,12 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
     };
     auto mma_tap = [&](const T (&bw)[NTW][KS], int tap) {
       const int ti = tap / KW, tj = tap - ti * KW;
-      const T* a = abase + (ti * TW + tj) * CS;
+      const T* a = ft + (ti * TW + tj) * CS;
 #pragma unroll
       for (int u = 0; u < KS; ++u) {
         T av[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) av[m] = a[m * TW * CS + 4 * u];    // one A element per M-tile, shared by the workgroup's n-tiles
+        for (int m = 0; m < 4; ++m) av[m] = a[aoff[m] + 4 * u];    // one A element per M-tile, shared by the workgroup's n-tiles
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
@@ -627,8 +624,10 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   // wave and a wave's LDS operations execute in order, so the n-tiles simply follow each other.
   T* R = resp + lv.cell_off * nf;
   T* tr = ft + wave * (16 * 65);           // per-wave [16 filters][64 cells + 1]
-  const int py = t.y0 + 4 * wave + (lane >> 4), pxx = t.x0 + (lane & 15);
-  const bool pvalid = (py < H && pxx < W);
+  // lane -> slot (M-tile lane >> 4, row lane & 15) -> packed cell -> (row, column) of the level
+  const int pc = 16 * (wave + 4 * (lane >> 4)) + (lane & 15);
+  const int pcy = pc / vw, py = t.y0 + pcy, pxx = t.x0 + (pc - pcy * vw);
+  const bool pvalid = pc < ncell;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
@@ -645,7 +644,6 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   CONV_STAMP(6);
 }
 
-int g_conv_stagger_ticks = PBD_CONV_STAGGER_TICKS;   // set by the host side (tuning knob PBD_CONV_STAGGER_US in the probe / tuning builds)
 template <typename T, int NHALF, int WPE, int NTW = 1>
 static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
                                  const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
@@ -654,8 +652,7 @@ static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelD
   optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>, lds);
   dim3 grid((ntiles + 7) / 8 * 8, (nf + 16 * NTW - 1) / (16 * NTW));   // tiles padded to a multiple of 8 (XCD-aware mapping in the kernel)
   static const int prio_mode = PBD_PROBE_ENV("PBD_CONV_PRIO") ? atoi(PBD_PROBE_ENV("PBD_CONV_PRIO")) : 0;   // probe build only
-  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles,
-                     (int)((size_t)grid.x * grid.y > 1280 ? g_conv_stagger_ticks : 0));
+  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles);
 }
 
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,

@@ -451,6 +451,17 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     for (int y = 0; y < L.ch; y += 16)
       for (int x = 0; x < L.cw; x += 16) ct.push_back(ConvTile{l, y, x, 0});
   }
+  // The filter bank runs tile position 8 g + x of this list on XCD x (k_conv.hip: groups of 8 tiles, all n-tiles of a
+  // tile on one XCD).  Horizontally adjacent tiles write the two halves of the same 128-byte lines of every response
+  // plane (a tile row is 64 bytes); in list order they sat on DIFFERENT XCDs, whose L2s cannot merge the halves
+  // (WRITE_SIZE 124 MB for 88 MB of responses).  Pairs of neighbours (2k, 2k + 1) go to the same XCD, one group apart.
+  {
+    std::vector<ConvTile> o(ct);
+    const size_t full = ct.size() / 16 * 16;
+    for (size_t b = 0; b < full; b += 16)
+      for (size_t x = 0; x < 8; ++x) { o[b + x] = ct[b + 2 * x]; o[b + 8 + x] = ct[b + 2 * x + 1]; }
+    ct.swap(o);
+  }
   h->n_hog_tiles = (int)ht.size();
   h->n_conv_tiles = (int)ct.size();
   if ((rc = dev_upload(h, &h->d_hog_tiles, ht))) return rc;
@@ -611,7 +622,11 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   struct Geo { size_t budget; bool round; };
   auto launch_geometry = [&](const std::vector<int>& rnd, size_t base, bool fold_x, bool ypass) {
     const Geo dflt{base, true};
-    if (PBD_PROBE_ENV("PBD_DT_NO_RESIDENT")) return dflt;
+    // fold launches keep the base budget: their blocks hold whole rows of all mixtures and quantise badly (1772 blocks
+    // for 1536 slots in the 4-part rounds), but the budgets that make them resident at once (36-40 KB, 4 per CU) cost
+    // more with four frames in flight than the second wave of blocks does (measured: 1 170 frames/s and dp_min 0.70 ms
+    // at 40 KB, 1 181 / 0.73 at 28 KB, 1 235 / 0.725 at the base 25 KB)
+    if (fold_x || PBD_PROBE_ENV("PBD_DT_NO_RESIDENT")) return dflt;
     const int waves_blk = std::max(1, h->dt_nt / 64);
     auto resident = [&](size_t b, bool rnd_lanes) {
       g_dt_round = rnd_lanes;
@@ -810,10 +825,8 @@ static int run_hog(pbd_handle* h) {
   return PBD_OK;
 }
 
-extern int g_conv_stagger_ticks;   // k_conv.hip
 static int run_pdf(pbd_handle* h) {
   const pbd_model_desc& m = h->md;
-  if (const char* e = PBD_PROBE_ENV("PBD_CONV_STAGGER_US")) g_conv_stagger_ticks = (int)(atof(e) * 100.0);
   if (h->conv_mode == PBD_CONV_MFMA)
     if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT, (double*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
     else {
