@@ -325,7 +325,7 @@ def main():
         if os.path.exists(tpath) and (W, H, args.mixtures, args.dtype) == (640, 480, 6, "f32"):
             tj = json.load(open(tpath))
             traffic = tj["hbm_bytes_per_frame_corrected"]
-            traffic_source = (f"profiles/traffic_dp.json ({tj.get('tag', '?')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+            traffic_source = (f"profiles/traffic_dp.json ({tj.get('round', '?')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               f"command, FETCH x2 per MI355X_MICROARCH.md; committed file, not measured in this run)")
         if stage["dp_min"] >= stage["pdf"]:
             roof = {"kernel": "dp_min stage (distance-transform passes + mixture reduce + root) per frame", "bound": "hbm",

@@ -108,7 +108,11 @@ typedef struct pbd_options {
   int32_t reserved[2];   /* [0]: ignored (rounds 1-2: DP level groups on separate streams, removed);
                             [1]: dp_mode — 0: a part's messages are folded by its own x pass wherever the model allows it
                                  (no filter id shared inside a component, <= 8 mixtures per part, <= 8 children per part),
-                                 1: the three-kernel structure (x pass, y pass, reduce + accumulated planes) for every model */
+                                 1: the three-kernel structure (x pass, y pass, reduce + accumulated planes) for every model,
+                                 2: fold + the compact memory plan (stage buffers that are never live together share
+                                    memory; automatic for large frames, e.g. 1920x1080: 1.47 GB instead of 3.3 GB per
+                                    handle): after min() / detect() the image, feature and response getters answer
+                                    PBD_ERR_STATE                                                                       */
 } pbd_options;
 /* The layout of pbd_options and pbd_model_desc is frozen from PBD_ABI_VERSION 3 on: new options take a reserved slot
  * or a new entry point, fields are never inserted.  pbd_abi_version() returns the version the LIBRARY was built with;

@@ -184,6 +184,11 @@ static int ingest_model(pbd_handle* h, const pbd_model_desc* m) {
   // fold mode (messages folded by the consumer, no accumulated planes): needs every part's accumulator to be its own
   // (no filter id shared inside a component: the reference's ncscores is indexed by FILTER id, so two parts with
   // one id would share an accumulator) and its mixtures / its children's to fit the register arrays of the fold
+  {
+    std::vector<int> fuse(m->nfilters, 0);
+    h->unique_filters = true;
+    for (int fm = 0; fm < nm; ++fm) if (++fuse[h->filterid[fm]] > 1) h->unique_filters = false;   // (also across components: face-like models share a pool)
+  }
   h->fold = !aliasing && h->opt.reserved[1] != 1;
   if (const char* e = PBD_PROBE_ENV("PBD_DP_MODE")) h->fold = h->fold && atoi(e) != 1;   // A/B: the three-kernel structure
   {
@@ -422,11 +427,35 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   if (cells >= (1u << 31)) return fail(h, PBD_ERR_UNSUPPORTED, "frame too large");
   int rc;
   if ((rc = dev_alloc(h, &h->d_img, (size_t)w * hgt * cn))) return rc;
-  if ((rc = dev_alloc(h, &h->d_pyr, pyr))) return rc;
   const size_t ts = (size_t)h->ts;   // sizeof(T); T buffers are char* addressed as elements * ts
-  if ((rc = dev_alloc(h, &h->d_feat, cells * PBD_FLEN * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_resp, cells * m.nfilters * ts))) return rc;
-  if ((rc = dev_alloc(h, &h->d_pk, cells * std::max(h->nplanes, 1)))) return rc;
+  // Memory plan.  Default: every stage buffer has its own allocation and stays valid after detect() (the parity
+  // tests read features / responses / tables of a finished frame).  Compact (fold structure, every filter id used by
+  // one mixture only; chosen automatically for large frames — the responses alone over 400 MB, e.g. 1920x1080 —
+  // or forced with dp_mode 2): buffers that are never live together share memory:
+  //   * a mixture's distance-transformed scores overwrite its own raw response plane (its x pass has consumed the
+  //     plane before its y pass writes it; nothing else reads the raw plane of a non-root part);
+  //   * the level images + HOG features (dead once the filter bank has run) share one region with the x pass's
+  //     per-round output + the Ik planes (first written by the DP);
+  // 1920x1080, person model: 1.47 GB instead of 3.3 GB.  After min() the image / feature / response getters of a
+  // compact handle answer PBD_ERR_STATE (the buffers have been reused).
+  size_t act_cells0 = 0;
+  for (int l = 0; l < n; ++l) if (h->lv[l].active) act_cells0 += (size_t)h->lv[l].cw * h->lv[l].ch;
+  size_t maxK0 = 1;
+  for (auto& rnd : h->rounds) { size_t k = 0; for (int fp : rnd) k += h->parts[fp].K; maxK0 = std::max(maxK0, k); }
+  h->compact = h->fold && h->unique_filters && (h->opt.reserved[1] == 2 || (h->opt.reserved[1] == 0 && cells * m.nfilters * ts > ((size_t)400 << 20)));
+  const size_t pk_bytes = cells * std::max(h->nplanes, 1), feat_bytes = cells * PBD_FLEN * ts;
+  const size_t al = 256, pyr_al = (pyr + al - 1) / al * al, pk_al = (pk_bytes + al - 1) / al * al;
+  if (h->compact) {
+    char* u = nullptr;
+    if ((rc = dev_alloc(h, &u, std::max(pyr_al + feat_bytes, pk_al + maxK0 * act_cells0 * ts)))) return rc;
+    h->d_pyr = (uint8_t*)u; h->d_feat = u + pyr_al;
+    h->d_pk = (uint8_t*)u; h->d_dt_tmpT = u + pk_al;
+  } else {
+    if ((rc = dev_alloc(h, &h->d_pyr, pyr))) return rc;
+    if ((rc = dev_alloc(h, &h->d_feat, feat_bytes))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pk, pk_bytes))) return rc;
+  }
   if ((rc = dev_alloc(h, &h->d_rootv, cells * m.ncomponents * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_rooti, cells * m.ncomponents))) return rc;
 
@@ -486,8 +515,11 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   // accumulated part scores.
   h->dt_cap_elems = std::max<size_t>(1, allmaps * act_cells);
   const size_t tmp_elems = fold ? std::max<size_t>(1, maxK * act_cells) : h->dt_cap_elems;
-  if ((rc = dev_alloc(h, &h->d_dt_tmpT, tmp_elems * ts))) return rc;
-  if ((rc = dev_alloc(h, &h->d_dt_sdt, h->dt_cap_elems * ts))) return rc;
+  h->d_dt_sdt = nullptr;
+  if (!h->compact) {
+    if ((rc = dev_alloc(h, &h->d_dt_tmpT, tmp_elems * ts))) return rc;
+    if ((rc = dev_alloc(h, &h->d_dt_sdt, h->dt_cap_elems * ts))) return rc;
+  }
   if ((rc = dev_alloc(h, &h->d_dt_ixT, h->dt_cap_elems))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_iy, h->dt_cap_elems))) return rc;
   if (!fold && (rc = dev_alloc(h, &h->d_acc, cells * h->nslots * ts))) return rc;
@@ -538,7 +570,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     return part_scr[fp] + (size_t)h->parts[fp].K * lvl_scr[l] + (size_t)mm * h->lv[l].cw * h->lv[l].ch;
   };
   auto resp_plane = [&](int l, int fid) { return h->d_resp + (h->lv[l].cell_off * m.nfilters + (size_t)fid * h->lv[l].cw * h->lv[l].ch) * ts; };
-  auto sdt_plane = [&](int fp, int l, int mm) { return h->d_dt_sdt + scr_of(fp, l, mm) * ts; };
+  // compact: the transformed scores of (part, mixture) live in the mixture's own response plane
+  auto sdt_plane = [&](int fp, int l, int mm) { return h->compact ? resp_plane(l, h->parts[fp].filterid[mm]) : h->d_dt_sdt + scr_of(fp, l, mm) * ts; };
   // children of every part, descending flat index (the order their messages are added in, src/DynamicProgram.cpp:95)
   std::vector<std::vector<int>> children(h->parts.size());
   for (int fp = (int)h->parts.size() - 1; fp >= 0; --fp)
@@ -867,6 +900,7 @@ static int run_dp_min(pbd_handle* h) {
   h->have_dp = true;
   h->ext_ptr = false;   // back-tracking reads this min()'s own tables again
   h->root_dirty = false;
+  if (h->compact) h->have_pyr = h->have_feat = h->have_resp = false;   // their memory now holds the DP's planes
   return PBD_OK;
 }
 
@@ -1009,7 +1043,8 @@ static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
   }
   HIPCHK(h, hipGraphLaunch(h->gexec, h->stream));
   h->frames_on_plan++;
-  h->have_pyr = h->have_feat = h->have_resp = h->have_dp = true;
+  h->have_pyr = h->have_feat = h->have_resp = !h->compact;
+  h->have_dp = true;
   h->ext_ptr = false;
   h->root_dirty = false;
   h->dp_timed = false;

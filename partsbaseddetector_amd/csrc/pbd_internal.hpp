@@ -178,6 +178,8 @@ struct pbd_handle {
   struct ReduceWave { int blk0, nblks; };
   struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; size_t lds_x, lds_y; int fold_x; std::vector<ReduceWave> waves; };
   size_t dt_lds = 0;                                 // LDS budget of a k_dt_pass block in the fullest launch of a frame (thinner launches get less)
+  bool unique_filters = false;                       // every filter id belongs to exactly one (component, part, mixture)
+  bool compact = false;                              // memory plan of the current frame geometry (plan_frame)
   bool fold = false;                                 // DP structure of this handle: messages folded by the parent's x pass (no k_reduce, no acc planes)
   FoldJob* d_foldjobs = nullptr;
   int fold_mix = 0;                                  // largest mixture count of a part (the fold kernels' register-array bound)

@@ -425,7 +425,9 @@ def test_detector_class_stagewise_equals_fused(gpu_required, orc):
 
 
 def test_person_1080p_plan_and_run(gpu_required):
-    """configs[3] geometry: 1920x1080, 58 levels, level 0 is 478 cells wide (DT lines of 478)."""
+    """configs[3] geometry: 1920x1080, 58 levels, level 0 is 478 cells wide (DT lines of 478).  The frame is large
+    enough for the compact memory plan to be chosen automatically: at most 1.5 GB of device memory per handle
+    (pbd_get_footprint; 3.3 GB with every stage buffer kept), and the buffers it reuses refuse to be read afterwards."""
     m = make_person_model()
     m.thresh = 3.0e38
     h = capi.Handle(m)
@@ -436,7 +438,43 @@ def test_person_1080p_plan_and_run(gpu_required):
     h._geo = g
     rv, _ = h.root(0, 0)
     assert np.isfinite(rv).all()
+    frame_bytes, model_bytes = h.footprint()
+    print(f"1920x1080 person model: {frame_bytes / 1e9:.3f} GB per frame plan + {model_bytes / 1e6:.1f} MB model")
+    assert frame_bytes + model_bytes <= 1.5e9
+    h._cn = 3
+    with pytest.raises(capi.PbdError) as e:
+        h.level_response(0, 0)
+    assert e.value.code == capi.PBD_ERR_STATE
     h.close()
+
+
+def test_compact_memory_plan_same_results(gpu_required, orc):
+    """dp_mode 2 (what large frames get automatically): transformed scores written over the mixtures' own response planes,
+    level images / features sharing memory with the DP's planes — candidates and root tables identical to the oracle's,
+    a smaller footprint than the default plan, stage buffers unreadable once min() has reused them."""
+    m = make_tree_model([-1, 0, 1, 1, 0, 4, 4, 2], 3, seed=9)
+    im = make_image(3, 240, 180)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.5)
+    ref = orc.detect(m, im)[:3]
+    assert len(ref[0]) > 10
+    hc = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dp_mode=2)
+    hd = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    for _ in range(2):                                   # twice: the second frame starts from reused buffers
+        assert_candidates_equal(hc.detect(im), ref)
+    assert_candidates_equal(hd.detect(im), ref)
+    assert hc.footprint()[0] < 0.8 * hd.footprint()[0]
+    hc._geo = hc.geometry(240, 180); hc._cn = 3
+    fr = orc.detect(m, im, capacity=1, keep=True)[4]
+    np.testing.assert_array_equal(hc.root(0, 0)[0].view(np.uint32), fr.root(0)[0].view(np.uint32))
+    fr.free()
+    for fn in (lambda: hc.level_features(0), lambda: hc.level_response(0, 0), lambda: hc.level_image(0)):
+        with pytest.raises(capi.PbdError) as e:
+            fn()
+        assert e.value.code == capi.PBD_ERR_STATE
+    # the staged sequence still works: pyramid -> pdf -> min -> argmin
+    hc.pyramid(im); hc.pdf(); hc.dp_min()
+    assert_candidates_equal(hc.dp_argmin(), ref)
+    hc.close(); hd.close()
 
 
 def _tables_checksum(orc, model, im, dtype=np.float32):
@@ -908,6 +946,66 @@ def test_group_batch_two_handles_one_gpu_equals_single_handle(gpu_required, orc)
     for got, f in zip(g3.detect_batch(frames * 3), frames * 3):
         assert_candidates_equal(got, single.detect(f))
     single.close(); g3.close()
+
+
+def test_group_batch_configs2_shape(gpu_required, orc):
+    """BASELINE configs[2]'s real shape: 32 person-model frames of 640x480 through pbd_group_detect_batch_u8, members
+    [0, 0, 0, 0] (on an 8-GPU node: [0..7], 4 frames each) == a single handle for all 32 frames and == the oracle for 4."""
+    m = make_person_model()
+    frames = [make_image(i, 640, 480) for i in range(32)]
+    m.thresh = thresh_from_oracle(orc, m, frames[0], 99.9)
+    g = capi.Group(m, [0, 0, 0, 0], conv_mode=capi.PBD_CONV_EXACT)
+    outs = g.detect_batch(frames)
+    g.close()
+    single = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    assert len(outs) == 32
+    for i, (f, got) in enumerate(zip(frames, outs)):
+        assert_candidates_equal(got, single.detect(f))
+        if i % 9 == 0:
+            assert_candidates_equal(got, orc.detect(m, f)[:3])
+    single.close()
+
+
+def test_group_drains_its_members_after_an_error(gpu_required, orc):
+    """A member over its device-side candidate capacity fails the batch (PBD_ERR_CAPACITY) — and must not leave the other
+    members with a frame in flight: the next batch on the same group works."""
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    frames = [make_image(i, 200, 150) for i in range(4)]
+    m.thresh = thresh_from_oracle(orc, m, frames[0], 99.3)
+    ref = [orc.detect(m, f)[:3] for f in frames]
+    small = min(len(r[0]) for r in ref)
+    assert small > 2
+    g = capi.Group(m, [0, 0, 0], conv_mode=capi.PBD_CONV_EXACT, max_candidates=small - 1)   # every frame overflows the device list
+    with pytest.raises(capi.PbdError) as e:
+        g.detect_batch(frames)
+    assert e.value.code == capi.PBD_ERR_CAPACITY
+    with pytest.raises(capi.PbdError):
+        g.detect_batch(frames)                           # same answer again, not "previous frame not collected"
+    assert "not collected" not in str(e.value)
+    g.close()
+    g = capi.Group(m, [0, 0, 0], conv_mode=capi.PBD_CONV_EXACT)
+    for got, r in zip(g.detect_batch(frames), ref):
+        assert_candidates_equal(got, r)
+    g.close()
+
+
+def test_bench_lines_parse(gpu_required):
+    """bench.py entry forms the driver (or a user without torchrun) may use: --group on one device, and --gpus 2 with
+    no torchrun environment (bench.py becomes its own launcher; gloo lets two ranks share this box's one GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for extra, ngpu in ((["--gpus", "1", "--group", "--steps", "3"], 1),
+                        (["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-prewarm"], 2)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == ngpu and line["value"] > 0 and line["unit"] == "frames/s"
+        if ngpu == 2:
+            assert "every step" in line["config"]["gather"] and line["config"]["candidates_last_frame"] > 0
 
 
 def test_group_level_sharding_more_members_than_needed(gpu_required, orc):
