@@ -209,13 +209,12 @@ def main():
         for hd in handles:
             hd.set_levels(my_levels)
 
-    gcap = 192 if W * H <= 640 * 480 else 2048      # records per rank in the fixed-size gather block (more raises, never truncates)
     gathered_last = [None]
 
     def gather(out):
         """The one collective of the path: this step's candidates of every rank -> rank 0 (N = 1: nothing to do)."""
         if world > 1:
-            gathered_last[0] = gather_candidates(out, handles[0].max_parts, capacity=gcap, device=cdev, dst=0)
+            gathered_last[0] = gather_candidates(out, handles[0].max_parts, capacity=cap, device=cdev, dst=0)
 
     def run(nsteps, collect_out=None, stamps=None, host=False):
         """S frames in flight; host=True hands over pinned host images (H2D inside every step).  N > 1: every
@@ -353,7 +352,7 @@ def main():
                        "prewarm_s": 0.0 if args.no_prewarm else PREWARM_S, "prewarm_frames": prewarm_frames,
                        "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}"),
                        "gather": (f"every step, inside the timed region: torch.distributed gather to rank 0, backend {args.backend}, "
-                                  f"{gcap} records per rank" if world > 1 else "none (one rank)")},
+                                  f"counts first, then the records padded to the longest list" if world > 1 else "none (one rank)")},
             "frame_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),
                          "what": "completion-to-completion wall time per frame in the timed loop (rank 0)"},
             "value_resident": round(value, 3), "value_incl_h2d": round(value_h2d, 3),

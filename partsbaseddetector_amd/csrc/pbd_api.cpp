@@ -380,17 +380,13 @@ static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget,
   DtGroup g{};
   g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len; g.fold = fold;
   g.stride = dt_stride_for(len);
-  g.lpb = dt_lpb_for(g.stride, len, fold >= 0 ? nmaps : 1, budget, ts, nt, seg);
+  g.lpb = dt_lpb_for(g.stride, len, 1, budget, ts, nt, seg);
   return g;
 }
 static void dt_add_tasks(const DtGroup& g, std::vector<DtTask>& out) {
-  if (g.fold >= 0) {
-    const int R = g.lpb / g.nmaps;
-    for (int r0 = 0; r0 < g.nlines; r0 += R) out.push_back(DtTask{r0, std::min(R, g.nlines - r0) * g.nmaps, g});
-  } else {
-    const int total = g.nmaps * g.nlines;
-    for (int g0 = 0; g0 < total; g0 += g.lpb) out.push_back(DtTask{g0, std::min(g.lpb, total - g0), g});
-  }
+  // plain: line gi = line gi % nlines of map gi / nlines; fold: line gi = mixture gi % nmaps of row gi / nmaps
+  const int total = g.nmaps * g.nlines;
+  for (int g0 = 0; g0 < total; g0 += g.lpb) out.push_back(DtTask{g0, std::min(g.lpb, total - g0), g});
 }
 static DtMap dt_map(const void* src, void* dst, int16_t* ptr, float wq, float wl, int os, int natural) {
   DtMap m{};
@@ -634,7 +630,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       if (fold_x) {
         for (int fp : rnd) {
           const DtGroup g = dt_group(0, h->parts[fp].K, nlines, len, budget, h->ts, h->dt_nt, h->dt_seg, 0);
-          nb += (size_t)(nlines + g.lpb / g.nmaps - 1) / (g.lpb / g.nmaps);
+          nb += ((size_t)g.nmaps * nlines + g.lpb - 1) / g.lpb;
           lds = std::max(lds, dt_lds_bytes(g.stride, g.lpb, h->ts, h->dt_nt));
         }
       } else {

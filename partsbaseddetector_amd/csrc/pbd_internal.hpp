@@ -68,7 +68,7 @@ struct DtMap {       // one 1-D pass over one score map
 //           block = nrows consecutive rows x K mixtures, and its loader builds the lines on the fly from the part's raw
 //           responses and its children's distance-transformed scores (FoldJob).
 struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, fold, pad; };  // stride: LDS elements per line (odd); lpb: lines per block; fold: FoldJob index or -1
-struct DtTask { int g0, nl; DtGroup g; };   // g0: first line (plain) / first row (fold); nl: lines of this block; the group travels with the task
+struct DtTask { int g0, nl; DtGroup g; };   // g0: first line of the block in the group's numbering; nl: its lines; the group travels with the task
 #ifndef PBD_DT_NT_DEFAULT
 #define PBD_DT_NT_DEFAULT 128   // lanes of a k_dt_pass block
 #endif

@@ -94,19 +94,29 @@ def unpack_candidates(buf: np.ndarray, max_parts: int):
 
 def gather_candidates(cands, max_parts: int, capacity: int = 4096, device=None, dst=None):
     """Gather of every rank's candidates; returns a list (one entry per rank) of (heads, boxes, locs).
-    dst=None: all_gather (every rank gets the list); dst=r: gather to rank r only (the others return None) — what a
-    detector host needs, and 1/world of the traffic.  Works with any initialised torch.distributed backend.
-    `capacity` (records per rank in the fixed-size exchange buffer) defaults to the handles' default
-    max_candidates; a rank holding more raises."""
+    dst=None: every rank gets the list (all_gather); dst=r: rank r only (the others return None) — what a detector
+    host needs, and 1/world of the traffic.  Works with any initialised torch.distributed backend (nccl = RCCL over
+    xGMI with device tensors, gloo on the host).  Two small collectives: the ranks' counts (every rank learns the
+    longest list), then the records padded to that length — KB-scale payloads whatever `capacity` (the most a rank
+    may hold; more raises, like PBD_ERR_CAPACITY) is."""
     import torch
     import torch.distributed as dist
 
-    buf = torch.from_numpy(pack_candidates(cands, max_parts, capacity))
+    heads = cands[0]
+    n = len(heads)
+    if n > capacity:     # the C ABI reports PBD_ERR_CAPACITY for the same condition: never drop detections silently
+        raise OverflowError(f"{n} candidates do not fit the gather capacity {capacity}: pass capacity >= the handle's max_candidates")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cnt = torch.tensor([n], dtype=torch.int32, device=device)
+    counts = torch.empty(world, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(counts, cnt)
+    counts = counts.cpu().tolist()
+    nmax = max(max(counts), 1)
+    buf = torch.from_numpy(pack_candidates(cands, max_parts, nmax))
     if device is not None:
         buf = buf.to(device)
-    world = dist.get_world_size()
     # one contiguous receive buffer (the per-rank blocks are views of it): ONE device-to-host copy afterwards
-    big = torch.empty(world * buf.numel(), dtype=buf.dtype, device=buf.device) if (dst is None or dist.get_rank() == dst) else None
+    big = torch.empty(world * buf.numel(), dtype=buf.dtype, device=buf.device) if (dst is None or rank == dst) else None
     outs = list(big.chunk(world)) if big is not None else None
     if dst is None:
         dist.all_gather(outs, buf)

@@ -465,7 +465,7 @@ def test_compact_memory_plan_same_results(gpu_required, orc):
     assert hc.footprint()[0] < 0.8 * hd.footprint()[0]
     hc._geo = hc.geometry(240, 180); hc._cn = 3
     fr = orc.detect(m, im, capacity=1, keep=True)[4]
-    np.testing.assert_array_equal(hc.root(0, 0)[0].view(np.uint32), fr.root(0)[0].view(np.uint32))
+    np.testing.assert_array_equal(hc.root(0, 0)[0].view(np.uint32), fr.root(0)[0][0].view(np.uint32))
     fr.free()
     for fn in (lambda: hc.level_features(0), lambda: hc.level_response(0, 0), lambda: hc.level_image(0)):
         with pytest.raises(capi.PbdError) as e:
@@ -1001,7 +1001,7 @@ def test_bench_lines_parse(gpu_required):
     for extra, ngpu in ((["--gpus", "1", "--group", "--steps", "3"], 1),
                         (["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-prewarm"], 2)):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True, timeout=600, env=env)
-        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-6000:]
         line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["n_gpus"] == ngpu and line["value"] > 0 and line["unit"] == "frames/s"
         if ngpu == 2:
