@@ -70,7 +70,7 @@ void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i]
 // 1/dx, dx < len (double[S], shared by all lines whatever their map: dt_core.hpp), and per line
 // {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
 // 9 bytes per line element for float: the lines resident on a CU are bounded by these bytes.
-#define DT_SEGS 96                                   // SEG words: P + 1 <= 65 segment starts; [76..93]: the fold block's PRE / RF tables; [94, 95]: {0, len} for a line redone as one segment
+#define DT_SEGS 72                                   // SEG entries: P + 1 <= 65 starts, then {0, len} for a line redone as one segment
 __host__ __device__ inline size_t dt_hdr_bytes(int nt, int ts, int its, int lpb) {   // per line 16 B, per lane 2 T + 4 IT
   return ((size_t)lpb * 16 + DT_SEGS * 4 + (size_t)nt * (2 * ts + 4 * its) + 15) & ~(size_t)15;
 }
@@ -95,7 +95,7 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // than the plain one.  Everything below is branch-free except the loop over the children.
 template <typename T, int M, int U>
 __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ /*biasw*/, const size_t (&off)[U],
-                                              size_t HW, int L, const unsigned (&own)[U], T (&acc)[U][M]) {
+                                              size_t HW, int L, const bool (&valid)[U], T (&acc)[U][M]) {
   const int nch = J->nch;
   for (int c = 0; c < nch; ++c) {
     const FoldChild& C = J->ch[c];
@@ -141,7 +141,7 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         if (m < L) {
-          if ((own[u] >> m) & 1u) okp[(size_t)m * HW + off[u]] = (uint8_t)bi[m];   // Ik (:150), written by the block that owns line (row, m)
+          if (valid[u]) okp[(size_t)m * HW + off[u]] = (uint8_t)bi[m];   // Ik (:150)
           acc[u][m] = acc[u][m] + v[m];                                                  // parent.score += maxv (:156), child order kept
         }
       }
@@ -154,13 +154,9 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
 // capacity leaves most lanes without a line of their own, so the NT / lpb lanes that share a line each scan one
 // SEGMENT of it concurrently and the segments are stitched into the sequential result (dt_core.hpp):
 // lane = p * lpb + line.
-// FOLD: the group's lines are numbered (row, mixture) — all K mixtures of a row next to each other, so that the block
-// that holds a row loads the children's values of its cells ONCE for all K lines — and a block takes nl consecutive
-// ones, i.e. a few whole rows and possibly a partial first / last row (whole rows only would quantise the lines per
-// block: 12 where 15 fit, 1 772 blocks for 1 536 residency slots).  In LDS the block's lines are ordered mixture-major
-// (neighbouring lanes then write neighbouring rows of one transposed plane): mixture l owns rows RF[l] .. RF[l] +
-// cnt(l) - 1, lines PRE[l] .. PRE[l + 1] - 1.  The loader builds the lines from the part's raw responses and its
-// children's messages (fold_children); a row shared by two blocks is folded by both, each keeping its own lines.
+// FOLD: the block's lines are nrows consecutive rows x the K mixtures of one part (line = mixture * nrows + row, so
+// that neighbouring lanes write neighbouring rows of one transposed plane) and the loader builds them from the part's
+// raw responses and its children's messages (fold_children).
 template <typename T, typename IT, int FM>   // FM: 0 = plain lines, else fold with at most FM mixtures per part
 __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps,
                                          const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
@@ -181,11 +177,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   IT* BSAVE = DMIN + NT;                       // [NT] local link of FT (before the patch)
   double* RDX = (double*)(smem + dt_hdr_bytes(NT, sizeof(T), sizeof(IT), lpb));   // [S] 1/dx
   const int nl = t.nl;                         // lines of this block
-  // FOLD: rows r_lo .. r_hi are touched; PRE / RF (header words behind SEG's {0, len} pair are free: P + 1 <= 65 of the 72)
-  const int fK = FOLD ? g.nmaps : 1;
-  const int r_lo = FOLD ? t.g0 / fK : 0, r_hi = FOLD ? (t.g0 + nl - 1) / fK : 0, nrows = r_hi - r_lo + 1;
-  int* PRE = (int*)(smem + lpb * 16) + DT_SEGS - 2 - 2 * (PBD_FOLD_MAXMIX + 1);   // [K + 1] first LDS line of mixture l
-  int* RF = PRE + PBD_FOLD_MAXMIX + 1;                                            // [K] first row of mixture l in this block
+  const int nrows = FOLD ? nl / g.nmaps : 0;   // FOLD: rows of this block
   P2* YZ = (P2*)(RDX + ((S + 1) & ~1));        // [lpb][S] (16-byte aligned) .x: line values (never modified); .y: z of the element when pushed
   IT* B = (IT*)(YZ + lpb * S);                 // [lpb][S] element below on the stack when pushed; later: element above (read-out)
   if (lane < nl) {
@@ -202,16 +194,6 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   const int P = dt_segments(nsub, len);          // segments per line
   if (lane <= P) SEG[lane] = dt_seg_start(lane, P, len);
   if (lane == 0) { SEG[DT_SEGS - 2] = 0; SEG[DT_SEGS - 1] = len; }
-  if (FOLD && lane == 64 % NT) {   // one lane, K <= 8 steps
-    int pre = 0;
-    for (int l = 0; l < fK; ++l) {
-      const int rf = r_lo + (r_lo * fK + l < t.g0 ? 1 : 0), rl = r_hi - (r_hi * fK + l >= t.g0 + nl ? 1 : 0);
-      PRE[l] = pre; RF[l] = rf;
-      pre += max(0, rl - rf + 1);
-    }
-    PRE[fK] = pre;
-  }
-  if (FOLD) __syncthreads();
   if (!FOLD) __syncthreads();
   DT_STAMP(1);
   if constexpr (FOLD) {
@@ -234,7 +216,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       for (int u = 0; u < U; ++u) {
         const int ec = min(e0 + u * NT + lane, n - 1);
         jj[u] = (int)((unsigned)ec / (unsigned)len); qq[u] = ec - jj[u] * len;
-        off[u] = (size_t)(r_lo + jj[u]) * len + qq[u];
+        off[u] = (size_t)(t.g0 + jj[u]) * len + qq[u];
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[u][m] = ((GP(T))srcp[m])[off[u]];
       }
@@ -243,20 +225,17 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         if (e0 == 0)
           for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
-      // which mixtures of the cell's row belong to this block (all of them except in a partial first / last row)
-      unsigned own[U];
+      bool valid[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) valid[u] = e0 + u * NT + lane < n;
+      fold_children<T, M, U>(J, biasw, off, HW, L, valid, acc);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int gi0 = (r_lo + jj[u]) * fK;   // group-linear index of the row's mixture 0
-        const int lo = max(t.g0 - gi0, 0), hi = min(t.g0 + nl - gi0, fK);   // owned mixtures [lo, hi)
-        own[u] = (e0 + u * NT + lane < n && hi > lo) ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-      }
-      fold_children<T, M, U>(J, biasw, off, HW, L, own, acc);
+        if (valid[u]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int m = 0; m < M; ++m)
-          if (m < L && ((own[u] >> m) & 1u)) YZ[(PRE[m] + (r_lo + jj[u]) - RF[m]) * S + qq[u]].x = acc[u][m];
+          for (int m = 0; m < M; ++m)
+            if (m < L) YZ[(m * nrows + jj[u]) * S + qq[u]].x = acc[u][m];
+        }
       }
     }
   } else {
@@ -298,10 +277,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   // line -> (map, line of the map): plain: map-major; FOLD: mixture-major inside the block's rows
   int mi = 0, li = 0;
   if (mine) {
-    if (FOLD) {
-      for (int l = 1; l < fK; ++l) mi = line >= PRE[l] ? l : mi;
-      li = RF[mi] + (line - PRE[mi]);
-    }
+    if (FOLD) { mi = line / nrows; li = t.g0 + (line - mi * nrows); }
     else { const int gi = t.g0 + line; mi = gi / g.nlines; li = gi - mi * g.nlines; }
   }
   DtMap mp;
@@ -567,7 +543,7 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
     constexpr int M = PBD_FOLD_MAXMIX;
     T acc[1][M];
     const size_t offs[1] = {cell};
-    const unsigned valids[1] = {0xFFFFFFFFu};
+    const bool valids[1] = {true};
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[0][m] = ((GP(T))J.score[m < J.K ? m : J.K - 1])[cell];
     // (acc is [1][M]: one cell per lane)

@@ -380,13 +380,17 @@ static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget,
   DtGroup g{};
   g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len; g.fold = fold;
   g.stride = dt_stride_for(len);
-  g.lpb = dt_lpb_for(g.stride, len, 1, budget, ts, nt, seg);
+  g.lpb = dt_lpb_for(g.stride, len, fold >= 0 ? nmaps : 1, budget, ts, nt, seg);
   return g;
 }
 static void dt_add_tasks(const DtGroup& g, std::vector<DtTask>& out) {
-  // plain: line gi = line gi % nlines of map gi / nlines; fold: line gi = mixture gi % nmaps of row gi / nmaps
-  const int total = g.nmaps * g.nlines;
-  for (int g0 = 0; g0 < total; g0 += g.lpb) out.push_back(DtTask{g0, std::min(g.lpb, total - g0), g});
+  if (g.fold >= 0) {
+    const int R = g.lpb / g.nmaps;
+    for (int r0 = 0; r0 < g.nlines; r0 += R) out.push_back(DtTask{r0, std::min(R, g.nlines - r0) * g.nmaps, g});
+  } else {
+    const int total = g.nmaps * g.nlines;
+    for (int g0 = 0; g0 < total; g0 += g.lpb) out.push_back(DtTask{g0, std::min(g.lpb, total - g0), g});
+  }
 }
 static DtMap dt_map(const void* src, void* dst, int16_t* ptr, float wq, float wl, int os, int natural) {
   DtMap m{};
@@ -528,6 +532,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   // per intersection): one wavefront and 20 KB = 8 blocks per CU (0.93 ms against 1.28 with the float geometry)
   h->dt_nt = h->ts == 8 ? 64 : PBD_DT_NT_DEFAULT;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
+  h->dt_nt_x = h->dt_nt;      // lanes of a fold x-pass block
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_NT_X")) h->dt_nt_x = std::max(64, std::min(256, atoi(e) & ~63));
   if (const char* e = PBD_PROBE_ENV("PBD_DT_SEG")) h->dt_seg = atoi(e);
   size_t dt_base = (h->ts == 8 ? 20 : 25) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
@@ -608,9 +614,9 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
     }
     v.swap(o);
   };
-  auto launch_lds = [&](const std::vector<DtTask>& v) {
+  auto launch_lds = [&](const std::vector<DtTask>& v, int nt) {
     size_t lds = 0;
-    for (const DtTask& t : v) lds = std::max(lds, dt_lds_bytes(t.g.stride, t.g.lpb, h->ts, h->dt_nt));
+    for (const DtTask& t : v) lds = std::max(lds, dt_lds_bytes(t.g.stride, t.g.lpb, h->ts, nt));
     if (const char* e = PBD_PROBE_ENV("PBD_DT_LDS_REQUEST_KB")) lds = std::max(lds, (size_t)atoi(e) * 1024);   // occupancy probe
     return lds;
   };
@@ -630,7 +636,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       if (fold_x) {
         for (int fp : rnd) {
           const DtGroup g = dt_group(0, h->parts[fp].K, nlines, len, budget, h->ts, h->dt_nt, h->dt_seg, 0);
-          nb += ((size_t)g.nmaps * nlines + g.lpb - 1) / g.lpb;
+          nb += (size_t)(nlines + g.lpb / g.nmaps - 1) / (g.lpb / g.nmaps);
           lds = std::max(lds, dt_lds_bytes(g.stride, g.lpb, h->ts, h->dt_nt));
         }
       } else {
@@ -706,7 +712,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
           gx_nmaps++;
         }
         tmp_round += (size_t)P.K * act_cells;
-        if (fold_x) dt_add_tasks(dt_group(part_map0, P.K, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg, make_fold(fp, l)), xt);
+        if (fold_x) dt_add_tasks(dt_group(part_map0, P.K, L.ch, L.cw, budget_x, h->ts, h->dt_nt_x, h->dt_seg, make_fold(fp, l)), xt);
       }
       g_dt_round = geox.round;
       if (!fold_x) dt_add_tasks(dt_group(gx_map0, gx_nmaps, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg), xt);
@@ -724,9 +730,10 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
       const std::vector<DtTask> x0 = xt, y0 = yt;
       for (int i = 1; i < ndup; ++i) { xt.insert(xt.end(), x0.begin(), x0.end()); yt.insert(yt.end(), y0.begin(), y0.end()); }
     }
+    if (PBD_PROBE_ENV("PBD_DT_REVERSE")) { std::reverse(xt.begin(), xt.end()); std::reverse(yt.begin(), yt.end()); }   // probe: coarse levels' blocks first
     xcd_order(xt);
     xcd_order(yt);
-    R.lds_x = launch_lds(xt); R.lds_y = launch_lds(yt); R.fold_x = fold_x ? 1 : 0;
+    R.lds_x = launch_lds(xt, fold_x ? h->dt_nt_x : h->dt_nt); R.lds_y = launch_lds(yt, h->dt_nt); R.fold_x = fold_x ? 1 : 0;
     if (dbg_plan) fprintf(stderr, "plan: round %zu: %zu x blocks (%zu B LDS%s), %zu y blocks (%zu B)\n", r, xt.size(), R.lds_x, fold_x ? ", fold" : "", yt.size(), R.lds_y);
     R.xtask0 = (int)tasks.size(); R.nxtasks = (int)xt.size();
     tasks.insert(tasks.end(), xt.begin(), xt.end());
@@ -882,7 +889,7 @@ static int run_dp_min(pbd_handle* h) {
   // messages) + y pass per round, the root's messages folded by k_root: 2 * rounds + 1 launches; legacy (models that
   // alias a filter id inside a component, or more than 8 mixtures): + the round's reduce launches.
   for (auto& R : h->rl) {
-    launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, R.fold_x ? h->d_foldjobs : nullptr, h->d_biasw, R.lds_x, h->ts, h->dt_nt, h->fold_mix, h->stream);
+    launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, R.fold_x ? h->d_foldjobs : nullptr, h->d_biasw, R.lds_x, h->ts, R.fold_x ? h->dt_nt_x : h->dt_nt, h->fold_mix, h->stream);
     launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, nullptr, h->d_biasw, R.lds_y, h->ts, h->dt_nt, 0, h->stream);
     for (auto& Wv : R.waves)
       launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);

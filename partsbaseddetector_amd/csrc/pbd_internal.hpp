@@ -68,7 +68,7 @@ struct DtMap {       // one 1-D pass over one score map
 //           block = nrows consecutive rows x K mixtures, and its loader builds the lines on the fly from the part's raw
 //           responses and its children's distance-transformed scores (FoldJob).
 struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, fold, pad; };  // stride: LDS elements per line (odd); lpb: lines per block; fold: FoldJob index or -1
-struct DtTask { int g0, nl; DtGroup g; };   // g0: first line of the block in the group's numbering; nl: its lines; the group travels with the task
+struct DtTask { int g0, nl; DtGroup g; };   // g0: first line (plain) / first row (fold); nl: lines of this block; the group travels with the task
 #ifndef PBD_DT_NT_DEFAULT
 #define PBD_DT_NT_DEFAULT 128   // lanes of a k_dt_pass block
 #endif
@@ -184,6 +184,7 @@ struct pbd_handle {
   FoldJob* d_foldjobs = nullptr;
   int fold_mix = 0;                                  // largest mixture count of a part (the fold kernels' register-array bound)
   int dt_nt = PBD_DT_NT_DEFAULT;                                   // lanes of a k_dt_pass block (64 or 128)
+  int dt_nt_x = PBD_DT_NT_DEFAULT;                                 // lanes of a fold x-pass block
   int dt_seg = 0;                                    // target segment length of the DT scans (0: as many lines per block as fit)
   int xcd_chunk = 16;                                // consecutive k_dt_pass tasks kept on one XCD (0: table order)
   std::vector<RoundLaunch> rl;
