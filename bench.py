@@ -149,6 +149,9 @@ def main():
                     help="ONE process driving --gpus N devices through pbd_group (no torchrun): every device listed --inflight "
                          "times, frames round-robin and software-pipelined over the members, host images in (H2D inside "
                          "the timed region), host gather of the candidates")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PBD_BATCH", "1")),
+                    help="frames per step and handle: >1 hands every handle a BATCH of same-sized frames (pbd_detect_batch_*: one "
+                         "launch per stage for the whole batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("PBD_GRAPH", "1")), help="pbd_options.graph: replay a captured hipGraph per frame")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm (profiling runs)")
@@ -200,8 +203,12 @@ def main():
     model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).to(dev), W, H, dtype=dtype)
 
     S = max(1, args.inflight)
+    B = max(1, args.batch)
     cap = 4096 if W * H <= 640 * 480 else 32768      # the 99.9th-percentile threshold scales the count with the area
-    handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=cap, dtype=dtype, graph=args.graph) for _ in range(S)]
+    handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=cap * (B if B > 1 else 1), dtype=dtype, graph=args.graph) for _ in range(S)]
+    if B > 1:   # batches: B frames back to back in HBM (and B pinned host frames) per step slot
+        dev_batches = [torch.stack([frames[(k * B + j) % nimg] for j in range(B)]).contiguous() for k in range(nimg)]
+        host_batches = [[host_frames[(k * B + j) % nimg].data_ptr() for j in range(B)] for k in range(nimg)]
     if by_levels:   # SURVEY 8e / configs[3]: one frame, levels spread over the ranks by greedy LPT on the cell counts
         from partsbaseddetector_amd.parallel import shard_levels_lpt
         g = handles[0].geometry(W, H)
@@ -216,6 +223,13 @@ def main():
         if world > 1:
             gathered_last[0] = gather_candidates(out, handles[0].max_parts, capacity=cap, device=cdev, dst=0)
 
+    def collect_one(hd):
+        """the step's candidates: one frame's, or the batch's (concatenated: (level, component, root) order inside a frame)"""
+        if B == 1:
+            return hd.collect(cap)
+        outs_b = hd.collect_batch(cap)
+        return tuple(np.concatenate([o[k] for o in outs_b]) for k in range(3))
+
     def run(nsteps, collect_out=None, stamps=None, host=False):
         """S frames in flight; host=True hands over pinned host images (H2D inside every step).  N > 1: every
         step's candidates are gathered to rank 0 — after the next frame has been enqueued, so the collective
@@ -225,12 +239,17 @@ def main():
             hd = handles[i % S]
             out = None
             if len(pending) == S:
-                out = pending.pop(0).collect(cap)
+                out = collect_one(pending.pop(0))
                 if stamps is not None:
                     stamps.append(time.perf_counter())
                 if collect_out is not None:
                     collect_out.append(out)
-            if host:
+            if B > 1:
+                if host:
+                    hd.enqueue_batch_host_ptrs(host_batches[i % nimg], W, H, 3)
+                else:
+                    hd.enqueue_batch_dev(dev_batches[i % nimg].data_ptr(), B, W, H, 3)
+            elif host:
                 hd.enqueue_host_ptr(host_frames[i % nimg].data_ptr(), W, H, 3)
             else:
                 hd.enqueue_dev(frames[i % nimg].data_ptr(), W, H, 3)
@@ -238,7 +257,7 @@ def main():
             if out is not None:
                 gather(out)
         for hd in pending:
-            out = hd.collect(cap)
+            out = collect_one(hd)
             if stamps is not None:
                 stamps.append(time.perf_counter())
             if collect_out is not None:
@@ -310,7 +329,7 @@ def main():
         work = hd.work()
         stage = stage_acc
         dp_ms = dp_ms_seq
-        per_rank = 1 if by_levels else world
+        per_rank = (1 if by_levels else world) * B
         ms_per_step = dt / args.steps * 1e3
         value = args.steps * per_rank / dt
         value_h2d = args.steps * per_rank / dt_h2d
@@ -347,14 +366,15 @@ def main():
             "config": {"workload": f"person 26 parts x {args.mixtures} mixtures ({len(model.filtersw)} 5x5x32 filters), "
                                    f"{W}x{H} BGR, full pyramid ({hd.geometry(W, H)['nlevels']} levels), "
                                    f"threshold = 99.9th pct of root scores",
-                       "frames_per_step_per_gpu": 1, "inflight": S, "conv": args.conv, "input": "frames resident in HBM",
+                       "frames_per_step_per_gpu": B, "inflight": S, "conv": args.conv, "input": "frames resident in HBM",
+                       "batching": (f"pbd_detect_batch: every handle processes {B} frames per step, one launch per stage for the batch" if B > 1 else "single frames"),
                        "launch": "hipGraph replay (one hipGraphLaunch per frame)" if args.graph else "eager (~40 launches per frame)",
                        "prewarm_s": 0.0 if args.no_prewarm else PREWARM_S, "prewarm_frames": prewarm_frames,
                        "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}"),
                        "gather": (f"every step, inside the timed region: torch.distributed gather to rank 0, backend {args.backend}, "
                                   f"counts first, then the records padded to the longest list" if world > 1 else "none (one rank)")},
             "frame_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),
-                         "what": "completion-to-completion wall time per frame in the timed loop (rank 0)"},
+                         "what": "completion-to-completion wall time per step (one frame, or one batch) in the timed loop (rank 0)"},
             "value_resident": round(value, 3), "value_incl_h2d": round(value_h2d, 3),
             "value_is": "frames resident in HBM when the timed region starts (this tier's contract for `value`); the H2D-inclusive "
                         "figure of SURVEY 8d is value_incl_h2d",

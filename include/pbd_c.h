@@ -183,6 +183,20 @@ int pbd_detect_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes,
  * image is staged by the runtime).  `im` must stay valid until pbd_detect_collect returns.               */
 int pbd_detect_enqueue_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride);
 
+/* ---- a batch of same-sized frames on ONE handle (BASELINE configs[2] gives every GPU 4 frames) ----------
+ * The frames of a batch go through every stage TOGETHER: one launch (or one chain of launches) per stage for the whole
+ * batch — the same kernels with `nframes` times the blocks per launch, which fills the chip in the thin rounds of the DP
+ * and pays every launch tail once per batch.  Results per frame are identical to pbd_detect_u8.
+ * Frame f's candidates land at heads[f*capacity], boxes[f*capacity*max_parts*4], locs[f*capacity*max_parts*3] (boxes /
+ * locs may be NULL), counts[f] = number found; PBD_ERR_CAPACITY if a frame exceeds `capacity` or the batch exceeds
+ * pbd_options.max_candidates.  1 <= nframes <= 64; the work tables are re-planned when nframes (or the size) changes.
+ * _enqueue_dev_: the frames already in device memory, tightly packed, back to back; collect after either enqueue.   */
+int pbd_detect_batch_u8(pbd_handle* h, const uint8_t* const* ims, int nframes, int w, int hgt, int cn, int stride,
+                        pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* counts);
+int pbd_detect_batch_enqueue_u8(pbd_handle* h, const uint8_t* const* ims, int nframes, int w, int hgt, int cn, int stride);
+int pbd_detect_batch_enqueue_dev_u8(pbd_handle* h, const void* d_ims, int nframes, int w, int hgt, int cn);
+int pbd_detect_batch_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* counts);
+
 /* ---- one process, several GPUs (SURVEY 8b "Threading", 8e) ------------------
  * The reference's hosts are single processes (src/demo.cpp:85-103, ros/Node.cpp:183, cells/detect.cpp:224).
  * A pbd_group owns one handle per listed device (a device may be listed more than once: several frames in

@@ -37,6 +37,7 @@ EXPORTS = [
     "pbd_group_gather_mode", "pbd_group_member", "pbd_group_detect_batch_u8", "pbd_group_detect_u8",
     "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps",
     "pbd_set_root", "pbd_set_root_f64", "pbd_set_dp_pointers", "pbd_get_footprint", "pbd_abi_version",
+    "pbd_detect_batch_u8", "pbd_detect_batch_enqueue_u8", "pbd_detect_batch_enqueue_dev_u8", "pbd_detect_batch_collect",
 ]
 PBD_ABI_VERSION = 3
 
@@ -186,6 +187,39 @@ class Handle:
         self._chk(self.L.pbd_detect_collect(self.h, heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32),
                                             _p(locs, C.c_int32), capacity, C.byref(cnt)))
         return self._out(heads, boxes, locs, cnt.value)
+
+    # ---- a batch of same-sized frames through this handle ------------------------------------
+    def detect_batch(self, frames, capacity=4096):
+        """pbd_detect_batch_u8: list of HxWxC uint8 frames -> list of (heads, boxes, locs), one per frame."""
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        hgt, w = frames[0].shape[:2]
+        cn = 1 if frames[0].ndim == 2 else frames[0].shape[2]
+        ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        return self._batch_out(len(frames), capacity, lambda hd, bx, lc, cnt: self.L.pbd_detect_batch_u8(
+            self.h, ptrs, len(frames), w, hgt, cn, w * cn, hd, bx, lc, capacity, cnt))
+
+    def enqueue_batch_dev(self, dptr: int, nframes, w, hgt, cn):
+        """frames back to back in device memory (tightly packed); collect with collect_batch"""
+        self._nb = nframes
+        self._chk(self.L.pbd_detect_batch_enqueue_dev_u8(self.h, C.c_void_p(dptr), nframes, w, hgt, cn))
+
+    def enqueue_batch_host_ptrs(self, ptrs, w, hgt, cn):
+        """host frames (raw pointers, e.g. pinned torch tensors); collect with collect_batch"""
+        self._nb = len(ptrs)
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        self._chk(self.L.pbd_detect_batch_enqueue_u8(self.h, arr, len(ptrs), w, hgt, cn, w * cn))
+
+    def collect_batch(self, capacity=4096):
+        return self._batch_out(self._nb, capacity, lambda hd, bx, lc, cnt: self.L.pbd_detect_batch_collect(self.h, hd, bx, lc, capacity, cnt))
+
+    def _batch_out(self, nb, capacity, call):
+        heads = np.zeros(nb * capacity, HEAD_DTYPE)
+        boxes = np.zeros((nb * capacity, self.max_parts, 4), np.int32)
+        locs = np.zeros((nb * capacity, self.max_parts, 3), np.int32)
+        counts = (C.c_int * nb)()
+        self._chk(call(heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32), _p(locs, C.c_int32), counts))
+        return [self._out(heads[f * capacity:(f + 1) * capacity], boxes[f * capacity:(f + 1) * capacity],
+                          locs[f * capacity:(f + 1) * capacity], counts[f]) for f in range(nb)]
 
     def set_levels(self, levels):
         """Process only this set of pyramid levels (empty = all): multi-GPU level sharding."""

@@ -11,19 +11,20 @@ __device__ __forceinline__ int sat_short_dev(float v) {
   return i < -32768 ? -32768 : (i > 32767 ? 32767 : i);
 }
 
-// One launch for all first-octave levels: blockIdx.y = level, grid-stride over pixels.
-__global__ __launch_bounds__(256) void k_resize_linear_u8(ResizeArgs a, const uint8_t* __restrict__ src,
-                                                          uint8_t* __restrict__ pyr) {
-  const int lvl = blockIdx.y;
-  const int dw = a.dw[lvl], dh = a.dh[lvl], cn = a.cn, sw = a.sw, sh = a.sh;
-  uint8_t* dst = pyr + a.off[lvl];
+// One launch for all first-octave levels of all frames of a batch: blockIdx.y = job (frame, level), grid-stride over pixels.
+__global__ __launch_bounds__(256) void k_resize_linear_u8(const PyrJob* __restrict__ jobs, int cn, int sstride,
+                                                          const uint8_t* __restrict__ src0, uint8_t* __restrict__ pyr) {
+  const PyrJob a = jobs[blockIdx.y];
+  const int dw = a.dw, dh = a.dh, sw = a.sw, sh = a.sh;
+  const uint8_t* src = src0 + a.soff;
+  uint8_t* dst = pyr + a.doff;
   const int npix = dw * dh;
   const bool copy = (dw == sw && dh == sh);
   const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
     const int dy = i / dw, dx = i - dy * dw;
     if (copy) {
-      for (int c = 0; c < cn; ++c) dst[(size_t)i * cn + c] = src[(size_t)dy * a.sstride + dx * cn + c];
+      for (int c = 0; c < cn; ++c) dst[(size_t)i * cn + c] = src[(size_t)dy * sstride + dx * cn + c];
       continue;
     }
     float fx = (float)((dx + 0.5) * scale_x - 0.5);
@@ -39,8 +40,8 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(ResizeArgs a, const ui
     const int b0 = sat_short_dev((1.f - fy) * 2048), b1 = sat_short_dev(fy * 2048);
     int sy0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
     int sy1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
-    const uint8_t* S0 = src + (size_t)sy0 * a.sstride + sx * cn;
-    const uint8_t* S1 = src + (size_t)sy1 * a.sstride + sx * cn;
+    const uint8_t* S0 = src + (size_t)sy0 * sstride + sx * cn;
+    const uint8_t* S1 = src + (size_t)sy1 * sstride + sx * cn;
     for (int c = 0; c < cn; ++c) {
       int r0, r1;
       if (edge) { r0 = S0[c] * 2048; r1 = S1[c] * 2048; }
@@ -57,13 +58,13 @@ __device__ __forceinline__ int reflect101_dev(int p, int len) {
   return p;
 }
 
-// One launch per octave step: blockIdx.y selects the chain (level j <- level j-interval).
-__global__ __launch_bounds__(256) void k_pyrdown_u8(PyrDownArgs a, uint8_t* __restrict__ pyr) {
-  const int ch = blockIdx.y;
-  const int sw = a.sw[ch], sh = a.sh[ch], cn = a.cn;
+// One launch per octave step: blockIdx.y selects the chain (frame, level j <- level j-interval).
+__global__ __launch_bounds__(256) void k_pyrdown_u8(const PyrJob* __restrict__ jobs, int cn, uint8_t* __restrict__ pyr) {
+  const PyrJob a = jobs[blockIdx.y];
+  const int sw = a.sw, sh = a.sh;
   const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-  const uint8_t* src = pyr + a.soff[ch];
-  uint8_t* dst = pyr + a.doff[ch];
+  const uint8_t* src = pyr + a.soff;
+  uint8_t* dst = pyr + a.doff;
   const int wt[5] = {1, 4, 6, 4, 1};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dw * dh; i += gridDim.x * blockDim.x) {
     const int y = i / dw, x = i - y * dw;
@@ -85,16 +86,14 @@ __global__ __launch_bounds__(256) void k_pyrdown_u8(PyrDownArgs a, uint8_t* __re
   }
 }
 
-void launch_resize(const ResizeArgs& a, const uint8_t* src, uint8_t* pyr, hipStream_t s) {
-  int maxpix = 0;
-  for (int i = 0; i < a.n; ++i) maxpix = max(maxpix, a.dw[i] * a.dh[i]);
-  dim3 grid((maxpix + 255) / 256, a.n);
-  hipLaunchKernelGGL(k_resize_linear_u8, grid, dim3(256), 0, s, a, src, pyr);
+void launch_resize(const PyrJob* jobs, int njobs, int maxpix, int cn, int sstride, const uint8_t* src, uint8_t* pyr, hipStream_t s) {
+  if (njobs <= 0) return;
+  dim3 grid((maxpix + 255) / 256, njobs);
+  hipLaunchKernelGGL(k_resize_linear_u8, grid, dim3(256), 0, s, jobs, cn, sstride, src, pyr);
 }
 
-void launch_pyrdown(const PyrDownArgs& a, uint8_t* pyr, hipStream_t s) {
-  int maxpix = 0;
-  for (int i = 0; i < a.n; ++i) maxpix = max(maxpix, ((a.sw[i] + 1) / 2) * ((a.sh[i] + 1) / 2));
-  dim3 grid((maxpix + 255) / 256, a.n);
-  hipLaunchKernelGGL(k_pyrdown_u8, grid, dim3(256), 0, s, a, pyr);
+void launch_pyrdown(const PyrJob* jobs, int njobs, int maxpix, int cn, uint8_t* pyr, hipStream_t s) {
+  if (njobs <= 0) return;
+  dim3 grid((maxpix + 255) / 256, njobs);
+  hipLaunchKernelGGL(k_pyrdown_u8, grid, dim3(256), 0, s, jobs, cn, pyr);
 }

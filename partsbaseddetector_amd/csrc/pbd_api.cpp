@@ -401,23 +401,31 @@ static DtMap dt_map(const void* src, void* dst, int16_t* ptr, float wq, float wl
   return m;
 }
 
-static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
-  if (h->fw == w && h->fh == hgt && h->fcn == cn) return PBD_OK;
+static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
+  if (h->fw == w && h->fh == hgt && h->fcn == cn && h->batch == batch) return PBD_OK;
   if (cn != 1 && cn != 3) return fail(h, PBD_ERR_UNSUPPORTED, "image: 1 or 3 channels of 8 bits");
+  if (batch < 1 || batch > 64) return fail(h, PBD_ERR_ARG, "batch: 1..64 frames");
   hipStreamSynchronize(h->stream);
   free_frame(h);
   const pbd_model_desc& m = h->md;
   int n = 0;
-  if (w < 3 || hgt < 3 || compute_geometry(w, hgt, m.sbin, m.interval, &n, h->lv))
+  h->lv.assign((size_t)PBD_MAX_LEVELS * batch, Level{});
+  if (w < 3 || hgt < 3 || compute_geometry(w, hgt, m.sbin, m.interval, &n, h->lv.data()))
     return fail(h, PBD_ERR_ARG, "image too small: the pyramid needs at least `interval` levels "
                                 "(src/HOGFeatures.cpp:99,114)");
-  h->nlevels = n;
+  const int n1 = n;             // levels of one frame
+  h->nlevels = n1; h->batch = batch; h->nvl = n1 * batch;
+  h->lv.resize(h->nvl);
+  for (int f = 1; f < batch; ++f)
+    for (int l = 0; l < n1; ++l) h->lv[f * n1 + l] = h->lv[l];
+  n = h->nvl;                   // from here on `n` counts the virtual levels (frame f's level l = f * n1 + l)
   int lb = h->opt.level_begin, le = h->opt.level_end;
-  if (le <= 0 || le > n) le = n;
+  if (le <= 0 || le > n1) le = n1;
   if (lb < 0) lb = 0;
   size_t cells = 0, pyr = 0;
-  for (int l = 0; l < n; ++l) {
-    Level& L = h->lv[l];
+  for (int vl = 0; vl < n; ++vl) {
+    Level& L = h->lv[vl];
+    const int l = vl % n1;
     L.active = (l >= lb && l < le) && (h->level_set.empty() || (l < (int)h->level_set.size() && h->level_set[l]));
     if (L.cw > 32767 || L.ch > 32767) return fail(h, PBD_ERR_UNSUPPORTED, "level too large for 16-bit pointers");
     L.img_off = pyr; pyr += (size_t)L.iw * L.ih * cn;
@@ -426,7 +434,32 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
   h->cells = cells; h->pyr_bytes = pyr;
   if (cells >= (1u << 31)) return fail(h, PBD_ERR_UNSUPPORTED, "frame too large");
   int rc;
-  if ((rc = dev_alloc(h, &h->d_img, (size_t)w * hgt * cn))) return rc;
+  if ((rc = dev_alloc(h, &h->d_img, (size_t)w * hgt * cn * batch))) return rc;
+  {  // image pyramid jobs: the first octave of every frame from the frame (tightly packed, back to back), then the chains
+    std::vector<PyrJob> jobs;
+    h->pyr_launches.clear();
+    pbd_handle::PyrLaunch R{0, 0, 1};
+    for (int f = 0; f < batch; ++f)
+      for (int i = 0; i < m.interval; ++i) {
+        const Level& L = h->lv[f * n1 + i];
+        jobs.push_back(PyrJob{(unsigned long long)f * w * hgt * cn, (unsigned long long)L.img_off, w, hgt, L.iw, L.ih});
+        R.maxpix = std::max(R.maxpix, L.iw * L.ih);
+      }
+    R.njobs = (int)jobs.size();
+    h->pyr_launches.push_back(R);
+    for (int base = m.interval; base < n1; base += m.interval) {
+      pbd_handle::PyrLaunch D{(int)jobs.size(), 0, 1};
+      for (int f = 0; f < batch; ++f)
+        for (int j = base; j < std::min(base + m.interval, n1); ++j) {
+          const Level &S = h->lv[f * n1 + j - m.interval], &L = h->lv[f * n1 + j];
+          jobs.push_back(PyrJob{(unsigned long long)S.img_off, (unsigned long long)L.img_off, S.iw, S.ih, L.iw, L.ih});
+          D.maxpix = std::max(D.maxpix, L.iw * L.ih);
+        }
+      D.njobs = (int)jobs.size() - D.job0;
+      h->pyr_launches.push_back(D);
+    }
+    if ((rc = dev_upload(h, &h->d_pyrjobs, jobs))) return rc;
+  }
   const size_t ts = (size_t)h->ts;   // sizeof(T); T buffers are char* addressed as elements * ts
   if ((rc = dev_alloc(h, &h->d_resp, cells * m.nfilters * ts))) return rc;
   // Memory plan.  Default: every stage buffer has its own allocation and stays valid after detect() (the parity
@@ -834,20 +867,11 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn) {
 // stages
 // ---------------------------------------------------------------------------
 static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
-  const pbd_model_desc& m = h->md;
-  ResizeArgs ra{};
-  ra.n = m.interval; ra.sw = h->fw; ra.sh = h->fh; ra.cn = h->fcn; ra.sstride = stride;
-  for (int i = 0; i < m.interval; ++i) { ra.dw[i] = h->lv[i].iw; ra.dh[i] = h->lv[i].ih; ra.off[i] = h->lv[i].img_off; }
-  launch_resize(ra, d_src, h->d_pyr, h->stream);
-  for (int base = m.interval; base < h->nlevels; base += m.interval) {
-    PyrDownArgs pa{};
-    pa.cn = h->fcn;
-    for (int j = base; j < std::min(base + m.interval, h->nlevels); ++j) {
-      const int k = pa.n++;
-      pa.sw[k] = h->lv[j - m.interval].iw; pa.sh[k] = h->lv[j - m.interval].ih;
-      pa.soff[k] = h->lv[j - m.interval].img_off; pa.doff[k] = h->lv[j].img_off;
-    }
-    launch_pyrdown(pa, h->d_pyr, h->stream);
+  // one launch for the first octave of every frame of the batch (cv::resize), one per octave step below it (cv::pyrDown)
+  for (size_t i = 0; i < h->pyr_launches.size(); ++i) {
+    const pbd_handle::PyrLaunch& P = h->pyr_launches[i];
+    if (i == 0) launch_resize(h->d_pyrjobs + P.job0, P.njobs, P.maxpix, h->fcn, stride, d_src, h->d_pyr, h->stream);
+    else launch_pyrdown(h->d_pyrjobs + P.job0, P.njobs, P.maxpix, h->fcn, h->d_pyr, h->stream);
   }
   LAUNCHCHK(h, "image pyramid");
   h->have_pyr = true;
@@ -921,7 +945,7 @@ static int run_argmin_enqueue(pbd_handle* h) {
                    h->d_depth, h->max_depth, (int)h->parts.size(), h->d_scr_base, h->d_dt_ixT, h->d_dt_iy,
                    h->opt.dt_correct_ptr, h->ext_ptr ? h->d_extx : nullptr, h->d_exty, h->d_ext_base, h->stream);
   LAUNCHCHK(h, "argmin");
-  const int first = std::min(kFirstCopy, h->opt.max_candidates);
+  const int first = std::min(kFirstCopy * h->batch, h->opt.max_candidates);
   if (h->d_gsend) {   // member of an RCCL-gathering pbd_group: pack {count, first records} for the all-gather instead of the D2H
     HIPCHK(h, hipMemcpyAsync(h->d_gsend, h->d_cand_count, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_gsend + 16, h->d_cand_out, h->cand_stride * first, hipMemcpyDeviceToDevice, h->stream));
@@ -942,7 +966,7 @@ int pbd_i_finish_frame(pbd_handle* h, int found) {
     if (hipEventElapsedTime(&ms, h->ev_dp0, h->ev_dp1) == hipSuccess) { h->dp_ms_sum += ms; h->dp_frames++; }
   }
   const int n = std::min(found, h->opt.max_candidates);
-  const int first = std::min(kFirstCopy, h->opt.max_candidates);
+  const int first = std::min(kFirstCopy * h->batch, h->opt.max_candidates);
   if (n > first) {
     HIPCHK(h, hipMemcpyAsync(h->h_cand_out + h->cand_stride * first, h->d_cand_out + h->cand_stride * first,
                              h->cand_stride * (n - first), hipMemcpyDeviceToHost, h->stream));
@@ -1030,8 +1054,8 @@ static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
   }
   const size_t row = (size_t)h->fw * h->fcn;
   if (d_src != h->d_img) {
-    if ((size_t)stride == row) HIPCHK(h, hipMemcpyAsync(h->d_img, d_src, row * h->fh, hipMemcpyDeviceToDevice, h->stream));
-    else HIPCHK(h, hipMemcpy2DAsync(h->d_img, row, d_src, stride, row, h->fh, hipMemcpyDeviceToDevice, h->stream));
+    if ((size_t)stride == row) HIPCHK(h, hipMemcpyAsync(h->d_img, d_src, row * h->fh * h->batch, hipMemcpyDeviceToDevice, h->stream));
+    else HIPCHK(h, hipMemcpy2DAsync(h->d_img, row, d_src, stride, row, h->fh, hipMemcpyDeviceToDevice, h->stream));   // (strided sources: single frames only)
   }
   if (!h->gexec) {
     hipGraph_t graph = nullptr;
@@ -1195,6 +1219,69 @@ int pbd_detect_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int 
   int rc = pbd_detect_enqueue_u8(h, im, w, hgt, cn, stride);
   if (rc) return rc;
   return pbd_detect_collect(h, heads, boxes, locs, capacity, count);
+}
+
+// ---- a batch of same-sized frames through ONE handle ---------------------------------------------------------
+// (SURVEY 8b lists pbd_detect_batch_u8; configs[2] hands every GPU 4 frames.)  The frames of a batch are planned as
+// extra "virtual levels" (pbd_internal.hpp), so every stage is one launch — or one chain of launches — for the whole
+// batch: the same kernels, B times the blocks per launch.  Results per frame are identical to pbd_detect_u8.
+int pbd_detect_batch_enqueue_dev_u8(pbd_handle* h, const void* d_ims, int nframes, int w, int hgt, int cn) {
+  if (!h || !d_ims || nframes < 1) return PBD_ERR_ARG;
+  if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
+  ON_DEVICE(h);
+  int rc = plan_frame(h, w, hgt, cn, nframes);
+  if (rc) return rc;
+  return enqueue_all(h, (const uint8_t*)d_ims, w * cn);
+}
+int pbd_detect_batch_enqueue_u8(pbd_handle* h, const uint8_t* const* ims, int nframes, int w, int hgt, int cn, int stride) {
+  if (!h || !ims || nframes < 1) return PBD_ERR_ARG;
+  if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
+  if (stride < w * cn) return fail(h, PBD_ERR_ARG, "stride < w*cn");
+  ON_DEVICE(h);
+  int rc = plan_frame(h, w, hgt, cn, nframes);
+  if (rc) return rc;
+  const size_t fb = (size_t)w * cn * hgt;
+  for (int f = 0; f < nframes; ++f) {
+    if (!ims[f]) return fail(h, PBD_ERR_ARG, "null frame pointer");
+    if (stride == w * cn) HIPCHK(h, hipMemcpyAsync(h->d_img + fb * f, ims[f], fb, hipMemcpyHostToDevice, h->stream));
+    else HIPCHK(h, hipMemcpy2DAsync(h->d_img + fb * f, (size_t)w * cn, ims[f], stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice, h->stream));
+  }
+  return enqueue_all(h, h->d_img, w * cn);
+}
+// frame f's candidates at heads[f * capacity], boxes[f * capacity * max_parts * 4], locs[f * capacity * max_parts * 3];
+// counts[f] = number found in frame f (PBD_ERR_CAPACITY if any exceeds `capacity`)
+int pbd_detect_batch_collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* counts) {
+  if (!h || !heads || !counts || capacity < 0) return PBD_ERR_ARG;
+  if (!h->pending) return fail(h, PBD_ERR_STATE, "collect without a pending detect");
+  if (h->d_gsend) return fail(h, PBD_ERR_STATE, "handle belongs to an RCCL-gathering pbd_group: collect through the group");
+  ON_DEVICE(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const int found = h->h_cand_count[0];
+  int rc = pbd_i_finish_frame(h, found);
+  read_stage_times(h);
+  if (rc) return rc;
+  const int mp = h->max_parts, n1 = h->nlevels, B = h->batch;
+  std::vector<std::vector<const char*>> per(B);
+  for (int i = 0; i < found; ++i) {
+    const char* r = h->h_cand_out + h->cand_stride * i;
+    per[((const pbd_candidate_head*)r)->level / n1].push_back(r);
+  }
+  int status = PBD_OK;
+  for (int f = 0; f < B; ++f) {
+    counts[f] = (int)per[f].size();
+    pbd_candidate_head* hf = heads + (size_t)f * capacity;
+    rc = pbd_i_emit(h, per[f], hf, boxes ? boxes + (size_t)f * capacity * mp * 4 : nullptr, locs ? locs + (size_t)f * capacity * mp * 3 : nullptr, capacity);
+    if (rc == PBD_ERR_CAPACITY) { status = rc; continue; }
+    if (rc) return rc;
+    for (int i = 0; i < counts[f]; ++i) hf[i].level -= f * n1;   // virtual level -> the frame's own pyramid level
+  }
+  return status;
+}
+int pbd_detect_batch_u8(pbd_handle* h, const uint8_t* const* ims, int nframes, int w, int hgt, int cn, int stride,
+                        pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* counts) {
+  int rc = pbd_detect_batch_enqueue_u8(h, ims, nframes, w, hgt, cn, stride);
+  if (rc) return rc;
+  return pbd_detect_batch_collect(h, heads, boxes, locs, capacity, counts);
 }
 
 // ---- stage entry points -----------------------------------------------------
@@ -1413,8 +1500,8 @@ int pbd_set_dp_pointers(pbd_handle* h, int level, int component, int part, int p
     int rc;
     if ((rc = dev_alloc(h, &h->d_extx, n))) return rc;
     if ((rc = dev_alloc(h, &h->d_exty, n))) return rc;
-    std::vector<unsigned long long> base((size_t)h->nlevels * h->md.ncomponents);
-    for (int l = 0; l < h->nlevels; ++l)
+    std::vector<unsigned long long> base((size_t)h->nvl * h->md.ncomponents);
+    for (int l = 0; l < h->nvl; ++l)
       for (int c = 0; c < h->md.ncomponents; ++c)
         base[(size_t)l * h->md.ncomponents + c] = h->lv[l].cell_off * h->nplanes + (size_t)h->comp_plane0[c] * h->lv[l].cw * h->lv[l].ch;
     if ((rc = dev_upload(h, &h->d_ext_base, base))) return rc;
@@ -1579,12 +1666,13 @@ int pbd_resize_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int 
   uint8_t *d_im, *d_out;
   HIPCHK(h, hipMalloc(&d_im, (size_t)w * hgt * cn)); HIPCHK(h, hipMalloc(&d_out, (size_t)ow * oh * cn));
   HIPCHK(h, hipMemcpy2D(d_im, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
-  ResizeArgs ra{};
-  ra.n = 1; ra.sw = w; ra.sh = hgt; ra.cn = cn; ra.sstride = w * cn; ra.dw[0] = ow; ra.dh[0] = oh; ra.off[0] = 0;
-  launch_resize(ra, d_im, d_out, h->stream);
+  PyrJob job{0, 0, w, hgt, ow, oh}, *d_job;
+  HIPCHK(h, hipMalloc(&d_job, sizeof(job)));
+  HIPCHK(h, hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice));
+  launch_resize(d_job, 1, ow * oh, cn, w * cn, d_im, d_out, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, d_out, (size_t)ow * oh * cn, hipMemcpyDeviceToHost));
-  hipFree(d_im); hipFree(d_out);
+  hipFree(d_im); hipFree(d_out); hipFree(d_job);
   return PBD_OK;
 }
 
@@ -1595,12 +1683,13 @@ int pbd_pyrdown_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
   uint8_t* d_buf;
   HIPCHK(h, hipMalloc(&d_buf, sb + db));
   HIPCHK(h, hipMemcpy2D(d_buf, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
-  PyrDownArgs pa{};
-  pa.n = 1; pa.cn = cn; pa.sw[0] = w; pa.sh[0] = hgt; pa.soff[0] = 0; pa.doff[0] = sb;
-  launch_pyrdown(pa, d_buf, h->stream);
+  PyrJob job{0, (unsigned long long)sb, w, hgt, (w + 1) / 2, (hgt + 1) / 2}, *d_job;
+  HIPCHK(h, hipMalloc(&d_job, sizeof(job)));
+  HIPCHK(h, hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice));
+  launch_pyrdown(d_job, 1, job.dw * job.dh, cn, d_buf, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, d_buf + sb, db, hipMemcpyDeviceToHost));
-  hipFree(d_buf);
+  hipFree(d_buf); hipFree(d_job);
   return PBD_OK;
 }
 

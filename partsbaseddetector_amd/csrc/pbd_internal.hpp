@@ -35,16 +35,9 @@ struct Level {
 };
 
 // ---- kernel work tables -----------------------------------------------------
-struct ResizeArgs {  // levels 0..interval-1 (cv::resize) ; by value
-  int n, sw, sh, cn, sstride;
-  int dw[16], dh[16];
-  unsigned long long off[16];
-};
-struct PyrDownArgs { // one octave step: level j from level j-interval
-  int n, cn;
-  int sw[16], sh[16];
-  unsigned long long soff[16], doff[16];
-};
+// one image of the pyramid: level image (frame f, level l) from the frame itself (cv::resize, first octave) or from
+// level l - interval (cv::pyrDown); tables in device memory, one launch covers every job of a stage
+struct PyrJob { unsigned long long soff, doff; int sw, sh, dw, dh; };
 struct HogTile { int level, cy0, cx0, pad; };
 struct LevelDev {    // per level, device copy
   int iw, ih, bw, bh, cw, ch;
@@ -151,8 +144,15 @@ struct pbd_handle {
   int* d_nparts = nullptr;
 
   // frame plan
-  int fw = 0, fh = 0, fcn = 0, nlevels = 0;
-  Level lv[PBD_MAX_LEVELS];
+  int fw = 0, fh = 0, fcn = 0, nlevels = 0;     // nlevels: levels of ONE frame
+  // A batch of B same-sized frames is planned as B x nlevels "virtual levels" (frame f's level l = f * nlevels + l):
+  // every stage is driven by per-level tables, so one launch of a stage then covers all frames of the batch — four
+  // times the blocks per launch, the thin rounds of the DP fill the chip and launch tails are paid once per batch.
+  int batch = 1, nvl = 0;                       // frames per plan, virtual levels = batch * nlevels
+  std::vector<Level> lv;                        // [nvl]
+  PyrJob* d_pyrjobs = nullptr;                  // resize jobs, then the pyrDown jobs octave by octave
+  struct PyrLaunch { int job0, njobs, maxpix; };
+  std::vector<PyrLaunch> pyr_launches;          // [0]: resize, [1..]: pyrDown octave steps
   size_t cells = 0, pyr_bytes = 0;
   bool have_pyr = false, have_feat = false, have_resp = false, have_dp = false;
 
@@ -266,8 +266,8 @@ int pbd_i_emit(pbd_handle* h, const std::vector<const char*>& recs, pbd_candidat
 #define PBD_FIRST_COPY 192   // candidate records fetched (or gathered) together with the count
 
 // ---- kernel launchers (k_*.hip) ----------------------------------------------
-void launch_resize(const ResizeArgs& a, const uint8_t* src, uint8_t* pyr, hipStream_t s);
-void launch_pyrdown(const PyrDownArgs& a, uint8_t* pyr, hipStream_t s);
+void launch_resize(const PyrJob* jobs, int njobs, int maxpix, int cn, int sstride, const uint8_t* src, uint8_t* pyr, hipStream_t s);
+void launch_pyrdown(const PyrJob* jobs, int njobs, int maxpix, int cn, uint8_t* pyr, hipStream_t s);
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
                 int cn, int sbin, int tc, hipStream_t s);
 size_t hog_lds_bytes(int sbin, int tc, int ts);

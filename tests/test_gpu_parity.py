@@ -948,6 +948,53 @@ def test_group_batch_two_handles_one_gpu_equals_single_handle(gpu_required, orc)
     single.close(); g3.close()
 
 
+def test_detect_batch_equals_single_frames(gpu_required, orc):
+    """pbd_detect_batch_u8: the frames of a batch go through every stage in ONE launch per stage (virtual pyramid levels);
+    per frame the candidates are exactly those of pbd_detect_u8 and of the oracle — exact and MFMA filter banks, a batch
+    size change (re-plan), graph replay, the asynchronous halves with frames resident in device memory."""
+    import torch
+    m = make_tree_model([-1, 0, 1, 1, 0, 4], 3, seed=5)
+    frames = [make_image(i, 200, 150) for i in range(5)]
+    m.thresh = thresh_from_oracle(orc, m, frames[0], 99.3)
+    refs = [orc.detect(m, f)[:3] for f in frames]
+    for graph in (0, 1):
+        h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, graph=graph)
+        for nb in (3, 5, 1, 3):
+            for rep in range(2 + graph):
+                for got, ref in zip(h.detect_batch(frames[:nb]), refs):
+                    assert_candidates_equal(got, ref)
+        assert_candidates_equal(h.detect(frames[4]), refs[4])        # single-frame entry on the same handle
+        dev = torch.from_numpy(np.stack(frames[1:4])).cuda()
+        h.enqueue_batch_dev(dev.data_ptr(), 3, 200, 150, 3)
+        for got, ref in zip(h.collect_batch(), refs[1:4]):
+            assert_candidates_equal(got, ref)
+        with pytest.raises(capi.PbdError) as e:
+            h.detect_batch(frames[:2], capacity=1)
+        assert e.value.code == capi.PBD_ERR_CAPACITY
+        h.close()
+    hm = capi.Handle(m)   # AUTO -> MFMA; compared with the single-frame MFMA path (same kernels, same numbers)
+    for got, f in zip(hm.detect_batch(frames[:4]), frames):
+        assert_candidates_equal(got, hm.detect(f))
+    hm.close()
+    hd = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dtype=np.float64)
+    for got, f in zip(hd.detect_batch(frames[:2]), frames):
+        assert_candidates_equal(got, orc.detect(m, f, dtype=np.float64)[:3])
+    hd.close()
+
+
+def test_detect_batch_person_model_640x480(gpu_required, orc):
+    """The timed shape: batches of 4 person-model frames at 640x480 == the oracle (exact filter bank), frame by frame."""
+    m = make_person_model()
+    frames = [make_image(i, 640, 480) for i in range(4)]
+    m.thresh = thresh_from_oracle(orc, m, frames[0], 99.9)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, graph=1)
+    for rep in range(3):
+        outs = h.detect_batch(frames)
+    for got, f in zip(outs, frames):
+        assert_candidates_equal(got, orc.detect(m, f)[:3])
+    h.close()
+
+
 def test_group_batch_configs2_shape(gpu_required, orc):
     """BASELINE configs[2]'s real shape: 32 person-model frames of 640x480 through pbd_group_detect_batch_u8, members
     [0, 0, 0, 0] (on an 8-GPU node: [0..7], 4 frames each) == a single handle for all 32 frames and == the oracle for 4."""
