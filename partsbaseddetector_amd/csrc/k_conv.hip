@@ -681,6 +681,8 @@ void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* l
   if (nhalf == 5) launch_conv_mfma16_t<float, 2, 3, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);        // two n-tiles (32 filters) per workgroup
   else if (nhalf == 6) launch_conv_mfma16_t<float, 2, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 7) launch_conv_mfma16_t<float, 1, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);   // whole tile, 32 filters
+  else if (nhalf == 8) launch_conv_mfma16_t<float, 2, 2, 5>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);   // five n-tiles (80 filters) per workgroup
+  else if (nhalf == 9) launch_conv_mfma16_t<float, 2, 3, 5>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 2) launch_conv_mfma16_t<float, 2, 5>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 3) launch_conv_mfma16_t<float, 2, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 4) launch_conv_mfma16_t<float, 4, 3>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
