@@ -149,7 +149,7 @@ def main():
                     help="ONE process driving --gpus N devices through pbd_group (no torchrun): every device listed --inflight "
                          "times, frames round-robin and software-pipelined over the members, host images in (H2D inside "
                          "the timed region), host gather of the candidates")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PBD_BATCH", "1")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PBD_BATCH", "3")),
                     help="frames per step and handle: >1 hands every handle a BATCH of same-sized frames (pbd_detect_batch_*: one "
                          "launch per stage for the whole batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -223,14 +223,14 @@ def main():
         if world > 1:
             gathered_last[0] = gather_candidates(out, handles[0].max_parts, capacity=cap, device=cdev, dst=0)
 
-    def collect_one(hd):
+    def collect_one(hd, B):
         """the step's candidates: one frame's, or the batch's (concatenated: (level, component, root) order inside a frame)"""
         if B == 1:
             return hd.collect(cap)
         outs_b = hd.collect_batch(cap)
         return tuple(np.concatenate([o[k] for o in outs_b]) for k in range(3))
 
-    def run(nsteps, collect_out=None, stamps=None, host=False):
+    def run(nsteps, collect_out=None, stamps=None, host=False, B=B):
         """S frames in flight; host=True hands over pinned host images (H2D inside every step).  N > 1: every
         step's candidates are gathered to rank 0 — after the next frame has been enqueued, so the collective
         overlaps the GPU's work on the frames in flight."""
@@ -239,7 +239,7 @@ def main():
             hd = handles[i % S]
             out = None
             if len(pending) == S:
-                out = collect_one(pending.pop(0))
+                out = collect_one(pending.pop(0), B)
                 if stamps is not None:
                     stamps.append(time.perf_counter())
                 if collect_out is not None:
@@ -257,21 +257,21 @@ def main():
             if out is not None:
                 gather(out)
         for hd in pending:
-            out = collect_one(hd)
+            out = collect_one(hd, B)
             if stamps is not None:
                 stamps.append(time.perf_counter())
             if collect_out is not None:
                 collect_out.append(out)
             gather(out)
 
-    def timed(nsteps, host):
+    def timed(nsteps, host, B=B):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         outs, stamps = [], [t0]
-        run(nsteps, outs, stamps, host=host)
+        run(nsteps, outs, stamps, host=host, B=B)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -304,6 +304,12 @@ def main():
         ncand_all = sum(len(g[0]) for g in gathered_last[0]) if rank == 0 else 0   # the last step's gather (inside the timed region)
     else:
         ncand_all = len(outs[-1][0])
+
+    # ---- the same handles called one frame at a time (pbd_detect_enqueue_dev_u8 / collect: S single frames in flight) ----
+    dt_single = None
+    if B > 1:
+        run(3 * S, B=1)                      # re-plan for single frames (untimed)
+        dt_single, _, _ = timed(args.steps * B, host=False, B=1)
 
     # ---- sequential leg: one frame in flight on one handle, host image in, candidates out (pbd_detect_u8 semantics) ----
     hd = handles[0]
@@ -376,8 +382,10 @@ def main():
             "frame_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),
                          "what": "completion-to-completion wall time per step (one frame, or one batch) in the timed loop (rank 0)"},
             "value_resident": round(value, 3), "value_incl_h2d": round(value_h2d, 3),
+            "value_single_frame_calls": (round(args.steps * B * (1 if by_levels else world) / dt_single, 3) if dt_single else round(value, 3)),
             "value_is": "frames resident in HBM when the timed region starts (this tier's contract for `value`); the H2D-inclusive "
-                        "figure of SURVEY 8d is value_incl_h2d",
+                        "figure of SURVEY 8d is value_incl_h2d; value_single_frame_calls = the same handles fed one frame per call "
+                        "(pbd_detect_enqueue_dev_u8) instead of batches",
             "incl_h2d": {"value": round(value_h2d, 3), "unit": "frames/s", "ms_per_step": round(dt_h2d / args.steps * 1e3, 4),
                          "frame_ms": {"median": pct(per_frame_ms_h2d, 50), "p10": pct(per_frame_ms_h2d, 10), "p90": pct(per_frame_ms_h2d, 90)},
                          "what": "the same K steps with every frame handed over as a pinned host image (pbd_detect_enqueue_u8: "

@@ -890,10 +890,13 @@ static int run_pdf(pbd_handle* h) {
   if (h->conv_mode == PBD_CONV_MFMA)
     if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT, (double*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
     else {
-      // default: 16x16x4 MFMA, tile staged in two channel halves (k_conv_mfma16<float, 2>: 27 KB of LDS per
-      // workgroup, so DT blocks of other frames co-reside on the CU); PBD_MFMA_VARIANT=0 selects the older
-      // 32x32x2 kernel, 1 the whole-tile variant, 2 the halves at 5 waves/SIMD (A/B knob)
-      static const int variant = PBD_PROBE_ENV("PBD_MFMA_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_MFMA_VARIANT")) : 3;
+      // default (5): 16x16x4 MFMA, tile staged in two channel halves, TWO 16-filter n-tiles per workgroup (k_conv_mfma16<float,
+      // 2, 3, 2>: 27 KB of LDS per workgroup, so DT blocks of other frames co-reside on the CU).  Alone the kernel takes the
+      // same 0.38 ms as with one n-tile per workgroup (3), but it stages every tile half as often, and with frames in
+      // flight that VALU / LDS time goes to the other frames' DT blocks: 1 392 vs 1 331 frames/s (batches of 4 on 3
+      // handles), 1 287 vs 1 258 (single frames on 4).  PBD_MFMA_VARIANT (probe / tuning builds): 0 = the older 32x32x2
+      // kernel, 1 = whole tile, 2 = halves at 5 waves/SIMD, 3 = one n-tile, 4 = channel quarters, 6-9 = further n-tile counts
+      static const int variant = PBD_PROBE_ENV("PBD_MFMA_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_MFMA_VARIANT")) : 5;
       if (variant && m.kh == 5 && m.kw == 5)
         launch_conv_mfma16_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT, (float*)h->d_resp, m.nfilters, h->nfpad, variant, h->stream);
       else

@@ -10,11 +10,15 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-B="python $REPO/bench.py --graph 0 --no-prewarm"   # eager launches under the profiler (the timed loop of the default run replays a hipGraph)
+B="python $REPO/bench.py --graph 0 --no-prewarm --batch 1"   # eager launches, single frames under the profiler (the timed loop of the default run replays a hipGraph of a batch)
 # throughput line (default flags) and the sequential line
 python $REPO/bench.py --steps 300 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_n1_driverflags.json" 2>> "$OUT/bench_n1.err"
 $B --steps 100 --inflight 1 --no-cpu-baseline > "$OUT/bench_n1_inflight1.json" 2>> "$OUT/bench_n1.err"
+python $REPO/bench.py --steps 300 --inflight 4 --batch 1 --no-cpu-baseline > "$OUT/bench_n1_b1.json" 2>> "$OUT/bench_n1.err"
+for sb in "3 4" "4 4" "3 8" "2 8"; do set -- $sb; python $REPO/bench.py --steps 60 --inflight $1 --batch $2 --no-cpu-baseline 2>> "$OUT/bench_n1.err" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('inflight $1 batch $2:', d['value'], 'frames/s')" >> "$OUT/sweep_sb.txt"; done
+python $REPO/tests/tools_batch_stages.py 1 2 4 8 > "$OUT/batch_stages.txt" 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_batch" -o run -- python $REPO/bench.py --graph 0 --no-prewarm --steps 12 --warmup 3 --inflight 1 --batch 4 --no-cpu-baseline > "$OUT/stats_batch.log" 2>&1
 $B --steps 50 --dtype f64 > "$OUT/bench_n1_f64.json" 2>> "$OUT/bench_n1.err"
 # per-kernel durations: sequential (undisturbed) and default (4 frames in flight)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_seq" -o run -- $B --steps 20 --warmup 3 --inflight 1 --no-cpu-baseline > "$OUT/stats_seq.log" 2>&1
