@@ -28,8 +28,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_f64" -o run 
 for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o run -- $B --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline > "$OUT/pmc_$c.log" 2>&1
 done
+# the same two counters on the benched unit of work: one launch chain per batch of 3 frames, batches one at a time
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmcb3_$c" -o run -- python $REPO/bench.py --graph 0 --no-prewarm --batch 3 --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline > "$OUT/pmcb3_$c.log" 2>&1
+done
 # SQ activity of the distance-transform / reduce / filter-bank kernels: one counter per pass
-for c in SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT; do
+for c in SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/sq_$c" -o run -- $B --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline > "$OUT/sq_$c.log" 2>&1
 done
 # configs[4]: direct VALU correlation vs MFMA implicit GEMM for N = 26 .. 312 filters (stage times + per-kernel view)

@@ -35,9 +35,9 @@ def stats_table(d):
     return "\n".join(out), f[0]
 
 
-def pmc(counter):
-    f = glob.glob(os.path.join(src, f"pmc_{counter}", "*counter_collection.csv")) + \
-        glob.glob(os.path.join(src, f"pmc_{counter}", "*", "*counter_collection.csv"))
+def pmc(counter, prefix="pmc"):
+    f = glob.glob(os.path.join(src, f"{prefix}_{counter}", "*counter_collection.csv")) + \
+        glob.glob(os.path.join(src, f"{prefix}_{counter}", "*", "*counter_collection.csv"))
     if not f:
         return {}
     acc = {}
@@ -52,14 +52,38 @@ def pmc(counter):
     return acc
 
 
+def pmc_chains(counter, prefix):
+    """dp_min launch chains of a pass in dispatch order (one frame in flight): each chain is the k_dt_pass launches up to and including
+    a k_root launch; returns {k_root grid size: [chains, summed counter]} — the batch chains have the larger k_root grid."""
+    f = glob.glob(os.path.join(src, f"{prefix}_{counter}", "*counter_collection.csv")) + \
+        glob.glob(os.path.join(src, f"{prefix}_{counter}", "*", "*counter_collection.csv"))
+    if not f:
+        return {}
+    rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    out, cur = {}, 0.0
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        if k.startswith(("k_dt_pass", "k_reduce")):
+            cur += float(r["Counter_Value"])
+        elif k.startswith("k_root"):
+            a = out.setdefault(int(r["Grid_Size"]), [0, 0.0])
+            a[0] += 1
+            a[1] += cur + float(r["Counter_Value"])
+            cur = 0.0
+    return out
+
+
 md = [f"# {tag}: rocprofv3 summaries (MI355X, gfx950).  Collected by `profiles/collect.sh {tag}` (run from the repo root "
       "through gpurun), summarised by `profiles/summarize.py`.  bench.py = 26x6 person model, 640x480.", ""]
 for d, title in (("stats_seq", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --inflight 1 --no-cpu-baseline\n"
                   "(sequential frames: per-kernel durations undisturbed)"),
-                 ("stats", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline\n"
-                  "(default: 4 frames in flight on 4 streams, 8 hardware queues; kernels of different frames overlap)"),
+                 ("stats", "rocprofv3 --kernel-trace --stats -- python bench.py --graph 0 --no-prewarm --batch 1 --steps 20 --warmup 3 --no-cpu-baseline\n"
+                  "(4 single frames in flight on 4 streams; kernels of different frames overlap)"),
                  ("stats_f64", "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --inflight 1 --dtype f64 --no-cpu-baseline\n"
-                  "(PartsBasedDetector<double>, sequential)")):
+                  "(PartsBasedDetector<double>, sequential)"),
+                 ("stats_batch", "rocprofv3 --kernel-trace --stats -- python bench.py --graph 0 --no-prewarm --steps 12 --warmup 3 --inflight 1 --batch 4 --no-cpu-baseline\n"
+                  "(batches of 4 frames, one launch per stage for the batch, batches one at a time)")):
     t, path = stats_table(d)
     if t:
         md += [f"## {title}", t, ""]
@@ -86,12 +110,31 @@ if fetch:
     dpk = [k for k in fetch if k.startswith(("k_dt_pass", "k_reduce", "k_root"))]
     fb = sum(fetch[k][1] for k in dpk) * 1e3 / nframes
     wb = sum(write.get(k, [0, 0.0])[1] for k in dpk) * 1e3 / nframes_w
-    json.dump({"round": tag, "source": f"profiles/{tag}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --inflight 1)",
-               "kernels": sorted(dpk), "fetch_bytes_raw": fb, "write_bytes": wb,
-               "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated, taken as is",
-               "hbm_bytes_per_frame_corrected": 2 * fb + wb}, open(os.path.join(HERE, "traffic_dp.json"), "w"), indent=1)
+    tj = {"round": tag, "source": f"profiles/{tag}_rocprof_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --inflight 1)",
+          "kernels": sorted(dpk), "fetch_bytes_raw": fb, "write_bytes": wb,
+          "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated, taken as is",
+          "hbm_bytes_per_frame_corrected": 2 * fb + wb}
     md += ["", f"dp_min stage ({', '.join(sorted(dpk))}): fetch {fb / 1e6:.1f} MB raw (x2 = {2 * fb / 1e6:.1f} MB) + write {wb / 1e6:.1f} MB "
            f"= {(2 * fb + wb) / 1e6:.1f} MB per frame (algorithmic B_dp: see bench line)."]
+    BF = 3
+    fetch_b, write_b = pmc("FETCH_SIZE", f"pmcb{BF}"), pmc("WRITE_SIZE", f"pmcb{BF}")
+    if fetch_b and write_b:
+        # the run also holds single-frame legs: keep the chains whose k_root grid is the batch's (the largest)
+        cf, cw = pmc_chains("FETCH_SIZE", f"pmcb{BF}"), pmc_chains("WRITE_SIZE", f"pmcb{BF}")
+        gb = max(cf)
+        nl = cf[gb][0]
+        dpb = [k for k in fetch_b if k.startswith(("k_dt_pass", "k_reduce", "k_root"))]
+        fbb = cf[gb][1] * 1e3 / nl
+        wbb = cw[gb][1] * 1e3 / cw[gb][0]
+        tj["batch"] = {"frames_per_launch": BF, "kernels": sorted(dpb), "fetch_bytes_raw": fbb, "write_bytes": wbb,
+                       "hbm_bytes_per_launch_corrected": 2 * fbb + wbb, "hbm_bytes_per_frame_corrected": (2 * fbb + wbb) / BF}
+        md += ["", f"the same passes with `--batch {BF}` (one launch chain per batch of {BF} frames, {nl} chains per run): dp_min stage fetch "
+               f"{fbb / 1e6:.1f} MB raw (x2 = {2 * fbb / 1e6:.1f} MB) + write {wbb / 1e6:.1f} MB = {(2 * fbb + wbb) / 1e6:.1f} MB per launch chain "
+               f"= {(2 * fbb + wbb) / BF / 1e6:.1f} MB per frame.",
+               "| kernel | calls | FETCH KB/call | WRITE KB/call |", "|---|---|---|---|"]
+        gs = min(cf)
+        md[-2:] = [f"(single-frame chains of the same run, for comparison: {(2 * cf[gs][1] / cf[gs][0] + cw[gs][1] / cw[gs][0]) / 1e3:.1f} MB per frame.)"]
+    json.dump(tj, open(os.path.join(HERE, "traffic_dp.json"), "w"), indent=1)
 # SQ counters (one per pass) for the kernels of the dp_min stage and the filter bank
 sq = {}
 for d in sorted(glob.glob(os.path.join(src, "sq_*"))):
@@ -133,7 +176,11 @@ if os.path.exists(cm) and os.path.getsize(cm):
     if t:
         md += ["", "per-kernel view of the same script (rocprofv3 --kernel-trace --stats):", t]
         shutil.copy(path, os.path.join(HERE, f"{tag}_kernel_stats_conv_modes.csv"))
-for b in ("bench_n1.json", "bench_n1_driverflags.json", "bench_n1_inflight1.json", "bench_n1_f64.json"):
+for t_ in ("sweep_sb.txt", "batch_stages.txt"):
+    p = os.path.join(src, t_)
+    if os.path.exists(p) and os.path.getsize(p):
+        md += ["", f"## {t_}", "```", open(p).read().strip(), "```"]
+for b in ("bench_n1.json", "bench_n1_driverflags.json", "bench_n1_b1.json", "bench_n1_inflight1.json", "bench_n1_f64.json"):
     p = os.path.join(src, b)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(HERE, f"{tag}_{b}"))
