@@ -19,13 +19,23 @@
 // workgroup (border values materialised there) and write plane-major outputs.
 #include <algorithm>
 #include "pbd_internal.hpp"
+#include <type_traits>
 
 // debug: per-phase wall-clock stamps (100 MHz) of one workgroup of the last k_conv_mfma launch
 #ifdef PBD_PROBES
 __device__ unsigned long long pbd_conv_dbg[8];
 #define CONV_STAMP(i) do { if (blockIdx.x == 300 && blockIdx.y == 2 && threadIdx.x == 0) pbd_conv_dbg[i] = wall_clock64(); } while (0)
 void conv_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(pbd_conv_dbg), sizeof(unsigned long long) * 8); }
+// k_conv_glds: per-phase sums over the units of one workgroup (wave 0 lane 0), slots: 0 = barrier waits before the K loops, 1 = both K loops, 2 = barrier before the epilogue, 4 = shader cycles of both K loops (s_memtime), 5 = epilogue; 6 = units; 7 = life
+#define GLDS_T(var) const unsigned long long var = wall_clock64()
+#define GLDS_C(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define GLDS_ACC(i, a, b) do { if (blockIdx.x == gridDim.x / 2 + 3 && threadIdx.x == 0) pbd_conv_dbg[i] += (b) - (a); } while (0)
+#define GLDS_INIT() do { if (blockIdx.x == gridDim.x / 2 + 3 && threadIdx.x == 0) for (int q_ = 0; q_ < 8; ++q_) pbd_conv_dbg[q_] = 0; } while (0)
 #else
+#define GLDS_T(var) do { } while (0)
+#define GLDS_C(var) do { } while (0)
+#define GLDS_ACC(i, a, b) do { } while (0)
+#define GLDS_INIT() do { } while (0)
 #define CONV_STAMP(i) do { } while (0)
 void conv_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i] = 0; }
 #endif
@@ -478,7 +488,10 @@ template <> struct Mfma16<float> {
   static __device__ __forceinline__ int drow(int reg, int ak) { return 4 * ak + reg; }
 };
 
-template <typename T, int KH, int KW, int NHALF, int WPE, int NTW = 1>   // WPE: waves per SIMD the register allocation must allow; NTW: 16-filter n-tiles per workgroup
+// B4 (float, two channel halves): wT is the [tap][half][k][nfpad][u] copy of the filters (channel 16 half + 4 u + k): a lane reads its four
+// k-steps of a tap and n-tile with ONE 16-byte load instead of four global_load_dword (which cost the MFMA pipe a quarter of its
+// issue rate with two waves per SIMD: tests/tools/mfma_rate_probe.hip)
+template <typename T, int KH, int KW, int NHALF, int WPE, int NTW = 1, bool B4 = false>   // WPE: waves per SIMD the register allocation must allow; NTW: 16-filter n-tiles per workgroup
 __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __restrict__ tiles,
                                                      const LevelDev* __restrict__ levels,
                                                      const T* __restrict__ feat, const T* __restrict__ wT,
@@ -520,7 +533,9 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   const int nbase = ntile_i * (16 * NTW);
   const T* F = feat + lv.cell_off * PBD_FLEN;
   const int ai = lane & 15, ak = lane >> 4;
-  const T* bsrc = wT + (size_t)ak * nfpad + nbase + ai;     // B[k = ak][j = ai] of k-step 0, tap 0, half 0, n-tile 0 (n-tile nt: + 16 nt)
+  static_assert(!B4 || (sizeof(T) == 4 && NHALF == 2), "16-byte B loads: float, two 16-channel halves");
+  const T* bsrc = B4 ? wT + ((size_t)ak * nfpad + nbase + ai) * 4      // w4[tap 0][half 0][k = ak][filter nbase + ai][u = 0..3]
+                     : wT + (size_t)ak * nfpad + nbase + ai;           // B[k = ak][j = ai] of k-step 0, tap 0, half 0, n-tile 0 (n-tile nt: + 16 nt)
   typename MM::acc_t acc[NTW][4];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
@@ -546,10 +561,21 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
     if (half) __syncthreads();
     const T* bh = bsrc + (size_t)(half * CH) * nfpad;
     T b0[NTW][KS], b1[NTW][KS];
+    auto load_tap = [&](T (&dst)[NTW][KS], int tap) {
+      const T* bs = bh + (size_t)min(tap, NTAP - 1) * PBD_FLEN * nfpad;
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
+      for (int nt = 0; nt < NTW; ++nt) {
+        if constexpr (B4) {
+          const V w = *(const V*)(bs + 64 * nt);
 #pragma unroll
-      for (int u = 0; u < KS; ++u) b0[nt][u] = bh[(size_t)(4 * u) * nfpad + 16 * nt];   // tap 0, issued before the staging
+          for (int u = 0; u < KS; ++u) dst[nt][u] = w.e[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < KS; ++u) dst[nt][u] = bs[(size_t)(4 * u) * nfpad + 16 * nt];
+        }
+      }
+    };
+    load_tap(b0, 0);   // tap 0, issued before the staging
     {  // stage CH channels of every cell: LPC lanes x 16 B per cell, batches of independent loads
       constexpr int N = TH * TW * LPC, NB = (N + 255) / 256, BATCH = 7;
       for (int j0 = 0; j0 < NB; j0 += BATCH) {
@@ -580,13 +606,6 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
     }
     __syncthreads();
     CONV_STAMP(1 + 2 * half);
-    auto load_tap = [&](T (&dst)[NTW][KS], int tap) {
-      const T* bs = bh + (size_t)min(tap, NTAP - 1) * PBD_FLEN * nfpad;
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-        for (int u = 0; u < KS; ++u) dst[nt][u] = bs[(size_t)(4 * u) * nfpad + 16 * nt];
-    };
     auto mma_tap = [&](const T (&bw)[NTW][KS], int tap) {
       const int ti = tap / KW, tj = tap - ti * KW;
       const T* a = ft + (ti * TW + tj) * CS;
@@ -644,15 +663,220 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   CONV_STAMP(6);
 }
 
-template <typename T, int NHALF, int WPE, int NTW = 1>
+template <typename T, int NHALF, int WPE, int NTW = 1, bool B4 = false>
 static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
                                  const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
   const size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + (sizeof(T) == 4 ? 2 : 1)), sizeof(T) * 4 * 16 * 65);
   static LdsOptIn optin;   // one per instantiation
-  optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>, lds);
+  optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW, B4>, lds);
   dim3 grid((ntiles + 7) / 8 * 8, (nf + 16 * NTW - 1) / (16 * NTW));   // tiles padded to a multiple of 8 (XCD-aware mapping in the kernel)
   static const int prio_mode = PBD_PROBE_ENV("PBD_CONV_PRIO") ? atoi(PBD_PROBE_ENV("PBD_CONV_PRIO")) : 0;   // probe build only
-  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles);
+  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW, B4>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles);
+}
+
+// ---------------------------------------------------------------------------
+// k_conv_glds: the fp32 filter bank as a PERSISTENT, double-buffered workgroup.  k_conv_mfma16 runs the MFMA pipe at
+// ~93 % while its K loops run, but every workgroup first stages its tile (global -> registers -> LDS, 9 + 5 us of a
+// 75 us life) and ends with an epilogue, and co-resident workgroups run those phases in step: over the whole kernel
+// the pipe is ~66 % busy.  Here a workgroup loops over work units (tile, pair of 16-filter n-tiles) and the NEXT
+// channel half (of this unit, or half 0 of the next unit) streams into the other LDS buffer with
+// global_load_lds_dwordx4 (LDS-DMA: no staging registers, no ds_write pass) while the MFMAs of the current half
+// run.  LDS image of a half: [cell 0..399][16 channels], 64 B per cell, lane-linear as the DMA writes it (piece p =
+// cells 16 p .. 16 p + 15, lane = 4 (cell & 15) + 16-byte chunk); border cells are DMA'd from a constant cell
+// (0, and 1 for the truncation channel 31, src/SpatialConvolutionEngine.cpp:147-155).  A operand: lane (i, k) reads ONE
+// ds_read_b128 per M-tile and tap = channels 4k .. 4k+3 of its cell, which feed k-steps s = 0..3 (k-step s contracts
+// channels {s, 4+s, 8+s, 12+s}; the B rows are picked to match) -- the 16 cells of a full-width M-tile are 1 KB
+// contiguous: conflict-free without padding.  Units of XCD x: tile positions 8 g + x (same convention as
+// k_conv_mfma16, so the plan's neighbour pairing holds), n-pairs minor: the n-pairs of one tile are taken by adjacent
+// workgroups of the XCD at the same time (one HBM fetch of the tile, L2 hits for the others).
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void pbd_lds_void;
+typedef __attribute__((address_space(1))) const void pbd_glb_cvoid;
+
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void k_conv_glds(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
+                                                        const float* __restrict__ feat, const float* __restrict__ wT,
+                                                        float* __restrict__ resp, int nf, int nfpad, int ntiles,
+                                                        const float* __restrict__ border) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TW = CT + 4, NCELL = TW * TW, NTAP = 25, NTW = 2, CH = 16, CELLB = CH * 4, BUFB = NCELL * CELLB, NPIECE = NCELL / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ai = lane & 15, ak = lane >> 4;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nwx = gridDim.x >> 3;
+  const int np = (nf + 16 * NTW - 1) / (16 * NTW);
+  const int ntx = ntiles > xcd ? (ntiles - xcd + 7) >> 3 : 0;     // tile positions xcd, xcd + 8, ...
+  const int nunits = ntx * np;
+  char* const buf0 = smem;
+  char* const buf1 = smem + BUFB;
+
+  // one wave's share of the LDS-DMA pieces of channel half `half` of the tile at (y0, x0) of a W x H level: 16 cells x 64 B per piece
+  auto issue_stage = [&](int y0, int x0, int W, int H, size_t cell_off, int half, char* buf) {
+    const float* F = feat + cell_off * PBD_FLEN + half * CH + 4 * (lane & 3);
+    const float* bz = border + half * CH + 4 * (lane & 3);
+    for (int p = wave; p < NPIECE; p += 4) {
+      const int cell = 16 * p + (lane >> 2);
+      const int ty = cell / TW, tx = cell - ty * TW;
+      const int y = y0 + ty - 2, x = x0 + tx - 2;
+      const bool inside = (y >= 0 && y < H && x >= 0 && x < W);
+      const float* src = inside ? F + ((size_t)y * W + x) * PBD_FLEN : bz;
+      __builtin_amdgcn_global_load_lds((pbd_glb_cvoid*)src, (pbd_lds_void*)(buf + p * 1024), 16, 0, 0);
+    }
+  };
+
+  int v = j;
+  if (v >= nunits) return;
+  int y0, x0, W, H;
+  size_t cell_off;
+  {
+    const ConvTile t = tiles[xcd + 8 * (v / np)];
+    const LevelDev lv = levels[t.level];
+    y0 = t.y0; x0 = t.x0; W = lv.cw; H = lv.ch; cell_off = lv.cell_off;
+  }
+  GLDS_INIT();
+  GLDS_T(tl0);
+  issue_stage(y0, x0, W, H, cell_off, 0, buf0);
+  while (v < nunits) {
+    GLDS_T(t0_);
+    // the next unit's descriptor (after the last unit: this unit again, its half 0 is then re-staged into the free buffer —
+    // the DMA issue stays unconditional: under a condition hipcc drains the whole load queue at every tap pair of the next K loop)
+    const int vn = v + nwx;
+    int y0n, x0n, Wn, Hn;
+    size_t cell_offn;
+    {
+      const ConvTile tn = tiles[xcd + 8 * ((vn < nunits ? vn : v) / np)];
+      const LevelDev lvn = levels[tn.level];
+      y0n = tn.y0; x0n = tn.x0; Wn = lvn.cw; Hn = lvn.ch; cell_offn = lvn.cell_off;
+    }
+    const int nbase = (v % np) * (16 * NTW);
+    const int vw = min(CT, W - x0), vh = min(CT, H - y0), ncell = vw * vh;
+    const int nmt = (ncell + 15) >> 4;
+    const int mvalid = __builtin_amdgcn_readfirstlane(max(0, min(4, (nmt - wave + 3) >> 2)));
+    int aoff[4];   // byte offset of the lane's 16-byte A chunk (tap 0) per M-tile
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int c = min(16 * (wave + 4 * m) + ai, ncell - 1);
+      const int cy = c / vw, cx = c - cy * vw;
+      aoff[m] = (cy * TW + cx) * CELLB + 16 * ak;
+    }
+    f32x4 acc[NTW][4];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[nt][m][r] = 0.f;
+    const float* bsrc = wT + ((size_t)ak * nfpad + nbase + ai) * 4;   // w4[tap 0][half 0][k = ak][filter nbase + ai][s = 0..3]
+
+    // MV = 4: all four M-tiles of the wave hold valid cells (the common case: no branch in the K loop); MV = 0: decided per M-tile at run time
+    auto kloop = [&](const char* buf, int half, auto mv_tag) {
+      constexpr int MV = decltype(mv_tag)::value;
+      const float* bh = bsrc + (size_t)half * 16 * nfpad;
+      f32x4 b0[NTW], b1[NTW];
+      f32x4 a0[4], a1[4];
+      auto load_b = [&](f32x4 (&dst)[NTW], int tap) {
+        const float* bs = bh + (size_t)tap * PBD_FLEN * nfpad;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) dst[nt] = *(const f32x4*)(bs + 64 * nt);
+      };
+      auto load_a = [&](f32x4 (&dst)[4], int tap) {
+        const int ti = tap / 5, tj = tap - ti * 5;
+        const char* a = buf + (ti * TW + tj) * CELLB;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dst[m] = *(const f32x4*)(a + aoff[m]);
+      };
+      auto mma = [&](const f32x4 (&av)[4], const f32x4 (&bw)[NTW]) {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              if (MV == 4 || m < mvalid) acc[nt][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][s_], bw[nt][s_], acc[nt][m], 0, 0, 0);
+      };
+      load_b(b0, 0);
+      load_a(a0, 0);
+      // vmcnt(0): the wave's DMA pieces of the NEXT buffer (issued just before) and tap 0's B have landed.  hipcc cannot count
+      // past an LDS-DMA in flight: left pending it waits vmcnt(0) at the first MFMA of every tap pair (exposing the B latency
+      // 12 times per K loop); drained here once (~1 us, the co-resident workgroup's waves keep the pipe busy) the loop gets
+      // exact counted waits.
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      // taps in pairs, operands in explicit ping-pong: the next tap's B (global, L2-resident) and A (LDS) are in flight while
+      // this tap's 32 MFMAs issue.  No condition inside the loop (hipcc sinks loads into a conditional use); tap 24 is peeled.
+      _Pragma("unroll 1") for (int tap = 0; tap < NTAP - 1; tap += 2) {
+        load_b(b1, tap + 1);
+        load_a(a1, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(b0, tap + 2);
+        load_a(a0, tap + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mma(a0, b0);
+    };
+
+    // two channel halves through ONE K-loop instance: half h computes on buffer h while the DMA fills buffer 1 - h with
+    // half 1 of this unit (h = 0) or half 0 of the next unit (h = 1)
+    _Pragma("unroll 1") for (int half = 0; half < 2; ++half) {
+      GLDS_T(ta_);
+      __syncthreads();          // buffer `half` has landed (the DMA queue is drained before the barrier); every wave is done with buffer 1 - half
+      GLDS_T(tb_);
+      GLDS_C(cb_);
+      char* const cur = half ? buf1 : buf0;
+      if (half == 0) issue_stage(y0, x0, W, H, cell_off, 1, buf1);
+      else issue_stage(y0n, x0n, Wn, Hn, cell_offn, 0, buf0);
+      if (mvalid == 4) kloop(cur, half, std::integral_constant<int, 4>()); else kloop(cur, half, std::integral_constant<int, 0>());
+      GLDS_T(tc_);
+      GLDS_C(cc_);
+      GLDS_ACC(0, ta_, tb_); GLDS_ACC(1, tb_, tc_); GLDS_ACC(4, cb_, cc_);
+    }
+    GLDS_T(t4_);
+    __syncthreads();            // every wave is done reading buf1: its first 16.6 KB become the four waves' transposition slabs
+    GLDS_T(t5_);
+    {
+      float* R = resp + cell_off * nf;
+      float* tr = (float*)buf1 + wave * (16 * 65);           // per-wave [16 filters][64 cells + 1]
+      const int pc = 16 * (wave + 4 * (lane >> 4)) + (lane & 15);
+      const int pcy = pc / vw, py = y0 + pcy, pxx = x0 + (pc - pcy * vw);
+      const bool pvalid = pc < ncell;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tr[ai * 65 + m * 16 + 4 * ak + r] = acc[nt][m][r];   // D[i = 4 ak + r][j = ai] of M-tile m
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int jf = 0; jf < 16; ++jf) {
+          const int fn = nbase + 16 * nt + jf;
+          if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[jf * 65 + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    }
+    GLDS_T(t6_);
+    GLDS_ACC(2, t4_, t5_); GLDS_ACC(5, t5_, t6_);
+    GLDS_ACC(6, 0ull, 1ull); GLDS_ACC(7, tl0 * 0ull + t0_, t6_);
+    v = vn;
+    y0 = y0n; x0 = x0n; W = Wn; H = Hn; cell_off = cell_offn;
+  }
+}
+
+void launch_conv_glds_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat, const float* wT,
+                          float* resp, int nf, int nfpad, const float* border, int wg_per_cu, int ncu, hipStream_t s) {
+  if (ntiles <= 0) return;
+  const size_t lds = 2 * (size_t)(CT + 4) * (CT + 4) * 64;
+  const int nwx = std::max(1, ncu / 8) * wg_per_cu;          // workgroups per XCD
+  if (wg_per_cu >= 3) {
+    static LdsOptIn optin;
+    optin.ensure((const void*)k_conv_glds<3>, lds);
+    hipLaunchKernelGGL((k_conv_glds<3>), dim3(8 * nwx), dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, ntiles, border);
+  } else {
+    static LdsOptIn optin;
+    optin.ensure((const void*)k_conv_glds<2>, lds);
+    hipLaunchKernelGGL((k_conv_glds<2>), dim3(8 * nwx), dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, ntiles, border);
+  }
 }
 
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
@@ -676,9 +900,12 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
 // double-buffered staging (next channel group prefetched into registers across the K loop, second LDS buffer):
 // 0.51-0.71 ms vs 0.39 ms.
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
-                            const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s) {
+                            const float* wT, const float* w4u, float* resp, int nf, int nfpad, int nhalf, hipStream_t s) {
   if (ntiles <= 0) return;
-  if (nhalf == 5) launch_conv_mfma16_t<float, 2, 3, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);        // two n-tiles (32 filters) per workgroup
+  if (nhalf == 20) launch_conv_mfma16_t<float, 2, 3, 2, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // two n-tiles per workgroup, 16-byte B loads
+  else if (nhalf == 21) launch_conv_mfma16_t<float, 2, 3, 1, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // one n-tile, 16-byte B loads
+  else if (nhalf == 22) launch_conv_mfma16_t<float, 2, 2, 2, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // two n-tiles, 2 waves/SIMD allocation
+  else if (nhalf == 5) launch_conv_mfma16_t<float, 2, 3, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);        // two n-tiles (32 filters) per workgroup
   else if (nhalf == 6) launch_conv_mfma16_t<float, 2, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 7) launch_conv_mfma16_t<float, 1, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);   // whole tile, 32 filters
   else if (nhalf == 8) launch_conv_mfma16_t<float, 2, 2, 5>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);   // five n-tiles (80 filters) per workgroup

@@ -261,7 +261,24 @@ static int upload_model(pbd_handle* h) {
   // filters transposed to [tap][c][nfpad] (n contiguous): scalar loads in the VALU kernel,
   // B-operand rows in the MFMA kernel.  nfpad is a multiple of 160 (5 x 32-wide MFMA n-tiles).
   h->nfpad = ((m.nfilters + 159) / 160) * 160;
-  std::vector<float> wT((size_t)m.kh * m.kw * m.flen * h->nfpad, 0.f);
+  // + one trailing border cell (0, and 1 in the truncation channel flen - 1): the source the persistent filter-bank kernel
+  // streams out-of-level cells from (src/SpatialConvolutionEngine.cpp:147-155)
+  const size_t wt_n = (size_t)m.kh * m.kw * m.flen * h->nfpad;
+  std::vector<float> wT(3 * wt_n + m.flen, 0.f);
+  wT[wt_n + m.flen - 1] = 1.f;
+  // ... and the same filters once more as [tap][16-channel half][k = 0..3][nfpad][s = 0..3] = channel 16 half + 4 k + s: the lane
+  // (k, filter) of the persistent kernel's B operand reads its four k-steps of a tap with ONE 16-byte load (eight
+  // global_load_dword per 32 MFMAs cost the MFMA pipe a quarter of its rate: tests/tools/mfma_rate_probe.hip)
+  if (m.flen == PBD_FLEN)
+    for (int n = 0; n < m.nfilters; ++n)
+      for (int tap = 0; tap < m.kh * m.kw; ++tap)
+        for (int c = 0; c < m.flen; ++c)
+        {
+          const float w = h->filters[((size_t)n * m.kh * m.kw + tap) * m.flen + c];
+          wT[wt_n + m.flen + ((((size_t)tap * 2 + c / 16) * 4 + (c % 16) / 4) * h->nfpad + n) * 4 + c % 4] = w;     // k = (c % 16) / 4, s = c % 4
+          // third copy, [tap][half][k][nfpad][u] with channel = 16 half + 4 u + k: the B operand of k_conv_mfma16<.., B4>
+          wT[2 * wt_n + m.flen + ((((size_t)tap * 2 + c / 16) * 4 + c % 4) * h->nfpad + n) * 4 + (c % 16) / 4] = w;
+        }
   for (int n = 0; n < m.nfilters; ++n)
     for (int i = 0; i < m.kh; ++i)
       for (int j = 0; j < m.kw; ++j)
@@ -660,6 +677,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   // larger budget at which its blocks are resident together (fewer, larger blocks; fewer blocks per CU).
   int ncu = 256;
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, h->opt.device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+  h->ncu = ncu;
   auto count_blocks = [&](const std::vector<int>& rnd, size_t budget, bool fold_x, bool ypass, size_t* lds_out) {
     size_t nb = 0, lds = 0;
     for (int l = 0; l < n; ++l) {
@@ -890,15 +908,24 @@ static int run_pdf(pbd_handle* h) {
   if (h->conv_mode == PBD_CONV_MFMA)
     if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT, (double*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
     else {
-      // default (5): 16x16x4 MFMA, tile staged in two channel halves, TWO 16-filter n-tiles per workgroup (k_conv_mfma16<float,
-      // 2, 3, 2>: 27 KB of LDS per workgroup, so DT blocks of other frames co-reside on the CU).  Alone the kernel takes the
-      // same 0.38 ms as with one n-tile per workgroup (3), but it stages every tile half as often, and with frames in
-      // flight that VALU / LDS time goes to the other frames' DT blocks: 1 392 vs 1 331 frames/s (batches of 4 on 3
-      // handles), 1 287 vs 1 258 (single frames on 4).  PBD_MFMA_VARIANT (probe / tuning builds): 0 = the older 32x32x2
-      // kernel, 1 = whole tile, 2 = halves at 5 waves/SIMD, 3 = one n-tile, 4 = channel quarters, 6-9 = further n-tile counts
-      static const int variant = PBD_PROBE_ENV("PBD_MFMA_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_MFMA_VARIANT")) : 5;
-      if (variant && m.kh == 5 && m.kw == 5)
-        launch_conv_mfma16_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT, (float*)h->d_resp, m.nfilters, h->nfpad, variant, h->stream);
+      // default (20): 16x16x4 MFMA, tile staged in two channel halves, TWO 16-filter n-tiles per workgroup, B operand by 16-byte
+      // loads from the [tap][half][k][n][u] copy of the filters (k_conv_mfma16<float, 2, 3, 2, true>: 27 KB of LDS per workgroup, so
+      // DT blocks of other frames co-reside on the CU).  Two n-tiles per workgroup: alone the same time as one, but every tile is
+      // staged half as often and with frames in flight that VALU / LDS time goes to the other frames' DT blocks (1 392 vs 1 331
+      // frames/s, batches of 4 on 3 handles).  16-byte B loads: 0.339 vs 0.388 ms sequential, 1 419 vs 1 391 frames/s (eight
+      // global_load_dword per 32 MFMAs cost the MFMA pipe a quarter of its issue rate: tests/tools/mfma_rate_probe.hip).
+      // PBD_MFMA_VARIANT (probe / tuning builds): 0 = the older 32x32x2 kernel, 1 = whole tile, 2 = halves at 5 waves/SIMD, 3 = one
+      // n-tile, 4 = channel quarters, 5-9 = n-tile counts with 4-byte B loads, 10 / 11 / 19 = the persistent double-buffered
+      // kernel k_conv_glds at 2 / 3 / 1 workgroups per CU (0.354 ms sequential, 1 353-1 378 frames/s), 21 / 22 = one n-tile /
+      // 2 waves per SIMD register allocation with 16-byte B loads
+      static const int variant = PBD_PROBE_ENV("PBD_MFMA_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_MFMA_VARIANT")) : 20;
+      if (variant >= 10 && variant < 20 && m.kh == 5 && m.kw == 5 && m.flen == PBD_FLEN)
+        launch_conv_glds_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat,
+                             (const float*)h->d_wT + (size_t)m.kh * m.kw * m.flen * h->nfpad + m.flen /* [tap][half][k][n][s] copy */, (float*)h->d_resp, m.nfilters, h->nfpad,
+                             (const float*)h->d_wT + (size_t)m.kh * m.kw * m.flen * h->nfpad /* border cell */, variant == 19 ? 1 : variant - 8, h->ncu, h->stream);
+      else if (variant && m.kh == 5 && m.kw == 5)
+        launch_conv_mfma16_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT,
+                               (const float*)h->d_wT + 2 * (size_t)m.kh * m.kw * m.flen * h->nfpad + m.flen, (float*)h->d_resp, m.nfilters, h->nfpad, variant, h->stream);
       else
         launch_conv_mfma(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT, (float*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
     }

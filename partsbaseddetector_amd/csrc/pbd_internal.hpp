@@ -137,6 +137,7 @@ struct pbd_handle {
   // device model
   int ts = 4;                // sizeof(T): 4 = PartsBasedDetector<float>, 8 = PartsBasedDetector<double>
   void* d_wT = nullptr;      // T [kh*kw][flen][nfpad] filters transposed (and converted to T) for the conv kernels
+  int ncu = 256;
   int nfpad = 0;
   float* d_biasw = nullptr;
   int* d_parent = nullptr;   // [ncomp][max_parts] parent of each part
@@ -277,8 +278,10 @@ void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels,
                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
                           const double* wT, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
+void launch_conv_glds_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat, const float* wT,
+                          float* resp, int nf, int nfpad, const float* border, int wg_per_cu, int ncu, hipStream_t s);
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
-                            const float* wT, float* resp, int nf, int nfpad, int nhalf, hipStream_t s);
+                            const float* wT, const float* w4u, float* resp, int nf, int nfpad, int nhalf, hipStream_t s);
 void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw, size_t lds,
                     int ts, int nt, int fm, hipStream_t s);
 size_t dt_lds_bytes(int stride, int lpb, int ts, int nt);
