@@ -26,9 +26,12 @@ for i in range(3):
     h.enqueue_dev(img.data_ptr(), W, H, 3); h.collect(16)
 read()                       # resets the launch counter
 t[:] = 0
+_st = (C.c_ulonglong * 8)(); L.pbd_debug_dt_stamps(_st)     # resets the redo counter
 h.enqueue_dev(img.data_ptr(), W, H, 3); h.collect(16)
 read()
-print("launches traced:", nl.value)
+st = (C.c_ulonglong * 8)()
+L.pbd_debug_dt_stamps(st)
+print("launches traced:", nl.value, "| lines redone sequentially since the last read:", st[7], "| PBD_DT_BF_MAXLEN", os.environ.get("PBD_DT_BF_MAXLEN"))
 for l in range(min(nl.value, NL)):
     s, e = t[l, :, 0].astype(np.int64), t[l, :, 7].astype(np.int64)
     nb = int((s > 0).sum())
