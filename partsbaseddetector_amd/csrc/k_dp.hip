@@ -149,11 +149,6 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
   }
 }
 
-// (float)(i - 128), i < 264: the candidate coordinate of the brute-force transform as a wave-uniform scalar load (gfx950
-// has no scalar int -> float conversion; a per-candidate v_cvt would be a sixth vector instruction per candidate)
-struct DtFTab { float v[264]; constexpr DtFTab() : v() { for (int i = 0; i < 264; ++i) v[i] = (float)(i - 128); } };
-__constant__ DtFTab pbd_dt_ftab = DtFTab();
-
 // One block = NT lanes (one or two wavefronts) = up to g.lpb lines of one group (lpb chosen per group so that every
 // block of the launch fits the same LDS budget: long lines -> fewer lines per block -> many more blocks).  LDS
 // capacity leaves most lanes without a line of their own, so the NT / lpb lanes that share a line each scan one
@@ -274,8 +269,6 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       }
     }
   }
-  const bool BF = !EX && g.pad != 0;          // brute force over the candidates (float instantiation, short lines: plan)
-  if (BF && lane == 0) { SEG[0] = 0; SEG[1] = 0; }   // max |f| of the block (float bits); outputs listed for the exact check
   __syncthreads();
   DT_STAMP(2);
 
@@ -291,191 +284,6 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   P2* YZl = YZ + line * S;
   IT* Bl = B + line * S;
   if (mine) mp = maps[g.map0 + mi];
-
-  if constexpr (!EX) {
-    if (BF) {
-      // ---- brute force: out(P) = min_v f_v + a (P - v)^2 + b (P - v) evaluated for every candidate v of the
-      // line, the lanes of a line taking its outputs q = p, p + nsub, ...  In coordinates centred on the line (v' = v - len/2,
-      // p' = P - len/2) the candidate's value is  w_v - 2 a p' v' + (a p'^2 + b p'),  w_v = f_v + a v'^2 - b v':  ONE fma per
-      // candidate and lane (w_v from LDS, v' a scalar), the last term common to all candidates of the output.  The minimum,
-      // the runner-up and the minimum's index are tracked; the output is final when the runner-up is further away than the
-      // reference's rounding of an intersection could matter (plus the float evaluation error of the two values), else
-      // every candidate is checked against the exact criterion in double, and a line with a real near-tie is redone
-      // sequentially like the reference (dt_seg_scan).
-      // The model's Quadratic has a < 0 (src/DynamicProgram.cpp:125-127: the transform takes the UPPER envelope, a maximum):
-      // negating f, a and b turns it into the minimum form with the same intersections and the same decisions, so the
-      // search below minimises  sg f_v + A d^2 + B d  with A = |a|, B = sg b, sg = sign(a).
-      const int half = len >> 1;
-      const double a = mine ? mp.a : 1.0, b = mine ? mp.b : 0.0;
-      const double sg = a < 0 ? -1.0 : 1.0, A = fabs(a), Bs = sg * b;
-      const float* __restrict__ ft = pbd_dt_ftab.v + (128 - half);     // ft[v] = (float)(v - half)
-      float fm = 0.f;
-      if (mine) {
-        for (int v = p; v < len; v += nsub) {
-          const float f = (float)YZl[v].x;
-          const double vv = (double)(v - half);
-          YZl[v].y = (T)(float)(sg * (double)f + vv * (A * vv - Bs));
-          fm = fmaxf(fm, fabsf(f));
-        }
-      }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) fm = fmaxf(fm, __shfl_xor(fm, o));
-      if ((lane & 63) == 0) atomicMax((unsigned*)SEG, __float_as_uint(fm));     // |f| >= 0: float order = unsigned order (NaN / inf sort above everything finite)
-      __syncthreads();
-      DT_STAMP(3);
-      const float Fmax = __uint_as_float(((unsigned*)SEG)[0]);
-      unsigned* LIST = (unsigned*)ZLO;            // outputs to be checked exactly: (line << 16) | q, up to 2 NT entries (ZLO + ZSAVE)
-      const int LCAP = 2 * NT;
-      // outside these ranges the error bounds below are not worth trusting: the line goes the sequential way
-      const bool sane = (A >= 1e-4) && (A <= 1e3) && (Fmax <= 1e8f) && (fabs(b) <= 1e4);
-      if (mine && !sane && p == 0) FLAG[line] = 1;
-      if (mine && sane) {
-        const float af = (float)A, bfl = fabsf((float)b);
-        const int aos = mp.os < 0 ? -mp.os : mp.os;
-        const float hh = (float)(half + aos + 2);
-        // E: four times the bound on the float evaluation error of the DIFFERENCE of two candidate values
-        // (|w| <= Fmax + A h^2 + |b| h, |m v'| <= 2 A h^2, one rounding each plus the fma's: 2^-22 (Fmax + 3 A h^2 + |b| h))
-        const float E = ldexpf(Fmax + 3.f * af * hh * hh + bfl * hh, -20);
-        constexpr int U = 8;                       // outputs per lane and sweep over the candidates (register-blocked)
-        for (int c0 = p; c0 < len; c0 += U * nsub) {
-          float m[U], best[U], second[U];
-          int blk[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int q = min(c0 + u * nsub, len - 1);
-            m[u] = (float)(-2.0 * A * (double)(mp.os + q - half));
-            best[u] = INFINITY; second[u] = INFINITY; blk[u] = 0;
-          }
-          // per candidate and output: fma, med3 (runner-up), min.  The minimum's index is not tracked per candidate: only the
-          // block of 8 candidates in which the minimum was last lowered is, and that block is evaluated once more below.
-          int v0 = 0;
-          for (; v0 + 8 <= len; v0 += 8) {
-            float bo[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) bo[u] = best[u];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float w = (float)YZl[v0 + j].y;
-              const float vf = (float)(v0 + j - half);
-#pragma unroll
-              for (int u = 0; u < U; ++u) {
-                const float val = fmaf(m[u], vf, w);
-                second[u] = __builtin_amdgcn_fmed3f(best[u], second[u], val);
-                best[u] = __builtin_fminf(best[u], val);
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) blk[u] = best[u] < bo[u] ? v0 : blk[u];
-          }
-          if (v0 < len) {
-            float bo[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) bo[u] = best[u];
-            for (int v = v0; v < len; ++v) {
-              const float w = (float)YZl[v].y;
-              const float vf = (float)(v - half);
-#pragma unroll
-              for (int u = 0; u < U; ++u) {
-                const float val = fmaf(m[u], vf, w);
-                second[u] = __builtin_amdgcn_fmed3f(best[u], second[u], val);
-                best[u] = __builtin_fminf(best[u], val);
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) blk[u] = best[u] < bo[u] ? v0 : blk[u];
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int q = c0 + u * nsub;
-            if (q < len) {
-              int idx = blk[u];
-#pragma unroll
-              for (int j = 7; j >= 0; --j) {            // the first candidate of the block that attains the minimum
-                const int v = min(blk[u] + j, len - 1);
-                const float val = fmaf(m[u], (float)(v - half), (float)YZl[v].y);
-                idx = val == best[u] ? v : idx;
-              }
-              Bl[q] = (IT)idx;
-              // the reference rounds an intersection s to float: an error below 2^-24 (|P| + 1) where it matters.  Candidate u
-              // cannot change the reference's choice at P if its exact value exceeds the minimum's by more than
-              // 2 A |e - u| (4 x that error) = A |e - u| 2^-21 (|P| + 1); |e - u| <= len gives the test on the runner-up
-              const int Pq = mp.os + q;
-              const float scale = ldexpf((float)((Pq < 0 ? -Pq : Pq) + 1), -21);
-              if (!(second[u] - best[u] > af * (float)len * scale + E)) {          // (also catches NaN)
-                const unsigned slot = atomicAdd((unsigned*)SEG + 1, 1u);
-                if (slot < (unsigned)LCAP) LIST[slot] = ((unsigned)line << 16) | (unsigned)q;
-                else FLAG[line] = 1;
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();
-      {
-        // ---- exact check of the listed outputs, one wavefront per output, lanes = candidates: the output is final iff every
-        // other candidate's exact value (double) exceeds the minimum's by more than A |e - u| 2^-21 (|P| + 1) ----
-        const int nlist = min((int)((unsigned*)SEG)[1], LCAP);
-        const int wv = lane >> 6, ln = lane & 63, nw = NT >> 6;
-        for (int sidx = wv; sidx < nlist; sidx += nw) {
-          const unsigned ent = LIST[sidx];
-          const int l2 = (int)(ent >> 16), q2 = (int)(ent & 0xffffu);
-          int mi2;
-          if (FOLD) mi2 = l2 / nrows;
-          else mi2 = (t.g0 + l2) / g.nlines;
-          const DtMap& m2 = maps[g.map0 + mi2];
-          const double a2 = m2.a, b2 = m2.b, sg2 = a2 < 0 ? -1.0 : 1.0, A2 = fabs(a2), Bs2 = sg2 * b2;
-          const int P2q = m2.os + q2;
-          const P2* Y2 = YZ + l2 * S;
-          const int e = (int)B[l2 * S + q2], de = P2q - e;
-          const double fe = sg2 * (double)Y2[e].x, ge = A2 * (double)(de * de) + Bs2 * (double)de;
-          const double sc = A2 * ldexp((double)((P2q < 0 ? -P2q : P2q) + 1), -21);
-          bool bad = false;
-          for (int u = ln; u < len; u += 64) {
-            if (u != e) {
-              const int du = P2q - u;
-              const double Du = (sg2 * (double)Y2[u].x - fe) + ((A2 * (double)(du * du) + Bs2 * (double)du) - ge);
-              if (!(Du > sc * (double)(e > u ? e - u : u - e))) bad = true;
-            }
-          }
-          if (DT_ANY(bad) && ln == 0) FLAG[l2] = 1;
-        }
-      }
-      __syncthreads();
-      DT_STAMP(6);
-      DT_STAMP(4);
-      if (mine) {
-        const bool nat = mp.ptr_natural != 0;
-        int16_t* pp = mp.ptr + (nat ? (size_t)li * len : (size_t)li);
-        const int pst = nat ? 1 : g.nlines;
-        const int nlines = g.nlines;
-        if (!FLAG[line]) {
-          for (int q = p; q < len; q += nsub) {
-            const int e = (int)Bl[q], d = mp.os + q - e;
-            ((GPW(T))mp.dst)[li + (size_t)q * nlines] = (T)(a * (double)__mul24(d, d) + b * (double)d + (double)YZl[e].x);   // :176
-            ((GPW(int16_t))pp)[(size_t)q * pst] = (int16_t)e;
-          }
-        } else if (p == 0) {
-          // the reference's algorithm on the whole line (IEEE divisions), read out like a line redone below
-          DT_COUNT_REDO();
-          dt_seg_scan<true, T, IT>(YZl, Bl, RDX, mp.r2a, 0, len, a, b);
-          // read-out (:172-178) downwards along the links, like the segment read-out
-          int os = mp.os + len - 1;
-          int e = len - 1;                         // the last element pushed is always on the stack
-          P2 eyz = YZl[e];
-          for (int q = len - 1; q >= 0; --q) {
-            const T fos = (T)os;
-            while (!(eyz.y < fos)) { e = (int)Bl[e]; eyz = YZl[e]; }
-            const int d = os - e;
-            ((GPW(T))mp.dst)[li + (size_t)q * nlines] = (T)(a * (double)__mul24(d, d) + b * (double)d + (double)eyz.x);
-            ((GPW(int16_t))pp)[(size_t)q * pst] = (int16_t)e;
-            os--;
-          }
-        }
-      }
-      DT_STAMP(5);
-      return;
-    }
-  }
   // ---- local scans: the envelope of every segment (DistanceTransform.hpp:156-170 on the segment alone) ----
   if (mine && p < P) {
     if (dt_seg_scan<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b)) FLAG[line] = 1;

@@ -393,12 +393,9 @@ static int dt_lpb_for(int stride, int len, int unit, size_t budget, int ts, int 
   return lpb;
 }
 // fold >= 0: the group is one part at one level, a block = whole rows of its nmaps mixtures
-// lines up to this length take the brute-force core of k_dt_pass (float instantiation): DtGroup::pad carries the choice
-static int g_dt_bf_maxlen = PBD_PROBE_ENV("PBD_DT_BF_MAXLEN") ? atoi(PBD_PROBE_ENV("PBD_DT_BF_MAXLEN")) : 0;
 static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts, int nt, int seg, int fold = -1) {
   DtGroup g{};
   g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len; g.fold = fold;
-  g.pad = (ts == 4 && len <= g_dt_bf_maxlen && len <= 256) ? 1 : 0;
   g.stride = dt_stride_for(len);
   g.lpb = dt_lpb_for(g.stride, len, fold >= 0 ? nmaps : 1, budget, ts, nt, seg);
   return g;
