@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--conv", choices=["auto", "exact", "mfma"], default="auto")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("PBD_INFLIGHT", "4")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("PBD_INFLIGHT", "3")),
                     help="frames in flight per GPU on independent handles/streams (default 4: best measured "
                          "throughput with 8 hardware queues); 1 = strictly sequential detect() calls (latency mode)")
     ap.add_argument("--width", type=int, default=640)
@@ -149,7 +149,7 @@ def main():
                     help="ONE process driving --gpus N devices through pbd_group (no torchrun): every device listed --inflight "
                          "times, frames round-robin and software-pipelined over the members, host images in (H2D inside "
                          "the timed region), host gather of the candidates")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PBD_BATCH", "3")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PBD_BATCH", "8")),
                     help="frames per step and handle: >1 hands every handle a BATCH of same-sized frames (pbd_detect_batch_*: one "
                          "launch per stage for the whole batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

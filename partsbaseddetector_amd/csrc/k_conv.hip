@@ -693,7 +693,9 @@ static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelD
 typedef __attribute__((address_space(3))) void pbd_lds_void;
 typedef __attribute__((address_space(1))) const void pbd_glb_cvoid;
 
-template <int WPE>
+// PERSIST = false: the same operand paths (LDS-DMA staging, 16-byte A and B reads) without the persistent loop: one unit per
+// workgroup, ONE 25.6 KB buffer (stage half, barrier, K loop, barrier, ...), grid and XCD mapping of k_conv_mfma16.
+template <int WPE, bool PERSIST = true>
 __global__ __launch_bounds__(256, WPE) void k_conv_glds(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
                                                         const float* __restrict__ feat, const float* __restrict__ wT,
                                                         float* __restrict__ resp, int nf, int nfpad, int ntiles,
@@ -702,8 +704,13 @@ __global__ __launch_bounds__(256, WPE) void k_conv_glds(const ConvTile* __restri
   constexpr int TW = CT + 4, NCELL = TW * TW, NTAP = 25, NTW = 2, CH = 16, CELLB = CH * 4, BUFB = NCELL * CELLB, NPIECE = NCELL / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ai = lane & 15, ak = lane >> 4;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nwx = gridDim.x >> 3;
   const int np = (nf + 16 * NTW - 1) / (16 * NTW);
+  // persistent: workgroup j of XCD blockIdx.x % 8 takes units j, j + nwx, ... of that XCD's tile positions xcd, xcd + 8, ...;
+  // else: groups of 8 tiles x np n-pairs, all n-pairs of a tile on one XCD (k_conv_mfma16's mapping), one unit per workgroup
+  const int xcd = blockIdx.x & 7;
+  const int grp_ = (int)blockIdx.x / (8 * np), rem_ = (int)blockIdx.x - grp_ * (8 * np);
+  const int j = PERSIST ? (int)(blockIdx.x >> 3) : grp_ * np + (rem_ >> 3);
+  const int nwx = PERSIST ? (int)(gridDim.x >> 3) : (1 << 30);
   const int ntx = ntiles > xcd ? (ntiles - xcd + 7) >> 3 : 0;     // tile positions xcd, xcd + 8, ...
   const int nunits = ntx * np;
   char* const buf0 = smem;
@@ -734,12 +741,12 @@ __global__ __launch_bounds__(256, WPE) void k_conv_glds(const ConvTile* __restri
   }
   GLDS_INIT();
   GLDS_T(tl0);
-  issue_stage(y0, x0, W, H, cell_off, 0, buf0);
+  if (PERSIST) issue_stage(y0, x0, W, H, cell_off, 0, buf0);
   while (v < nunits) {
     GLDS_T(t0_);
     // the next unit's descriptor (after the last unit: this unit again, its half 0 is then re-staged into the free buffer —
     // the DMA issue stays unconditional: under a condition hipcc drains the whole load queue at every tap pair of the next K loop)
-    const int vn = v + nwx;
+    const int vn = PERSIST ? v + nwx : nunits;
     int y0n, x0n, Wn, Hn;
     size_t cell_offn;
     {
@@ -821,12 +828,18 @@ __global__ __launch_bounds__(256, WPE) void k_conv_glds(const ConvTile* __restri
     // half 1 of this unit (h = 0) or half 0 of the next unit (h = 1)
     _Pragma("unroll 1") for (int half = 0; half < 2; ++half) {
       GLDS_T(ta_);
+      if (!PERSIST) {
+        if (half) __syncthreads();                        // every wave is done with half 0
+        issue_stage(y0, x0, W, H, cell_off, half, buf0);
+      }
       __syncthreads();          // buffer `half` has landed (the DMA queue is drained before the barrier); every wave is done with buffer 1 - half
       GLDS_T(tb_);
       GLDS_C(cb_);
-      char* const cur = half ? buf1 : buf0;
-      if (half == 0) issue_stage(y0, x0, W, H, cell_off, 1, buf1);
-      else issue_stage(y0n, x0n, Wn, Hn, cell_offn, 0, buf0);
+      char* const cur = (PERSIST && half) ? buf1 : buf0;
+      if (PERSIST) {
+        if (half == 0) issue_stage(y0, x0, W, H, cell_off, 1, buf1);
+        else issue_stage(y0n, x0n, Wn, Hn, cell_offn, 0, buf0);
+      }
       if (mvalid == 4) kloop(cur, half, std::integral_constant<int, 4>()); else kloop(cur, half, std::integral_constant<int, 0>());
       GLDS_T(tc_);
       GLDS_C(cc_);
@@ -837,7 +850,7 @@ __global__ __launch_bounds__(256, WPE) void k_conv_glds(const ConvTile* __restri
     GLDS_T(t5_);
     {
       float* R = resp + cell_off * nf;
-      float* tr = (float*)buf1 + wave * (16 * 65);           // per-wave [16 filters][64 cells + 1]
+      float* tr = (float*)(PERSIST ? buf1 : buf0) + wave * (16 * 65);           // per-wave [16 filters][64 cells + 1]
       const int pc = 16 * (wave + 4 * (lane >> 4)) + (lane & 15);
       const int pcy = pc / vw, py = y0 + pcy, pxx = x0 + (pc - pcy * vw);
       const bool pvalid = pc < ncell;
@@ -868,7 +881,12 @@ void launch_conv_glds_f32(const ConvTile* tiles, int ntiles, const LevelDev* lev
   if (ntiles <= 0) return;
   const size_t lds = 2 * (size_t)(CT + 4) * (CT + 4) * 64;
   const int nwx = std::max(1, ncu / 8) * wg_per_cu;          // workgroups per XCD
-  if (wg_per_cu >= 3) {
+  if (wg_per_cu <= 0) {    // one unit per workgroup, single buffer
+    const int np = (nf + 31) / 32;
+    static LdsOptIn optin;
+    optin.ensure((const void*)k_conv_glds<3, false>, lds / 2);
+    hipLaunchKernelGGL((k_conv_glds<3, false>), dim3((ntiles + 7) / 8 * 8 * np), dim3(256), lds / 2, s, tiles, levels, feat, wT, resp, nf, nfpad, ntiles, border);
+  } else if (wg_per_cu >= 3) {
     static LdsOptIn optin;
     optin.ensure((const void*)k_conv_glds<3>, lds);
     hipLaunchKernelGGL((k_conv_glds<3>), dim3(8 * nwx), dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad, ntiles, border);

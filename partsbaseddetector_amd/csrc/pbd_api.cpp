@@ -922,7 +922,7 @@ static int run_pdf(pbd_handle* h) {
       if (variant >= 10 && variant < 20 && m.kh == 5 && m.kw == 5 && m.flen == PBD_FLEN)
         launch_conv_glds_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat,
                              (const float*)h->d_wT + (size_t)m.kh * m.kw * m.flen * h->nfpad + m.flen /* [tap][half][k][n][s] copy */, (float*)h->d_resp, m.nfilters, h->nfpad,
-                             (const float*)h->d_wT + (size_t)m.kh * m.kw * m.flen * h->nfpad /* border cell */, variant == 19 ? 1 : variant - 8, h->ncu, h->stream);
+                             (const float*)h->d_wT + (size_t)m.kh * m.kw * m.flen * h->nfpad /* border cell */, variant == 19 ? 1 : variant == 18 ? 0 : variant - 8, h->ncu, h->stream);
       else if (variant && m.kh == 5 && m.kw == 5)
         launch_conv_mfma16_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT,
                                (const float*)h->d_wT + 2 * (size_t)m.kh * m.kw * m.flen * h->nfpad + m.flen, (float*)h->d_resp, m.nfilters, h->nfpad, variant, h->stream);

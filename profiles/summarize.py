@@ -116,11 +116,13 @@ if fetch:
           "hbm_bytes_per_frame_corrected": 2 * fb + wb}
     md += ["", f"dp_min stage ({', '.join(sorted(dpk))}): fetch {fb / 1e6:.1f} MB raw (x2 = {2 * fb / 1e6:.1f} MB) + write {wb / 1e6:.1f} MB "
            f"= {(2 * fb + wb) / 1e6:.1f} MB per frame (algorithmic B_dp: see bench line)."]
-    BF = 3
-    fetch_b, write_b = pmc("FETCH_SIZE", f"pmcb{BF}"), pmc("WRITE_SIZE", f"pmcb{BF}")
+    bn = os.path.join(src, "batch_n.txt")
+    BF = int(open(bn).read().strip()) if os.path.exists(bn) else 3
+    pfx = "pmcb" if os.path.exists(bn) else f"pmcb{BF}"
+    fetch_b, write_b = pmc("FETCH_SIZE", pfx), pmc("WRITE_SIZE", pfx)
     if fetch_b and write_b:
         # the run also holds single-frame legs: keep the chains whose k_root grid is the batch's (the largest)
-        cf, cw = pmc_chains("FETCH_SIZE", f"pmcb{BF}"), pmc_chains("WRITE_SIZE", f"pmcb{BF}")
+        cf, cw = pmc_chains("FETCH_SIZE", pfx), pmc_chains("WRITE_SIZE", pfx)
         gb = max(cf)
         nl = cf[gb][0]
         dpb = [k for k in fetch_b if k.startswith(("k_dt_pass", "k_reduce", "k_root"))]
