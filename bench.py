@@ -4,21 +4,27 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one PartsBasedDetector::detect() pass per GPU over one 640x480 synthetic frame (full pyramid: 46
-levels; HOG -> filter bank -> DP min -> argmin; the candidates are copied back to the host every step).
+One "step" = one pass of the hot path per GPU over one BATCH of B synthetic 640x480 frames (default B = 8:
+pbd_detect_batch_enqueue_dev_u8 — every frame the full pyramid of 46 levels, HOG -> filter bank -> DP min -> argmin, one
+launch per stage for the whole batch; the candidates of every frame are copied back to the host every step).  S steps
+are in flight per GPU on S handles / streams (default S = 3).  --batch 1 = one frame per step (pbd_detect_enqueue_dev_u8).
 
-Protocol (SURVEY 8d, VERDICT r01 #2):
+Protocol (SURVEY 8d, VERDICT r01 #2, r02 #2/#6):
   * setup (untimed, independent of --warmup): every handle and the clocks are pre-warmed for a fixed wall time;
   * W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides, max over ranks;
-  * `value` = frames/s with the input frames ALREADY RESIDENT IN HBM when the timed region starts (the contract
-    of this tier); the same K steps are then repeated handing over PINNED HOST images, so that every step
-    contains its H2D copy (pbd_detect_enqueue_u8): reported beside it as `value_incl_h2d`;
-  * per-frame wall time of the timed loop (completion-to-completion): median / p10 / p90;
+  * `value` = frames/s (K x B x ranks frames / that time) with the input frames ALREADY RESIDENT IN HBM when the timed
+    region starts (the contract of this tier); the same K steps are then repeated handing over PINNED HOST images, so
+    that every step contains its H2D copy (pbd_detect_batch_enqueue_u8): `value_incl_h2d`; and once more feeding the
+    same handles one frame per call: `value_single_frame_calls`;
+  * per-step wall time of the timed loop (completion-to-completion): median / p10 / p90;
   * a strictly sequential leg (one frame in flight, pbd_detect_u8-equivalent: H2D + kernels + D2H per call) gives
-    the latency figures and the per-stage GPU times behind `roofline` (HIP events on the handle's stream);
+    the latency figures and the per-stage GPU times (HIP events on the handle's stream) behind
+    `roofline_single_frame`; a second one runs BATCHES one at a time: `roofline` prices the dp_min launch chain of one
+    batch (the unit the timed loop launches): B x B_dp algorithmic bytes / its HIP-event time; `traffic` = the PMC
+    figure of the same chain from profiles/traffic_dp.json;
   * `cpu_baseline`: the oracle (reference-structured OpenMP restatement) on the box's host cores — 2 warm-ups +
     median of 5 frames on all cores, and a one-thread leg on a bounded sample.
-Frames are independent, so ranks shard frames with no data-path collective ("weak" scaling: one frame per rank
+Frames are independent, so ranks shard frames with no data-path collective ("weak" scaling: one batch per rank
 per step); the only collective is the gather of the candidate buffers to rank 0 (RCCL over xGMI with backend
 nccl) — done for EVERY step, inside the timed region ("multi-GPU wall time includes the RCCL
 candidate gather").  `python bench.py --gpus N` without a torchrun environment spawns its own N ranks
@@ -133,8 +139,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--conv", choices=["auto", "exact", "mfma"], default="auto")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("PBD_INFLIGHT", "3")),
-                    help="frames in flight per GPU on independent handles/streams (default 4: best measured "
-                         "throughput with 8 hardware queues); 1 = strictly sequential detect() calls (latency mode)")
+                    help="steps in flight per GPU on independent handles/streams (default 3 handles x batches of 8 frames: "
+                         "best measured throughput); 1 = strictly sequential calls (latency mode)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--mixtures", type=int, default=6)
