@@ -663,10 +663,12 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   CONV_STAMP(6);
 }
 
+int g_conv_lds_req_kb = 0;   // set by pbd_api.cpp from PBD_CONV_LDS_KB in probe / tuning builds
 template <typename T, int NHALF, int WPE, int NTW = 1, bool B4 = false>
 static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
                                  const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
-  const size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + (sizeof(T) == 4 ? 2 : 1)), sizeof(T) * 4 * 16 * 65);
+  size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + (sizeof(T) == 4 ? 2 : 1)), sizeof(T) * 4 * 16 * 65);
+  if (g_conv_lds_req_kb > 0) lds = std::max(lds, (size_t)g_conv_lds_req_kb * 1024);   // tuning builds: occupancy cap by LDS request
   static LdsOptIn optin;   // one per instantiation
   optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW, B4>, lds);
   dim3 grid((ntiles + 7) / 8 * 8, (nf + 16 * NTW - 1) / (16 * NTW));   // tiles padded to a multiple of 8 (XCD-aware mapping in the kernel)

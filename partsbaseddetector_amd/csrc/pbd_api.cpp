@@ -918,6 +918,8 @@ static int run_pdf(pbd_handle* h) {
       // n-tile, 4 = channel quarters, 5-9 = n-tile counts with 4-byte B loads, 10 / 11 / 19 = the persistent double-buffered
       // kernel k_conv_glds at 2 / 3 / 1 workgroups per CU (0.354 ms sequential, 1 353-1 378 frames/s), 21 / 22 = one n-tile /
       // 2 waves per SIMD register allocation with 16-byte B loads
+      static const int lds_req = g_conv_lds_req_kb = PBD_PROBE_ENV("PBD_CONV_LDS_KB") ? atoi(PBD_PROBE_ENV("PBD_CONV_LDS_KB")) : 0;
+      (void)lds_req;
       static const int variant = PBD_PROBE_ENV("PBD_MFMA_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_MFMA_VARIANT")) : 20;
       if (variant >= 10 && variant < 20 && m.kh == 5 && m.kw == 5 && m.flen == PBD_FLEN)
         launch_conv_glds_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat,
