@@ -488,8 +488,8 @@ template <> struct Mfma16<float> {
   static __device__ __forceinline__ int drow(int reg, int ak) { return 4 * ak + reg; }
 };
 
-// B4 (float, two channel halves): wT is the [tap][half][k][nfpad][u] copy of the filters (channel 16 half + 4 u + k): a lane reads its four
-// k-steps of a tap and n-tile with ONE 16-byte load instead of four global_load_dword (which cost the MFMA pipe a quarter of its
+// B4 (float, two channel halves; double, four 8-channel groups): wT is the [tap][group][k][nfpad][u] copy of the filters (channel
+// CH group + 4 u + k): a lane reads the k-steps of a tap and n-tile with ONE 16-byte load instead of four global_load_dword (which cost the MFMA pipe a quarter of its
 // issue rate with two waves per SIMD: tests/tools/mfma_rate_probe.hip)
 template <typename T, int KH, int KW, int NHALF, int WPE, int NTW = 1, bool B4 = false>   // WPE: waves per SIMD the register allocation must allow; NTW: 16-filter n-tiles per workgroup
 __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __restrict__ tiles,
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   const int nbase = ntile_i * (16 * NTW);
   const T* F = feat + lv.cell_off * PBD_FLEN;
   const int ai = lane & 15, ak = lane >> 4;
-  static_assert(!B4 || (sizeof(T) == 4 && NHALF == 2), "16-byte B loads: float, two 16-channel halves");
-  const T* bsrc = B4 ? wT + ((size_t)ak * nfpad + nbase + ai) * 4      // w4[tap 0][half 0][k = ak][filter nbase + ai][u = 0..3]
+  static_assert(!B4 || (sizeof(T) == 4 && NHALF == 2) || (sizeof(T) == 8 && NHALF == 4), "16-byte B loads: the k-steps of a channel group fill one 16-byte vector");
+  const T* bsrc = B4 ? wT + ((size_t)ak * nfpad + nbase + ai) * KS     // w4[tap 0][group 0][k = ak][filter nbase + ai][u = 0..KS-1]
                      : wT + (size_t)ak * nfpad + nbase + ai;           // B[k = ak][j = ai] of k-step 0, tap 0, half 0, n-tile 0 (n-tile nt: + 16 nt)
   typename MM::acc_t acc[NTW][4];
 #pragma unroll
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         if constexpr (B4) {
-          const V w = *(const V*)(bs + 64 * nt);
+          const V w = *(const V*)(bs + 16 * KS * nt);
 #pragma unroll
           for (int u = 0; u < KS; ++u) dst[nt][u] = w.e[u];
         } else {
@@ -900,12 +900,13 @@ void launch_conv_glds_f32(const ConvTile* tiles, int ntiles, const LevelDev* lev
 }
 
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
-                          const double* wT, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
+                          const double* wT, const double* w4u, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
   if (ntiles <= 0) return;
   if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, 8, nf, nfpad, kh, kw, s); return; }
   // four 8-channel passes (27 KB of LDS per workgroup) measured 7 % faster than two 16-channel halves (54 KB)
   static const int q = PBD_PROBE_ENV("PBD_MFMA64_QUARTERS") ? atoi(PBD_PROBE_ENV("PBD_MFMA64_QUARTERS")) : 1;   // probe-build knob
-  if (q) launch_conv_mfma16_t<double, 4, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
+  if (q == 2) launch_conv_mfma16_t<double, 4, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);                // 8-byte B loads
+  else if (q) launch_conv_mfma16_t<double, 4, 2, 1, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);      // 16-byte B loads (default)
   else launch_conv_mfma16_t<double, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
 }
 

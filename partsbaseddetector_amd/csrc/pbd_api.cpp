@@ -288,6 +288,14 @@ static int upload_model(pbd_handle* h) {
   HIPCHK(h, hipMalloc(&h->d_wT, wT.size() * h->ts));
   if (h->ts == 8) {   // filters convertTo(DataType<double>), src/PartsBasedDetector.cpp:113-117 (exact widening)
     std::vector<double> wd(wT.begin(), wT.end());
+    // the double filter bank's 16-byte B layout replaces the (unused) float copy behind the border cell:
+    // [tap][8-channel group][k][nfpad][u = 0, 1], channel = 8 group + 4 u + k (k_conv_mfma16<double, 4, .., B4>)
+    if (m.flen == PBD_FLEN)
+      for (int n = 0; n < m.nfilters; ++n)
+        for (int tap = 0; tap < m.kh * m.kw; ++tap)
+          for (int c = 0; c < m.flen; ++c)
+            wd[wt_n + m.flen + ((((size_t)tap * 4 + c / 8) * 4 + c % 4) * h->nfpad + n) * 2 + (c % 8) / 4] =
+                (double)h->filters[((size_t)n * m.kh * m.kw + tap) * m.flen + c];
     HIPCHK(h, hipMemcpy(h->d_wT, wd.data(), wd.size() * sizeof(double), hipMemcpyHostToDevice));
   } else {
     HIPCHK(h, hipMemcpy(h->d_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -906,7 +914,8 @@ static int run_hog(pbd_handle* h) {
 static int run_pdf(pbd_handle* h) {
   const pbd_model_desc& m = h->md;
   if (h->conv_mode == PBD_CONV_MFMA)
-    if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT, (double*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
+    if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT,
+                                         (const double*)h->d_wT + (size_t)m.kh * m.kw * m.flen * h->nfpad + m.flen, (double*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
     else {
       // default (20): 16x16x4 MFMA, tile staged in two channel halves, TWO 16-filter n-tiles per workgroup, B operand by 16-byte
       // loads from the [tap][half][k][n][u] copy of the filters (k_conv_mfma16<float, 2, 3, 2, true>: 27 KB of LDS per workgroup, so

@@ -277,7 +277,7 @@ void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels
 void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                       const float* wT, float* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
-                          const double* wT, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
+                          const double* wT, const double* w4u, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s);
 extern int g_conv_lds_req_kb;
 void launch_conv_glds_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat, const float* wT,
                           float* resp, int nf, int nfpad, const float* border, int wg_per_cu, int ncu, hipStream_t s);

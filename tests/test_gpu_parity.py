@@ -1,6 +1,9 @@
 """GPU parity tests: libpbd_hip.so (through the C ABI) vs the CPU oracle on the
 same seeded inputs.  Integer / index outputs and the VALU float paths must be
 bit-exact; the MFMA filter bank is held to 1e-4 (BASELINE.json north_star)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -9,6 +12,7 @@ from partsbaseddetector_amd.model import (make_face_like_model, make_image, make
 from tests.util import assert_candidates_equal, thresh_from_oracle
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -101,6 +105,41 @@ def test_pdf_mfma_tolerance(gpu_required, orc):
     # north_star: scores within 1e-4; the k-ordered fma chain differs from the reference order by ~1e-6
     assert _pdf_case(orc, capi.PBD_CONV_MFMA, 5, 4, 13) < 2e-5
     assert _pdf_case(orc, capi.PBD_CONV_MFMA, 9, 5, 14) < 2e-5  # 45 filters: padded N
+
+
+@pytest.mark.parametrize("variant", [3, 5, 10, 18, 21])
+def test_pdf_mfma_tuning_variants(gpu_required, variant):
+    """The filter-bank kernels kept behind PBD_MFMA_VARIANT (tuning build only: one n-tile / 4-byte B loads / the persistent and
+    the single-buffer LDS-DMA kernels / one n-tile with 16-byte loads) stay within the MFMA tolerance of the oracle, ragged
+    levels and a padded filter count included.  Runs in a subprocess: the library is chosen at import time."""
+    import subprocess
+    tune = os.path.join(ROOT, "partsbaseddetector_amd", "libpbd_hip_tune.so")
+    if not os.path.exists(tune):
+        pytest.skip("tuning build absent (make -C partsbaseddetector_amd/csrc tune)")
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from partsbaseddetector_amd import capi\n"
+        "from partsbaseddetector_amd.model import make_image, make_tree_model\n"
+        "from oracle import orc\n"
+        "worst = 0.0\n"
+        "for (parts, K, seed, w, h) in [(9, 5, 14, 120, 90), (6, 6, 15, 333, 207)]:\n"
+        "    m = make_tree_model([-1] + [0] * (parts - 1), K, seed=seed)\n"
+        "    hd = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA)\n"
+        "    hd.pyramid(make_image(seed, w, h)); hd.pdf()\n"
+        "    g = hd._geo\n"
+        "    for l in (0, 1, 5, g['nlevels'] - 1):\n"
+        "        ref = orc.pdf_level(hd.level_features(l), m.filtersw)\n"
+        "        for n in range(len(m.filtersw)):\n"
+        "            worst = max(worst, float(np.abs(hd.level_response(l, n) - ref[n]).max()))\n"
+        "    hd.close()\n"
+        "print('WORST', worst)\n"
+    )
+    env = dict(os.environ, PBD_LIBRARY=tune, PBD_MFMA_VARIANT=str(variant))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float(r.stdout.strip().split("WORST")[-1])
+    assert worst < 2e-5, worst
 
 
 def test_pdf_zero_taps_and_border_channel(gpu_required, orc):
