@@ -926,6 +926,8 @@ void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* l
   if (nhalf == 20) launch_conv_mfma16_t<float, 2, 3, 2, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // two n-tiles per workgroup, 16-byte B loads
   else if (nhalf == 21) launch_conv_mfma16_t<float, 2, 3, 1, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // one n-tile, 16-byte B loads
   else if (nhalf == 22) launch_conv_mfma16_t<float, 2, 2, 2, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // two n-tiles, 2 waves/SIMD allocation
+  else if (nhalf == 23) launch_conv_mfma16_t<float, 2, 2, 5, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // five n-tiles (80 filters), 16-byte B loads
+  else if (nhalf == 24) launch_conv_mfma16_t<float, 2, 2, 3, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // three n-tiles (48 filters)
   else if (nhalf == 5) launch_conv_mfma16_t<float, 2, 3, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);        // two n-tiles (32 filters) per workgroup
   else if (nhalf == 6) launch_conv_mfma16_t<float, 2, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 7) launch_conv_mfma16_t<float, 1, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);   // whole tile, 32 filters
