@@ -1032,6 +1032,16 @@ def test_detect_batch_person_model_640x480(gpu_required, orc):
     for got, f in zip(outs, frames):
         assert_candidates_equal(got, orc.detect(m, f)[:3])
     h.close()
+    # bench.py's unit of work: batches of 8 through PBD_CONV_AUTO (-> the MFMA bank), graph replay — frame by frame what the
+    # same handle returns for the frame on its own (the single-frame MFMA path is held to the oracle, every difference
+    # classified, by test_detect_person_timed_configuration_classified)
+    frames8 = [make_image(10 + i, 640, 480) for i in range(8)]
+    ha = capi.Handle(m, graph=1, max_candidates=8 * 4096)
+    for rep in range(3):
+        outs8 = ha.detect_batch(frames8)
+    for got, f in zip(outs8, frames8):
+        assert_candidates_equal(got, ha.detect(f))
+    ha.close()
 
 
 def test_group_batch_configs2_shape(gpu_required, orc):
