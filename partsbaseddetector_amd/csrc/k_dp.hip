@@ -261,11 +261,13 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         if (f0 == 0)
           for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
+      // (unpredicated: a lane past the block's last element holds that element's value again — its load address was
+      // clamped — and stores it once more; a predicate per element made hipcc emit 24 nested exec-mask regions)
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
-        const int f = f0 + j * NT + lane, fc = min(f, n - 1);
+        const int fc = min(f0 + j * NT + lane, n - 1);
         const int i = len > 1 ? (int)__umulhi((unsigned)fc, magic) : fc;
-        if (f < n) YZ[i * S + (fc - i * len)].x = r[j];
+        YZ[i * S + (fc - i * len)].x = r[j];
       }
     }
   }
