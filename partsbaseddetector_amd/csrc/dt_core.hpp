@@ -122,7 +122,7 @@ DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const dou
   const double r1 = EXACT ? 0.0 : i2a * RDX[1];
   int vk = s0, nv = s0, nb = s0;            // top, the entry below it, the entry below that (element indices)
   T zk = (T)-INFINITY, nz = (T)-INFINITY;
-  double yk = (double)YZ[s0].x, ny = yk;
+  T yk = YZ[s0].x, ny = yk;                 // kept in T: one select each per step (the widening to double is exact and free of state)
   double r_top = r1;
   int q = s0 + 1;
   T yq_f = YZ[q].x;
@@ -132,20 +132,21 @@ DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const dou
     const DtPair<T> pyz = YZ[nb];
     const int pb = (int)B[nb];
     const double r_nxt = EXACT ? 0.0 : i2a * RDX[q - nv];  // reciprocal for the entry below the top (used if this step pops)
-    const T ynext_f = YZ[q + 1 < s1 ? q + 1 : s1 - 1].x;
-    const double yq = (double)yq_f;
-    const T s = dt_isect<EXACT, T>(yk, vk, yq, q, a, b, twoa, r_top, suspect);
-    const bool pop = (s <= zk) && (vk != s0);            // :162
+    const T ynext_f = YZ[q + 1].x;          // q + 1 == s1 <= len: the slot exists (the stride is >= len + 1) and the value is never used
+    const T s = dt_isect<EXACT, T>((double)yk, vk, (double)yq_f, q, a, b, twoa, r_top, suspect);
+    // :162.  EXACT = false: the bottom's z is -inf, so only s = -inf could pop it — an out-of-range quotient, which
+    // dt_isect flags (the line is redone with EXACT = true): no `k > 0` test on this path
+    const bool pop = EXACT ? ((s <= zk) && (vk != s0)) : (s <= zk);
     // push: B[q] = top (:166-169).  pop: the popped top's slot is dead from now on and records its popper.
     B[pop ? vk : q] = (IT)(pop ? q : vk);
     YZ[q].y = s;                                         // dead if this step pops
-    const int vk_o = vk; const double yk_o = yk; const T zk_o = zk; const int nv_o = nv;
+    const int vk_o = vk; const T yk_o = yk; const T zk_o = zk; const int nv_o = nv;
     vk = pop ? nv : q;
-    yk = pop ? ny : yq;
+    yk = pop ? ny : yq_f;
     zk = pop ? nz : s;
     r_top = pop ? r_nxt : r1;
     nv = pop ? nb : vk_o;
-    ny = pop ? (double)pyz.x : yk_o;
+    ny = pop ? pyz.x : yk_o;
     nz = pop ? pyz.y : zk_o;
     nb = pop ? pb : nv_o;
     yq_f = pop ? yq_f : ynext_f;
