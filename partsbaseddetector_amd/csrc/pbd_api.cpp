@@ -1048,6 +1048,7 @@ int pbd_i_emit(pbd_handle* h, const std::vector<const char*>& recs, pbd_candidat
 static int collect(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
   if (!h->pending) return fail(h, PBD_ERR_STATE, "collect without a pending detect");
   if (h->d_gsend) return fail(h, PBD_ERR_STATE, "handle belongs to an RCCL-gathering pbd_group: collect through the group");
+  if (h->batch > 1) return fail(h, PBD_ERR_STATE, "a batch of frames is pending: collect it with pbd_detect_batch_collect");
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const int found = h->h_cand_count[0];
   if (count) *count = found;

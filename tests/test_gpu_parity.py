@@ -1005,7 +1005,10 @@ def test_detect_batch_equals_single_frames(gpu_required, orc):
         assert_candidates_equal(h.detect(frames[4]), refs[4])        # single-frame entry on the same handle
         dev = torch.from_numpy(np.stack(frames[1:4])).cuda()
         h.enqueue_batch_dev(dev.data_ptr(), 3, 200, 150, 3)
-        for got, ref in zip(h.collect_batch(), refs[1:4]):
+        with pytest.raises(capi.PbdError) as e:          # a pending batch is not collected as one frame ...
+            h.collect()
+        assert e.value.code == capi.PBD_ERR_STATE
+        for got, ref in zip(h.collect_batch(), refs[1:4]):   # ... and is still there
             assert_candidates_equal(got, ref)
         with pytest.raises(capi.PbdError) as e:
             h.detect_batch(frames[:2], capacity=1)
