@@ -215,6 +215,22 @@ def test_bench_respawns_itself_for_n_ranks():
     assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
 
 
+def test_traffic_file_matches_the_bench_defaults():
+    """`roofline.traffic` of the default bench line comes from profiles/traffic_dp.json: its batch-chain entry has to be the
+    one for bench.py's default batch size (else the line silently carries traffic = null), and its figures have to be
+    self-consistent (FETCH_SIZE x2 + WRITE_SIZE; per-frame figures within 5 % of each other for single and batched chains)."""
+    import json
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    default_batch = int(re.search(r'os\.environ\.get\("PBD_BATCH", "(\d+)"\)', src).group(1))
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_dp.json")))
+    assert tj["batch"]["frames_per_launch"] == default_batch
+    assert abs(tj["hbm_bytes_per_frame_corrected"] - (2 * tj["fetch_bytes_raw"] + tj["write_bytes"])) < 1.0
+    b = tj["batch"]
+    assert abs(b["hbm_bytes_per_launch_corrected"] - (2 * b["fetch_bytes_raw"] + b["write_bytes"])) < 1.0
+    assert abs(b["hbm_bytes_per_frame_corrected"] / tj["hbm_bytes_per_frame_corrected"] - 1.0) < 0.05
+
+
 def test_bench_line_schema_fields():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
