@@ -80,9 +80,9 @@ enum {
                          correlation from 26 to 312 filters: profiles/r02b_conv_modes.json), else EXACT     */
   PBD_CONV_EXACT = 1, /* VALU direct correlation, reference summation order:
                          bit-identical to src/filter.cpp:3899-3922 + pdf+=pdfc */
-  PBD_CONV_MFMA = 2   /* MFMA implicit GEMM (k-ordered fma chain): fp32
-                         v_mfma_f32_32x32x2 for float handles, fp64
-                         v_mfma_f64_16x16x4 for double handles                 */
+  PBD_CONV_MFMA = 2   /* MFMA implicit GEMM (k-ordered fma chain) for any kh x kw: fp32
+                         v_mfma_f32_16x16x4_f32 for float handles, fp64
+                         v_mfma_f64_16x16x4_f64 for double handles             */
 };
 /* Scalar type T of the instantiation (src/PartsBasedDetector.cpp:132-133):
  * PartsBasedDetector<float> (src/demo.cpp:85) or PartsBasedDetector<double>
@@ -268,7 +268,15 @@ int pbd_set_root(pbd_handle* h, int level, int component, const float* rootv, co
 int pbd_set_root_f64(pbd_handle* h, int level, int component, const double* rootv, const int32_t* rooti);
 int pbd_set_dp_pointers(pbd_handle* h, int level, int component, int part, int parent_mix,
                         const int32_t* ix, const int32_t* iy, const int32_t* ik);
-/* DynamicProgram<T>::argmin (src/DynamicProgram.cpp:189-255)                  */
+/* Which stage buffers of the current frame plan hold valid data: state[0] level images, [1] features, [2] responses,
+ * [3] the DP tables (what the getters / the next stage would answer PBD_ERR_STATE for when 0).  On a handle with the
+ * compact memory plan (reserved[1] = 2, or automatic for large frames) min() reuses the image / feature memory and
+ * transforms the responses in place: [0..2] read 0 afterwards, and a response / feature setter makes its stage valid
+ * again only once EVERY plane of the active levels has been handed in.  A caller that caches what is resident on the
+ * device (host/pbd_host.hpp: content fingerprints) must drop that knowledge when a flag reads 0.                      */
+int pbd_get_stage_state(const pbd_handle* h, int32_t state[4]);
+/* DynamicProgram<T>::argmin (src/DynamicProgram.cpp:189-255).  With tables handed in and NO min() of this handle on the
+ * frame, every pointer table and every root table of the handle's levels must have been provided (PBD_ERR_STATE else). */
 int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
                   int capacity, int* count);
 

@@ -38,6 +38,7 @@ EXPORTS = [
     "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps",
     "pbd_set_root", "pbd_set_root_f64", "pbd_set_dp_pointers", "pbd_get_footprint", "pbd_abi_version",
     "pbd_detect_batch_u8", "pbd_detect_batch_enqueue_u8", "pbd_detect_batch_enqueue_dev_u8", "pbd_detect_batch_collect",
+    "pbd_get_stage_state",
 ]
 PBD_ABI_VERSION = 3
 
@@ -192,6 +193,11 @@ class Handle:
     def detect_batch(self, frames, capacity=4096):
         """pbd_detect_batch_u8: list of HxWxC uint8 frames -> list of (heads, boxes, locs), one per frame."""
         frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        if not frames:
+            raise ValueError("detect_batch: at least one frame")
+        if any(f.shape != frames[0].shape for f in frames):   # the C side reads w * hgt * cn bytes behind every pointer
+            raise ValueError("detect_batch: all frames of a batch must have the same shape, got "
+                             f"{sorted({f.shape for f in frames})}")
         hgt, w = frames[0].shape[:2]
         cn = 1 if frames[0].ndim == 2 else frames[0].shape[2]
         ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
@@ -284,6 +290,12 @@ class Handle:
 
     def dp_min(self):
         self._chk(self.L.pbd_dp_min(self.h))
+
+    def stage_state(self):
+        """pbd_get_stage_state: dict of which stage buffers currently hold valid data"""
+        st = (C.c_int32 * 4)()
+        self._chk(self.L.pbd_get_stage_state(self.h, st))
+        return dict(pyramid=bool(st[0]), features=bool(st[1]), responses=bool(st[2]), dp=bool(st[3]))
 
     def dp_pointers(self, l, c, p, m):
         g = self._geo
@@ -428,6 +440,8 @@ class Group:
         """frames: list of equal-sized uint8 images -> list of (heads, boxes, locs), frame f on member f % size."""
         frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
         n = len(frames)
+        if not n or any(f.shape != frames[0].shape for f in frames):
+            raise ValueError("detect_batch: one or more frames, all of the same shape")
         hgt, w = frames[0].shape[:2]
         cn = 1 if frames[0].ndim == 2 else frames[0].shape[2]
         ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])

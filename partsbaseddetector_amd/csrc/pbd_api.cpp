@@ -372,6 +372,21 @@ static void free_frame(pbd_handle* h) {
   h->d_extx = h->d_exty = nullptr; h->d_ext_base = nullptr; h->ext_ptr = false;
   h->fw = h->fh = h->fcn = 0;
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
+  h->min_ran = false;
+  h->feat_ok.clear(); h->resp_ok.clear(); h->ext_set.clear(); h->root_set.clear();
+}
+
+// Compact plan: validity of the stage planes the DP overwrites (pbd_internal.hpp).  all = true: a producer stage has just
+// written every plane; false: min() has just reused the memory.
+static void compact_mark_feat(pbd_handle* h, bool all) { if (h->compact) h->feat_ok.assign((size_t)h->nvl, all ? 1 : 0); }
+static void compact_mark_resp(pbd_handle* h, bool all) { if (h->compact) h->resp_ok.assign((size_t)h->nvl * h->md.nfilters, all ? 1 : 0); }
+static bool all_active_set(const pbd_handle* h, const std::vector<char>& v, int per_level) {
+  if (v.size() != (size_t)h->nvl * per_level) return false;
+  for (int l = 0; l < h->nvl; ++l) {
+    if (!h->lv[l].active || h->lv[l].cw == 0 || h->lv[l].ch == 0) continue;
+    for (int k = 0; k < per_level; ++k) if (!v[(size_t)l * per_level + k]) return false;
+  }
+  return true;
 }
 
 // DT block geometry under an LDS budget.  stride = LDS elements per line: >= len + 1 and ODD — the (y, z) pairs of
@@ -380,15 +395,14 @@ static void free_frame(pbd_handle* h) {
 // of the scan was an lpb-way bank conflict); lpb = lines per block: 4 .. lanes of the block (plain), or a whole
 // number of rows x the K mixtures of the part (fold: unit = K).
 static int dt_stride_for(int len) { return (len + 1) | 1; }
-static bool g_dt_round = true;   // plan-time switch of the search in plan_frame (single-threaded per handle; set before every use)
-static int dt_lpb_for(int stride, int len, int unit, size_t budget, int ts, int nt, int seg) {
+static int dt_lpb_for(int stride, int len, int unit, size_t budget, int ts, int nt, int seg, bool round_lanes) {
   const int lmin = unit > 1 ? unit : 4;
   int lpb = std::min(nt, 128);   // at most one line per lane
   if (unit > 1) lpb = std::max(unit, lpb / unit * unit);
   while (lpb > lmin && dt_lds_bytes(stride, lpb, ts, nt) > budget) lpb -= (unit > 1 ? unit : 1);
   // plain: the nt / lpb lanes of a line are a whole number, so 45 lines that fit would leave 128 - 2 * 45 lanes idle and
   // every line with two segments where 42 lines get three: the largest lpb <= the fit that uses all lanes
-  if (g_dt_round && unit <= 1 && lpb > lmin) lpb = std::max(lmin, nt / ((nt + lpb - 1) / lpb));
+  if (round_lanes && unit <= 1 && lpb > lmin) lpb = std::max(lmin, nt / ((nt + lpb - 1) / lpb));
   // The nt / lpb lanes that share a line scan one segment of it each (dt_core.hpp), and a block lasts as long as
   // its segments are: with a target segment length, lines are given up for lanes per line where the budget
   // would put so many lines into a block that each is left with one or two lanes.
@@ -401,11 +415,12 @@ static int dt_lpb_for(int stride, int len, int unit, size_t budget, int ts, int 
   return lpb;
 }
 // fold >= 0: the group is one part at one level, a block = whole rows of its nmaps mixtures
-static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts, int nt, int seg, int fold = -1) {
+// round_lanes: plain groups only — the largest lines-per-block <= the fit that leaves no lane idle (a per-launch choice of plan_frame)
+static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget, int ts, int nt, int seg, int fold = -1, bool round_lanes = true) {
   DtGroup g{};
   g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len; g.fold = fold;
   g.stride = dt_stride_for(len);
-  g.lpb = dt_lpb_for(g.stride, len, fold >= 0 ? nmaps : 1, budget, ts, nt, seg);
+  g.lpb = dt_lpb_for(g.stride, len, fold >= 0 ? nmaps : 1, budget, ts, nt, seg, round_lanes);
   return g;
 }
 static void dt_add_tasks(const DtGroup& g, std::vector<DtTask>& out) {
@@ -686,7 +701,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   int ncu = 256;
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, h->opt.device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
   h->ncu = ncu;
-  auto count_blocks = [&](const std::vector<int>& rnd, size_t budget, bool fold_x, bool ypass, size_t* lds_out) {
+  auto count_blocks = [&](const std::vector<int>& rnd, size_t budget, bool fold_x, bool ypass, bool round_lanes, size_t* lds_out) {
     size_t nb = 0, lds = 0;
     for (int l = 0; l < n; ++l) {
       const Level& L = h->lv[l];
@@ -701,7 +716,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
       } else {
         int nm = 0;
         for (int fp : rnd) nm += h->parts[fp].K;
-        const DtGroup g = dt_group(0, nm, nlines, len, budget, h->ts, h->dt_nt, h->dt_seg);
+        const DtGroup g = dt_group(0, nm, nlines, len, budget, h->ts, h->dt_nt, h->dt_seg, -1, round_lanes);
         nb += ((size_t)nm * nlines + g.lpb - 1) / g.lpb;
         lds = std::max(lds, dt_lds_bytes(g.stride, g.lpb, h->ts, h->dt_nt));
       }
@@ -723,10 +738,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
     if (fold_x || PBD_PROBE_ENV("PBD_DT_NO_RESIDENT")) return dflt;
     const int waves_blk = std::max(1, h->dt_nt / 64);
     auto resident = [&](size_t b, bool rnd_lanes) {
-      g_dt_round = rnd_lanes;
       size_t lds = 0;
-      const size_t nb = count_blocks(rnd, b, fold_x, ypass, &lds);
-      g_dt_round = true;
+      const size_t nb = count_blocks(rnd, b, fold_x, ypass, rnd_lanes, &lds);
       const size_t per_cu = std::min<size_t>(160 * 1024 / std::max<size_t>(lds, 1), 24 / waves_blk);
       return nb <= per_cu * ncu;
     };
@@ -773,11 +786,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
         tmp_round += (size_t)P.K * act_cells;
         if (fold_x) dt_add_tasks(dt_group(part_map0, P.K, L.ch, L.cw, budget_x, h->ts, h->dt_nt_x, h->dt_seg, make_fold(fp, l)), xt);
       }
-      g_dt_round = geox.round;
-      if (!fold_x) dt_add_tasks(dt_group(gx_map0, gx_nmaps, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg), xt);
-      g_dt_round = geoy.round;
-      const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, budget, h->ts, h->dt_nt, h->dt_seg);
-      g_dt_round = true;
+      if (!fold_x) dt_add_tasks(dt_group(gx_map0, gx_nmaps, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg, -1, geox.round), xt);
+      const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, budget, h->ts, h->dt_nt, h->dt_seg, -1, geoy.round);
       for (auto& my : ymaps) maps.push_back(my);
       dt_add_tasks(gy, yt);
       if (dbg_plan)
@@ -901,6 +911,7 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
   }
   LAUNCHCHK(h, "image pyramid");
   h->have_pyr = true;
+  if (h->compact) h->have_dp = false;   // the level images + features share their memory with the Ik planes / the x pass's scratch
   return PBD_OK;
 }
 
@@ -908,6 +919,8 @@ static int run_hog(pbd_handle* h) {
   launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->stream);
   LAUNCHCHK(h, "HOG");
   h->have_feat = true;
+  compact_mark_feat(h, true);
+  if (h->compact) h->have_dp = false;
   return PBD_OK;
 }
 
@@ -944,6 +957,7 @@ static int run_pdf(pbd_handle* h) {
     launch_conv_exact(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat, h->d_wT, h->d_resp, h->ts, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
   LAUNCHCHK(h, "filter bank");
   h->have_resp = true;
+  compact_mark_resp(h, true);
   return PBD_OK;
 }
 
@@ -966,9 +980,14 @@ static int run_dp_min(pbd_handle* h) {
   h->dp_timed = dpt;
   LAUNCHCHK(h, "DP min");
   h->have_dp = true;
+  h->min_ran = true;
   h->ext_ptr = false;   // back-tracking reads this min()'s own tables again
   h->root_dirty = false;
-  if (h->compact) h->have_pyr = h->have_feat = h->have_resp = false;   // their memory now holds the DP's planes
+  if (h->compact) {     // their memory now holds the DP's planes: every feature / response plane is stale until produced or handed in again
+    h->have_pyr = h->have_feat = h->have_resp = false;
+    compact_mark_feat(h, false);
+    compact_mark_resp(h, false);
+  }
   return PBD_OK;
 }
 
@@ -1113,7 +1132,10 @@ static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
   HIPCHK(h, hipGraphLaunch(h->gexec, h->stream));
   h->frames_on_plan++;
   h->have_pyr = h->have_feat = h->have_resp = !h->compact;
+  compact_mark_feat(h, false);
+  compact_mark_resp(h, false);
   h->have_dp = true;
+  h->min_ran = true;
   h->ext_ptr = false;
   h->root_dirty = false;
   h->dp_timed = false;
@@ -1350,6 +1372,10 @@ int pbd_begin_frame(pbd_handle* h, int w, int hgt, int cn) {
   int rc = plan_frame(h, w, hgt, cn);
   if (rc) return rc;
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
+  h->min_ran = false;
+  compact_mark_feat(h, false);
+  compact_mark_resp(h, false);
+  h->ext_set.clear(); h->root_set.clear();
   return PBD_OK;
 }
 
@@ -1366,6 +1392,7 @@ int pbd_pyramid_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
 #define CHECK_LEVEL(h, level)                                                     \
   if (!(h)) return PBD_ERR_ARG;                                                   \
   if ((h)->fw == 0) return fail(h, PBD_ERR_STATE, "no frame geometry");           \
+  if ((h)->batch > 1) return fail(h, PBD_ERR_STATE, "the current plan is a batch of frames (pbd_detect_batch_*): the stage entry points address single-frame plans"); \
   if ((level) < 0 || (level) >= (h)->nlevels) return fail(h, PBD_ERR_ARG, "level out of range");
 
 int pbd_get_level_image(pbd_handle* h, int level, uint8_t* out) {
@@ -1400,7 +1427,14 @@ static int set_level_features_(pbd_handle* h, int level, const void* in, int ts)
   ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->d_feat + L.cell_off * PBD_FLEN * ts, in, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyHostToDevice));
-  h->have_feat = true;
+  if (h->compact) {   // the write went over the Ik planes / the x pass's scratch; the other levels may still be stale
+    h->have_dp = false;
+    if (h->feat_ok.size() != (size_t)h->nvl) compact_mark_feat(h, false);
+    h->feat_ok[level] = 1;
+    h->have_feat = all_active_set(h, h->feat_ok, 1);
+  } else {
+    h->have_feat = true;
+  }
   return PBD_OK;
 }
 int pbd_get_level_features(pbd_handle* h, int level, float* out) { return get_level_features_(h, level, out, 4); }
@@ -1409,7 +1443,7 @@ int pbd_set_level_features(pbd_handle* h, int level, const float* in) { return s
 int pbd_set_level_features_f64(pbd_handle* h, int level, const double* in) { return set_level_features_(h, level, in, 8); }
 int pbd_pdf(pbd_handle* h) {
   if (!h) return PBD_ERR_ARG;
-  if (!h->have_feat) return fail(h, PBD_ERR_STATE, "pdf() before pyramid()");
+  if (!h->have_feat) return fail(h, PBD_ERR_STATE, h->compact ? "pdf(): features are not resident (compact memory plan: min() reuses their memory — run pyramid() or hand in every level again)" : "pdf() before pyramid()");
   ON_DEVICE(h);
   int rc = run_pdf(h);
   if (rc) return rc;
@@ -1438,7 +1472,13 @@ static int set_level_response_(pbd_handle* h, int level, int filter, const void*
   ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->d_resp + (L.cell_off * h->md.nfilters + filter * HW) * ts, in, HW * ts, hipMemcpyHostToDevice));
-  h->have_resp = true;
+  if (h->compact) {   // min() transformed the planes in place: the responses are valid again once EVERY plane has been handed in (or pdf() re-run)
+    if (h->resp_ok.size() != (size_t)h->nvl * h->md.nfilters) compact_mark_resp(h, false);
+    h->resp_ok[(size_t)level * h->md.nfilters + filter] = 1;
+    h->have_resp = all_active_set(h, h->resp_ok, h->md.nfilters);
+  } else {
+    h->have_resp = true;
+  }
   return PBD_OK;
 }
 int pbd_get_level_response(pbd_handle* h, int level, int filter, float* out) { return get_level_response_(h, level, filter, out, 4); }
@@ -1447,7 +1487,7 @@ int pbd_set_level_response(pbd_handle* h, int level, int filter, const float* in
 int pbd_set_level_response_f64(pbd_handle* h, int level, int filter, const double* in) { return set_level_response_(h, level, filter, in, 8); }
 int pbd_dp_min(pbd_handle* h) {
   if (!h) return PBD_ERR_ARG;
-  if (!h->have_resp) return fail(h, PBD_ERR_STATE, "min() before pdf()");
+  if (!h->have_resp) return fail(h, PBD_ERR_STATE, h->compact ? "min(): responses are not resident (compact memory plan: min() transforms them in place — run pdf() or hand in every plane again)" : "min() before pdf()");
   ON_DEVICE(h);
   int rc = run_dp_min(h);
   if (rc) return rc;
@@ -1515,11 +1555,20 @@ static int set_root_(pbd_handle* h, int level, int component, const void* rootv,
   const Level& L = h->lv[level];
   if (!L.active) return fail(h, PBD_ERR_STATE, "level is not processed by this handle (pbd_set_levels / level_begin..level_end)");
   const size_t HW = (size_t)L.cw * L.ch;
+  if (rooti) {   // rooti becomes the root's mixture in back-tracking and indexes the children's Ik planes
+    const int K0 = h->parts[h->part_offset[component]].K;
+    for (size_t i = 0; i < HW; ++i)
+      if (rooti[i] < 0 || rooti[i] >= K0) return fail(h, PBD_ERR_ARG, "rooti entry out of range (0..K_root-1)");
+  }
   ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (rootv) HIPCHK(h, hipMemcpy(h->d_rootv + (L.cell_off * h->md.ncomponents + component * HW) * ts, rootv, HW * ts, hipMemcpyHostToDevice));
   if (rooti) HIPCHK(h, hipMemcpy(h->d_rooti + L.cell_off * h->md.ncomponents + component * HW, rooti, HW * 4, hipMemcpyHostToDevice));
   h->root_dirty = true;
+  if (rootv && rooti) {
+    if (h->root_set.size() != (size_t)h->nvl * h->md.ncomponents) h->root_set.assign((size_t)h->nvl * h->md.ncomponents, 0);
+    h->root_set[(size_t)level * h->md.ncomponents + component] = 1;
+  }
   return PBD_OK;
 }
 int pbd_set_root(pbd_handle* h, int level, int component, const float* rootv, const int32_t* rooti) { return set_root_(h, level, component, rootv, rooti, 4); }
@@ -1542,13 +1591,15 @@ int pbd_set_dp_pointers(pbd_handle* h, int level, int component, int part, int p
     int rc;
     if ((rc = dev_alloc(h, &h->d_extx, n))) return rc;
     if ((rc = dev_alloc(h, &h->d_exty, n))) return rc;
+    HIPCHK(h, hipMemset(h->d_extx, 0, n * sizeof(int16_t)));   // planes never handed in read as (0, 0): in range for every level
+    HIPCHK(h, hipMemset(h->d_exty, 0, n * sizeof(int16_t)));
     std::vector<unsigned long long> base((size_t)h->nvl * h->md.ncomponents);
     for (int l = 0; l < h->nvl; ++l)
       for (int c = 0; c < h->md.ncomponents; ++c)
         base[(size_t)l * h->md.ncomponents + c] = h->lv[l].cell_off * h->nplanes + (size_t)h->comp_plane0[c] * h->lv[l].cw * h->lv[l].ch;
     if ((rc = dev_upload(h, &h->d_ext_base, base))) return rc;
   }
-  if (!h->ext_ptr && h->have_dp) {
+  if (!h->ext_ptr && h->have_dp && h->min_ran) {
     // the planes the caller does NOT hand in keep this handle's own tables: materialise all of them once, composed
     // (costly, but this is the compatibility path of a mixed-engine caller, not detect())
     std::vector<int32_t> x, y, k;
@@ -1584,6 +1635,10 @@ int pbd_set_dp_pointers(pbd_handle* h, int level, int component, int part, int p
   HIPCHK(h, hipMemcpy(h->d_exty + eo, ys.data(), HW * 2, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_pk + eo, ks.data(), HW, hipMemcpyHostToDevice));
   h->ext_ptr = true;
+  if (h->ext_set.size() != (size_t)h->nvl * std::max(h->nplanes, 1)) h->ext_set.assign((size_t)h->nvl * std::max(h->nplanes, 1), 0);
+  h->ext_set[(size_t)level * std::max(h->nplanes, 1) + P.plane0 + parent_mix] = 1;
+  // with a min() of this handle behind them the planes not handed in keep its tables; without one, back-tracking may only
+  // run once EVERY plane and every root table of the active levels has been provided (pbd_dp_argmin checks)
   h->have_dp = true;
   return PBD_OK;
 }
@@ -1594,13 +1649,26 @@ int pbd_get_footprint(const pbd_handle* h, size_t* frame_bytes, size_t* model_by
   return PBD_OK;
 }
 int pbd_abi_version(void) { return PBD_ABI_VERSION; }
+int pbd_get_stage_state(const pbd_handle* h, int32_t state[4]) {
+  if (!h || !state) return PBD_ERR_ARG;
+  state[0] = h->have_pyr; state[1] = h->have_feat; state[2] = h->have_resp; state[3] = h->have_dp;
+  return PBD_OK;
+}
 
 int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count) {
   if (!h) return PBD_ERR_ARG;
   if (!h->have_dp) return fail(h, PBD_ERR_STATE, "argmin() before min()");
+  if (h->batch > 1) return fail(h, PBD_ERR_STATE, "the current plan is a batch of frames: its candidates come from pbd_detect_batch_collect");
+  if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
+  if (!h->min_ran) {   // tables handed in by the caller only: all of them, or back-tracking would walk uninitialised planes
+    if (!all_active_set(h, h->ext_set, std::max(h->nplanes, 1)) && h->nplanes > 0)
+      return fail(h, PBD_ERR_STATE, "argmin(): no min() on this frame and not every pointer table has been handed in (pbd_set_dp_pointers)");
+    if (!all_active_set(h, h->root_set, h->md.ncomponents))
+      return fail(h, PBD_ERR_STATE, "argmin(): no min() on this frame and not every root table has been handed in (pbd_set_root)");
+  }
   ON_DEVICE(h);
   int rc = run_argmin_enqueue(h);
-  if (rc) return rc;
+  if (rc) { h->pending = false; return rc; }
   return collect(h, heads, boxes, locs, capacity, count);
 }
 

@@ -156,6 +156,13 @@ struct pbd_handle {
   std::vector<PyrLaunch> pyr_launches;          // [0]: resize, [1..]: pyrDown octave steps
   size_t cells = 0, pyr_bytes = 0;
   bool have_pyr = false, have_feat = false, have_resp = false, have_dp = false;
+  // Compact memory plan only: the DP reuses the feature / response memory, so after min() every plane is stale until it
+  // is produced (pyramid / pdf) or handed in (pbd_set_level_*) again: have_feat / have_resp are true only when ALL are.
+  std::vector<char> feat_ok, resp_ok;            // [level], [level * nfilters + filter]
+  // tables handed in by the caller with no min() of this handle behind them: back-tracking needs every plane and every
+  // root table of the active levels before it may run
+  bool min_ran = false;                          // this plan's tables (Ik, DT pointer planes, roots) come from run_dp_min
+  std::vector<char> ext_set, root_set;           // [level * nplanes + plane], [level * ncomp + comp]
 
   // device frame buffers
   uint8_t* d_img = nullptr; size_t img_cap = 0;

@@ -263,6 +263,16 @@ class Device {
     check(pbd_pyramid_geometry(h, w, hgt, &n, 0, 0, cell_w.data(), cell_h.data(), scales.data()));
     fp_feat.assign(n, 0); fp_resp.clear(); fp_root.clear(); fp_tab.clear(); tables_resident = false;
   }
+  // What the fingerprints claim to be resident must still BE resident: on a handle with the compact memory plan min()
+  // overwrites the features and the responses (pbd_get_stage_state), so an argument that matches a fingerprint taken
+  // before that min() would be skipped and the DP would run on the overwritten planes.
+  void dropStale() {
+    int32_t st[4] = {1, 1, 1, 1};
+    check(pbd_get_stage_state(h, st));
+    if (!st[1]) std::fill(fp_feat.begin(), fp_feat.end(), 0);
+    if (!st[2]) for (auto& v : fp_resp) std::fill(v.begin(), v.end(), 0);
+    if (!st[3]) { tables_resident = false; fp_tab.clear(); for (auto& v : fp_root) std::fill(v.begin(), v.end(), 0); }
+  }
   // a caller that brings features from another IFeatures declares the frame first (the level sizes follow from it)
   void beginFrame(int w, int hgt, int cn) { check(pbd_begin_frame(h, w, hgt, cn)); geometry(w, hgt); }
   void checkLevels(const vectorMat& v, int per_cell, const char* what) const {
@@ -463,6 +473,7 @@ class DynamicProgram {
       }
     }
     dev_->check(pbd_dp_min(dev_->h));
+    dev_->dropStale();   // compact memory plan: min() reused the feature memory and transformed the responses in place
     Ix.assign(nscales, vector3DMat(ncomponents)); Iy.assign(nscales, vector3DMat(ncomponents)); Ik.assign(nscales, vector3DMat(ncomponents));
     rootv.assign(nscales, vectorMat(ncomponents));
     rooti.assign(nscales, vectorMat(ncomponents));

@@ -516,6 +516,106 @@ def test_compact_memory_plan_same_results(gpu_required, orc):
     hc.close(); hd.close()
 
 
+def test_compact_plan_stage_state_is_tracked(gpu_required, orc):
+    """on a compact handle min() overwrites the features and transforms the responses in place.
+    One plane handed in afterwards must NOT make the whole stage valid again (min() would run on overwritten planes);
+    handing in every plane does, and gives the oracle's result.  The image pyramid is written over the Ik planes, so
+    the DP tables are gone after pyramid() (argmin / pointer getters must refuse instead of reading image bytes)."""
+    m = make_tree_model([-1, 0, 1, 1, 0], 2, seed=21)
+    im = make_image(5, 160, 120)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.5)
+    ref = orc.detect(m, im)[:3]
+    fr = orc.detect(m, im, capacity=1, keep=True)[4]
+    hc = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dp_mode=2)
+    hc.pyramid(im); hc.pdf()
+    assert hc.stage_state() == dict(pyramid=True, features=True, responses=True, dp=False)
+    nf, nl = len(m.filtersw), hc._geo["nlevels"]
+    resp = [[hc.level_response(l, n) for n in range(nf)] for l in range(nl)]
+    hc.dp_min()
+    assert hc.stage_state() == dict(pyramid=False, features=False, responses=False, dp=True)
+    assert_candidates_equal(hc.dp_argmin(), ref)
+    hc.set_level_response(0, 0, resp[0][0])                      # one plane: the others are still transformed scores
+    assert not hc.stage_state()["responses"]
+    with pytest.raises(capi.PbdError) as e:
+        hc.dp_min()
+    assert e.value.code == capi.PBD_ERR_STATE
+    for l in range(nl):                                          # every plane: a valid min() input again
+        for n in range(nf):
+            hc.set_level_response(l, n, resp[l][n])
+    assert hc.stage_state()["responses"]
+    hc.dp_min()
+    assert_candidates_equal(hc.dp_argmin(), ref)
+    # one feature level handed in: pdf() must refuse (the other levels hold Ik bytes), and the DP tables are gone
+    hc.set_level_features(0, fr.feat(0))
+    st = hc.stage_state()
+    assert not st["features"] and not st["dp"]
+    for fn in (hc.pdf, hc.dp_argmin, lambda: hc.dp_pointers(0, 0, 1, 0)):
+        with pytest.raises(capi.PbdError) as e:
+            fn()
+        assert e.value.code == capi.PBD_ERR_STATE
+    # a new pyramid over a finished frame: tables invalid until min() has run again
+    assert_candidates_equal(hc.detect(im), ref)
+    hc._geo = hc.geometry(160, 120); hc._cn = 3
+    hc.pyramid(im)
+    assert not hc.stage_state()["dp"]
+    with pytest.raises(capi.PbdError) as e:
+        hc.dp_argmin()
+    assert e.value.code == capi.PBD_ERR_STATE
+    hc.pdf(); hc.dp_min()
+    assert_candidates_equal(hc.dp_argmin(), ref)
+    fr.free(); hc.close()
+
+
+def test_foreign_tables_must_be_complete_and_in_range(gpu_required, orc):
+    """argmin on caller tables with no min() behind them needs EVERY plane and root table (the planes
+    are otherwise uninitialised device memory); rooti is range-checked like ik; argmin on a batch plan is refused and
+    leaves the handle usable."""
+    m = make_tree_model([-1, 0, 1], 2, seed=3)
+    m.thresh = 1.0
+    hd = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    hd.begin_frame(100, 80, 3)
+    g, desc = hd._geo, m.to_desc()
+    rng = np.random.default_rng(4)
+    nf = len(m.filtersw)
+    tabs = [orc.dp_min_level(desc, 0, rng.normal(0, 1, (nf, g["cell_h"][l], g["cell_w"][l])).astype(np.float32)) for l in range(g["nlevels"])]
+    x, y, k, rv, ri = tabs[0]
+    hd.set_dp_pointers(0, 0, 1, 0, x[0], y[0], k[0])
+    with pytest.raises(capi.PbdError) as e:                      # one plane of one level only
+        hd.dp_argmin()
+    assert e.value.code == capi.PBD_ERR_STATE
+    bad = ri.copy(); bad[0, 0] = 2                               # the root has 2 mixtures
+    with pytest.raises(capi.PbdError) as e:
+        hd.set_root(0, 0, rv, bad)
+    assert e.value.code == capi.PBD_ERR_ARG
+    ref = []
+    for l, (x, y, k, rv, ri) in enumerate(tabs):
+        hd.set_root(l, 0, rv, ri)
+        for pl in range(4):                                      # parts 1, 2 x parent mixtures 0, 1
+            if l == g["nlevels"] - 1 and pl == 3:
+                with pytest.raises(capi.PbdError) as e:          # all but the very last plane: still refused
+                    hd.dp_argmin()
+                assert e.value.code == capi.PBD_ERR_STATE
+            hd.set_dp_pointers(l, 0, 1 + pl // 2, pl % 2, x[pl], y[pl], k[pl])
+        ref.append(orc.dp_argmin_level(desc, 0, l, g["scales"][l], rv, ri, x, y, k))
+    want = tuple(np.concatenate([c[i] for c in ref]) for i in range(3))
+    assert len(want[0]) > 0
+    assert_candidates_equal(hd.dp_argmin(), want)
+    # batch plan: the stage entry points refuse, nothing stays pending
+    frames = [make_image(s, 100, 80) for s in (1, 2)]
+    outs = hd.detect_batch(frames)
+    for fn in (hd.dp_argmin, lambda: hd.root(0, 0)):
+        with pytest.raises(capi.PbdError) as e:
+            fn()
+        assert e.value.code == capi.PBD_ERR_STATE
+    for got, again in zip(outs, hd.detect_batch(frames)):
+        assert_candidates_equal(got, again)
+    with pytest.raises(ValueError):
+        hd.detect_batch([frames[0], make_image(1, 96, 80)])
+    with pytest.raises(ValueError):
+        hd.detect_batch([])
+    hd.close()
+
+
 def _tables_checksum(orc, model, im, dtype=np.float32):
     """Position-weighted checksum of the oracle's Ix / Iy / Ik tables in the order host/demo.cpp walks them."""
     fr = orc.detect(model, im, capacity=1, keep=True, dtype=dtype)[4]
