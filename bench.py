@@ -29,6 +29,11 @@ per step); the only collective is the gather of the candidate buffers to rank 0 
 nccl) — done for EVERY step, inside the timed region ("multi-GPU wall time includes the RCCL
 candidate gather").  `python bench.py --gpus N` without a torchrun environment spawns its own N ranks
 (torch.distributed.run on 127.0.0.1); `--group` is the one-process alternative (pbd_group).
+N > 1: only the timed legs run on every rank; the single-frame / sequential / batch-stage / CPU legs are rank 0's (the
+other ranks wait at one barrier), and the line carries `config.ranks` (rank -> device index, PCI bus id, uuid, pid) and
+`config.backend_world` gathered inside the run, so that a multi-GPU line can be audited from its JSON.
+`--legs` restricts the run to some legs (profiling: `--legs batchseq --graph 0 --inflight 1` launches only batch chains,
+one at a time — what `roofline` is quoted on; profiles/collect.sh).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -126,7 +131,11 @@ def main_group(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"person 26 parts x {args.mixtures} mixtures, {W}x{H} BGR, full pyramid, threshold = 99.9th pct of root scores",
                        "frames_per_step_per_gpu": 1, "inflight": S, "input": "pinned host images (H2D inside the timed region)",
-                       "parallelism": f"pbd_group: one process, {N} device(s) x {S} members, host gather", "prewarm_frames": nwarm,
+                       "parallelism": f"pbd_group: one process, {N} device(s) x {S} members", "prewarm_frames": nwarm,
+                       "group_size": g.size, "gather_mode": {capi.PBD_GATHER_HOST: "host", capi.PBD_GATHER_RCCL: "rccl"}.get(g.gather_mode, g.gather_mode),
+                       "devices": [{"device": d, "name": torch.cuda.get_device_properties(d).name,
+                                    "pci_bus_id": getattr(torch.cuda.get_device_properties(d), "pci_bus_id", None),
+                                    "uuid": str(getattr(torch.cuda.get_device_properties(d), "uuid", "")) or None} for d in range(N)],
                        "candidates_last_frame": int(len(outs[-1][0]))}}
     print(json.dumps(line), flush=True)
     g.close()
@@ -162,7 +171,18 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("PBD_GRAPH", "1")), help="pbd_options.graph: replay a captured hipGraph per frame")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU-side smoke runs)")
+    ap.add_argument("--legs", default="all",
+                    help="comma-separated subset of timed,h2d,single,seq,batchseq,cpu (default all).  timed = the K steps `value` is quoted "
+                         "on; h2d = the same with pinned host images; single = the handles fed one frame per call; seq = sequential "
+                         "single frames with stage events; batchseq = batches one at a time with stage events (`roofline`); cpu = the "
+                         "oracle on the host cores.  Without `timed` the line's value is null (profiling runs)")
     args = ap.parse_args()
+    ALL_LEGS = ("timed", "h2d", "single", "seq", "batchseq", "cpu")
+    legs = set(ALL_LEGS) if args.legs == "all" else set(x for x in args.legs.split(",") if x)
+    if legs - set(ALL_LEGS):
+        raise SystemExit(f"--legs: unknown leg(s) {sorted(legs - set(ALL_LEGS))}; choose from {ALL_LEGS}")
+    if args.no_cpu_baseline:
+        legs.discard("cpu")
 
     import torch
     import torch.distributed as dist
@@ -201,7 +221,9 @@ def main():
     dtype = np.float64 if args.dtype == "f64" else np.float32
     # distinct frames per rank and per step slot (32 seeds as in configs[2]); resident in HBM and, for the
     # H2D-inclusive leg, in pinned host memory
-    nimg = 8
+    B = max(1, args.batch)
+    nimg = 32 if W * H <= 640 * 480 else 8           # (large frames: fewer, the buffers are 6 MB each)
+    nimg = max(nimg // B, 1) * B if B <= nimg else B  # a whole number of distinct batches
     by_levels = args.shard == "levels" and world > 1
     host_frames = [torch.from_numpy(make_image((0 if by_levels else rank * nimg) + i, W, H)).pin_memory() for i in range(nimg)]
     frames = [t.to(dev) for t in host_frames]
@@ -209,12 +231,12 @@ def main():
     model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).to(dev), W, H, dtype=dtype)
 
     S = max(1, args.inflight)
-    B = max(1, args.batch)
     cap = 4096 if W * H <= 640 * 480 else 32768      # the 99.9th-percentile threshold scales the count with the area
     handles = [capi.Handle(model, device=local, conv_mode=conv, max_candidates=cap * (B if B > 1 else 1), dtype=dtype, graph=args.graph) for _ in range(S)]
+    nslots = nimg // B    # distinct step slots: slot k holds frames k * B .. k * B + B - 1 (no frame is in two slots)
     if B > 1:   # batches: B frames back to back in HBM (and B pinned host frames) per step slot
-        dev_batches = [torch.stack([frames[(k * B + j) % nimg] for j in range(B)]).contiguous() for k in range(nimg)]
-        host_batches = [[host_frames[(k * B + j) % nimg].data_ptr() for j in range(B)] for k in range(nimg)]
+        dev_batches = [torch.stack([frames[k * B + j] for j in range(B)]).contiguous() for k in range(nslots)]
+        host_batches = [[host_frames[k * B + j].data_ptr() for j in range(B)] for k in range(nslots)]
     if by_levels:   # SURVEY 8e / configs[3]: one frame, levels spread over the ranks by greedy LPT on the cell counts
         from partsbaseddetector_amd.parallel import shard_levels_lpt
         g = handles[0].geometry(W, H)
@@ -236,10 +258,10 @@ def main():
         outs_b = hd.collect_batch(cap)
         return tuple(np.concatenate([o[k] for o in outs_b]) for k in range(3))
 
-    def run(nsteps, collect_out=None, stamps=None, host=False, B=B):
+    def run(nsteps, collect_out=None, stamps=None, host=False, B=B, solo=False):
         """S frames in flight; host=True hands over pinned host images (H2D inside every step).  N > 1: every
         step's candidates are gathered to rank 0 — after the next frame has been enqueued, so the collective
-        overlaps the GPU's work on the frames in flight."""
+        overlaps the GPU's work on the frames in flight.  solo: this rank alone (rank 0's extra legs): no collective."""
         pending = []
         for i in range(nsteps):
             hd = handles[i % S]
@@ -252,15 +274,15 @@ def main():
                     collect_out.append(out)
             if B > 1:
                 if host:
-                    hd.enqueue_batch_host_ptrs(host_batches[i % nimg], W, H, 3)
+                    hd.enqueue_batch_host_ptrs(host_batches[i % nslots], W, H, 3)
                 else:
-                    hd.enqueue_batch_dev(dev_batches[i % nimg].data_ptr(), B, W, H, 3)
+                    hd.enqueue_batch_dev(dev_batches[i % nslots].data_ptr(), B, W, H, 3)
             elif host:
                 hd.enqueue_host_ptr(host_frames[i % nimg].data_ptr(), W, H, 3)
             else:
                 hd.enqueue_dev(frames[i % nimg].data_ptr(), W, H, 3)
             pending.append(hd)
-            if out is not None:
+            if out is not None and not solo:
                 gather(out)
         for hd in pending:
             out = collect_one(hd, B)
@@ -268,28 +290,42 @@ def main():
                 stamps.append(time.perf_counter())
             if collect_out is not None:
                 collect_out.append(out)
-            gather(out)
+            if not solo:
+                gather(out)
 
-    def timed(nsteps, host, B=B):
+    def timed(nsteps, host, B=B, solo=False):
+        coll = world > 1 and not solo
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         outs, stamps = [], [t0]
-        run(nsteps, outs, stamps, host=host, B=B)
+        run(nsteps, outs, stamps, host=host, B=B, solo=solo)
         torch.cuda.synchronize()
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if coll:
             tmax = torch.tensor([dt], dtype=torch.float64)
             if cdev is not None:
                 tmax = tmax.to(cdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt, outs, np.diff(np.asarray(stamps)) * 1e3
+
+    # ---- who is who (N > 1): gathered inside the run, so that the line proves which ranks ran on which devices ----
+    ranks_info, backend_world = None, 1
+    if world > 1:
+        pr = torch.cuda.get_device_properties(local)
+        me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": local, "name": pr.name,
+              "pci_bus_id": getattr(pr, "pci_bus_id", None), "pci_device_id": getattr(pr, "pci_device_id", None),
+              "pci_domain_id": getattr(pr, "pci_domain_id", None), "uuid": str(getattr(pr, "uuid", "")) or None,
+              "pid": os.getpid(), "visible_devices": torch.cuda.device_count()}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+        backend_world = dist.get_world_size()
 
     # ---- setup: pre-warm every handle (plan, LDS opt-ins, pinned buffers) and the clocks for a fixed wall time ----
     prewarm_frames = 0
@@ -303,63 +339,72 @@ def main():
         hd.dp_timer(reset=True)
 
     # ---- the timed region: exactly K steps, frames resident in HBM ----
-    dt, outs, per_frame_ms = timed(args.steps, host=False)
+    dt = dt_h2d = None
+    outs, per_frame_ms, per_frame_ms_h2d = [], [0.0], [0.0]
+    if "timed" in legs:
+        dt, outs, per_frame_ms = timed(args.steps, host=False)
     # ---- the same K steps handing over pinned host images: H2D inside every step ----
-    dt_h2d, outs_h2d, per_frame_ms_h2d = timed(args.steps, host=True)
+    if "h2d" in legs:
+        dt_h2d, _, per_frame_ms_h2d = timed(args.steps, host=True)
     if world > 1:
-        ncand_all = sum(len(g[0]) for g in gathered_last[0]) if rank == 0 else 0   # the last step's gather (inside the timed region)
+        ncand_all = sum(len(g[0]) for g in gathered_last[0]) if (rank == 0 and gathered_last[0]) else 0   # the last step's gather (inside the timed region)
     else:
-        ncand_all = len(outs[-1][0])
+        ncand_all = len(outs[-1][0]) if outs else 0
 
-    # ---- the same handles called one frame at a time (pbd_detect_enqueue_dev_u8 / collect: S single frames in flight) ----
+    # Everything below describes ONE GPU (single-frame calls, sequential latency, stage times, roofline, CPU baseline): rank 0
+    # measures it, the other ranks wait at the barrier — an N-rank run is N x the timed legs, not N x the whole script.
+    extra = rank == 0
     dt_single = None
-    if B > 1:
-        run(3 * S, B=1)                      # re-plan for single frames (untimed)
-        dt_single, _, _ = timed(args.steps * B, host=False, B=1)
-
-    # ---- sequential leg: one frame in flight on one handle, host image in, candidates out (pbd_detect_u8 semantics) ----
+    seq_ms, stage_acc, dp_ms_seq, stage_batch, nseq = [0.0], {}, 0.0, None, 30
     hd = handles[0]
-    hd.set_profiling(True)
-    hd.dp_timer(reset=True)
-    nseq = 30
-    stage_acc, seq_ms = {}, []
-    for i in range(nseq + 3):
-        t1 = time.perf_counter()
-        hd.enqueue_host_ptr(host_frames[i % nimg].data_ptr(), W, H, 3)
-        hd.collect(cap)
-        t2 = time.perf_counter()
-        if i < 3:
-            hd.dp_timer(reset=True)
-            continue
-        seq_ms.append((t2 - t1) * 1e3)
-        for k, v in hd.stage_ms().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v / nseq
-    dp_ms_seq = hd.dp_timer()[0]
-    # ---- the benched unit of work, one at a time: a batch of B frames per call, per-stage HIP events on (eager launches) ----
-    stage_batch = None
-    if B > 1:
-        nbat = 12
-        stage_batch = {}
-        for i in range(nbat + 3):
-            hd.enqueue_batch_dev(dev_batches[i % nimg].data_ptr(), B, W, H, 3)
-            hd.collect_batch(cap)
-            if i >= 3:
+    if extra:
+        # ---- the same handles called one frame at a time (pbd_detect_enqueue_dev_u8 / collect: S single frames in flight) ----
+        if B > 1 and "single" in legs:
+            run(3 * S, B=1, solo=True)                      # re-plan for single frames (untimed)
+            dt_single, _, _ = timed(args.steps * B, host=False, B=1, solo=True)
+        hd.set_profiling(True)
+        hd.dp_timer(reset=True)
+        # ---- sequential leg: one frame in flight on one handle, host image in, candidates out (pbd_detect_u8 semantics) ----
+        if "seq" in legs:
+            seq_ms = []
+            for i in range(nseq + 3):
+                t1 = time.perf_counter()
+                hd.enqueue_host_ptr(host_frames[i % nimg].data_ptr(), W, H, 3)
+                hd.collect(cap)
+                t2 = time.perf_counter()
+                if i < 3:
+                    hd.dp_timer(reset=True)
+                    continue
+                seq_ms.append((t2 - t1) * 1e3)
                 for k, v in hd.stage_ms().items():
-                    stage_batch[k] = stage_batch.get(k, 0.0) + v / nbat
-    hd.set_profiling(False)
+                    stage_acc[k] = stage_acc.get(k, 0.0) + v / nseq
+            dp_ms_seq = hd.dp_timer()[0]
+        # ---- the benched unit of work, one at a time: a batch of B frames per call, per-stage HIP events on (eager launches) ----
+        if B > 1 and "batchseq" in legs:
+            nbat = 12
+            stage_batch = {}
+            for i in range(nbat + 3):
+                hd.enqueue_batch_dev(dev_batches[i % nslots].data_ptr(), B, W, H, 3)
+                hd.collect_batch(cap)
+                if i >= 3:
+                    for k, v in hd.stage_ms().items():
+                        stage_batch[k] = stage_batch.get(k, 0.0) + v / nbat
+        hd.set_profiling(False)
 
     if rank == 0:
+        if not stage_acc and stage_batch is None:   # neither stage leg ran: one plan is still needed for work()
+            hd.enqueue_dev(frames[0].data_ptr(), W, H, 3); hd.collect(cap)
         work = hd.work()
-        stage = stage_acc
+        stage = stage_acc or {k: 0.0 for k in ("image_pyramid", "hog", "pdf", "dp_min", "argmin", "total")}
         dp_ms = dp_ms_seq
         per_rank = (1 if by_levels else world) * B
-        ms_per_step = dt / args.steps * 1e3
-        value = args.steps * per_rank / dt
-        value_h2d = args.steps * per_rank / dt_h2d
+        ms_per_step = dt / args.steps * 1e3 if dt else None
+        value = args.steps * per_rank / dt if dt else None
+        value_h2d = args.steps * per_rank / dt_h2d if dt_h2d else None
         # roofline of the stage the north_star prices: the DP/distance-transform pass (HBM-bound by bytes).
         # achieved = algorithmic bytes of one frame's pass (B_dp) / its GPU time measured
         # with HIP events on the handle's stream in the sequential leg.
-        dp_gbs = work["B_dp"] / (dp_ms * 1e-3) / 1e9
+        dp_gbs = work["B_dp"] / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
         pdf_tf = work["F_pdf"] / (stage["pdf"] * 1e-3) / 1e12 if stage["pdf"] > 0 else 0.0
         traffic, traffic_source, traffic_b = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_dp.json")
@@ -371,7 +416,7 @@ def main():
             tb = tj.get("batch")
             if tb and tb.get("frames_per_launch") == B:
                 traffic_b = tb["hbm_bytes_per_launch_corrected"]
-        roof_single = {"kernel": "dp_min stage (distance-transform passes + mixture reduce + root), one frame per launch chain", "bound": "hbm",
+        roof_single = {"kernel": "dp_min stage (distance-transform passes + root), one frame per launch chain", "bound": "hbm",
                        "achieved": round(dp_gbs, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(dp_gbs / 8000.0, 5),
                        "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(float(dp_ms), 4),
                        "algorithmic_bytes": work["B_dp"], "launch_mode": "eager launches, per-stage HIP events on (the timed loop replays a hipGraph)",
@@ -386,7 +431,8 @@ def main():
                     "launch_ms": round(float(stage_batch["dp_min"]), 4), "units_per_launch": B,
                     "algorithmic_bytes": B * work["B_dp"], "algorithmic_bytes_per_frame": work["B_dp"],
                     "launch_mode": "eager launches, per-stage HIP events on (the timed loop replays a hipGraph)",
-                    "timing": "HIP events around the stage, mean of 12 sequential batches after the timed loop"}
+                    "timing": "HIP events around the stage, mean of 12 sequential batches after the timed loop; the rocprofv3 kernel trace of the "
+                              "same leg (bench.py --legs batchseq --graph 0 --inflight 1) is profiles/*_kernel_stats_batch8.csv"}
         elif stage["dp_min"] >= stage["pdf"]:
             roof = roof_single
         else:
@@ -396,31 +442,41 @@ def main():
                     "achieved": round(pdf_tf, 3),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(pdf_tf / peak, 5), "traffic": None,
                     "launch_ms": round(float(stage["pdf"]), 4), "algorithmic_flops": work["F_pdf"]}
+        rnd = lambda v, n=3: None if v is None else round(v, n)
+        config = {"workload": f"person 26 parts x {args.mixtures} mixtures ({len(model.filtersw)} {model.filtersw[0].shape[0]}x{model.filtersw[0].shape[1] // 32}x32 filters), "
+                              f"{W}x{H} BGR, full pyramid ({hd.geometry(W, H)['nlevels']} levels), "
+                              f"threshold = 99.9th pct of root scores",
+                  "frames_per_step_per_gpu": B, "inflight": S, "conv": args.conv, "input": "frames resident in HBM",
+                  "distinct_frames_per_rank": nimg, "distinct_step_slots": nslots,
+                  "batching": (f"pbd_detect_batch: every handle processes {B} frames per step, one launch per stage for the batch" if B > 1 else "single frames"),
+                  "launch": "hipGraph replay (one hipGraphLaunch per step)" if args.graph else "eager (~30 launches per step)",
+                  "legs": sorted(legs), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                  "prewarm_s": 0.0 if args.no_prewarm else PREWARM_S, "prewarm_frames": prewarm_frames,
+                  "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}"),
+                  "gather": (f"every step, inside the timed region: torch.distributed gather to rank 0, backend {args.backend}, "
+                             f"counts first, then the records padded to the longest list" if world > 1 else "none (one rank)")}
+        if world > 1:
+            config["backend"] = dist.get_backend()
+            config["backend_world"] = backend_world
+            config["ranks"] = ranks_info
+            config["distinct_devices"] = len({(r["device"], r["pci_bus_id"], r["uuid"]) for r in ranks_info})
+            config["rank0_only_legs"] = "single-frame calls, sequential latency, stage times / roofline, CPU baseline (the other ranks wait at a barrier)"
         line = {
             "metric": f"detect() frames/sec, {W}x{H}, 26-part person model",
-            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "value": rnd(value), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": rnd(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if by_levels else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"person 26 parts x {args.mixtures} mixtures ({len(model.filtersw)} 5x5x32 filters), "
-                                   f"{W}x{H} BGR, full pyramid ({hd.geometry(W, H)['nlevels']} levels), "
-                                   f"threshold = 99.9th pct of root scores",
-                       "frames_per_step_per_gpu": B, "inflight": S, "conv": args.conv, "input": "frames resident in HBM",
-                       "batching": (f"pbd_detect_batch: every handle processes {B} frames per step, one launch per stage for the batch" if B > 1 else "single frames"),
-                       "launch": "hipGraph replay (one hipGraphLaunch per frame)" if args.graph else "eager (~40 launches per frame)",
-                       "prewarm_s": 0.0 if args.no_prewarm else PREWARM_S, "prewarm_frames": prewarm_frames,
-                       "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}"),
-                       "gather": (f"every step, inside the timed region: torch.distributed gather to rank 0, backend {args.backend}, "
-                                  f"counts first, then the records padded to the longest list" if world > 1 else "none (one rank)")},
+            "config": config,
             "frame_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),
-                         "what": "completion-to-completion wall time per step (one frame, or one batch) in the timed loop (rank 0)"},
-            "value_resident": round(value, 3), "value_incl_h2d": round(value_h2d, 3),
-            "value_single_frame_calls": (round(args.steps * B * (1 if by_levels else world) / dt_single, 3) if dt_single else round(value, 3)),
-            "value_is": "frames resident in HBM when the timed region starts (this tier's contract for `value`); the H2D-inclusive "
-                        "figure of SURVEY 8d is value_incl_h2d; value_single_frame_calls = the same handles fed one frame per call "
-                        "(pbd_detect_enqueue_dev_u8) instead of batches",
-            "incl_h2d": {"value": round(value_h2d, 3), "unit": "frames/s", "ms_per_step": round(dt_h2d / args.steps * 1e3, 4),
+                         "what": f"completion-to-completion wall time per step in the timed loop (rank 0): completions of the {S} steps in flight "
+                                 f"arrive in bursts — throughput pacing, not latency (latency: `sequential`)"},
+            "value_resident": rnd(value), "value_incl_h2d": rnd(value_h2d),
+            "value_single_frame_calls": (round(args.steps * B / dt_single, 3) if dt_single else None),
+            "value_is": "frames resident in HBM when the timed region starts (the tier's contract, DESIGN.md 7); value_incl_h2d = the same steps "
+                        "from pinned host images; value_single_frame_calls = ONE GPU's handles fed one frame per call",
+            "incl_h2d": {"value": rnd(value_h2d), "unit": "frames/s", "ms_per_step": rnd(dt_h2d / args.steps * 1e3 if dt_h2d else None, 4),
                          "frame_ms": {"median": pct(per_frame_ms_h2d, 50), "p10": pct(per_frame_ms_h2d, 10), "p90": pct(per_frame_ms_h2d, 90)},
-                         "what": "the same K steps with every frame handed over as a pinned host image (pbd_detect_enqueue_u8: "
+                         "what": "the same K steps with every frame handed over as a pinned host image (pbd_detect_[batch_]enqueue_u8: "
                                  "H2D + kernels + D2H of the candidates per step)"},
             "sequential": {"latency_ms": {"median": pct(seq_ms, 50), "p10": pct(seq_ms, 10), "p90": pct(seq_ms, 90)},
                            "frames": nseq, "what": "one frame in flight: host image in, candidates out, wall time per call"},
@@ -433,7 +489,7 @@ def main():
             "stage_ms_sequential": {k: round(v, 4) for k, v in stage.items()},
             "stage_ms_per_frame_batched": ({k: round(v / B, 4) for k, v in stage_batch.items()} if stage_batch else None),
         }
-        if not args.no_cpu_baseline:
+        if "cpu" in legs:
             # bounded CPU sample: the oracle (reference-structured OpenMP restatement), same model and image size.
             from oracle import orc
             ims = [make_image(i, W, H) for i in range(3)]
@@ -453,16 +509,27 @@ def main():
             orc.detect(model, ims[0], dtype=dtype)
             t1 = time.perf_counter() - t
             orc.set_num_threads(ncores)
+            flags = "unknown"
+            try:
+                for ln in open(os.path.join(ROOT, "oracle", "Makefile")):
+                    if ln.startswith("CFLAGS"):
+                        flags = ln.split("=", 1)[1].strip()
+            except OSError:
+                pass
             line["cpu_baseline"] = {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": ncores, "threads": ncores,
                                     "hw_threads": nhw, "kind": "port", "cpu": cpu_name,
+                                    "flags": f"gcc {flags} (built where the repository is built: no -march=native, the binary travels to the "
+                                             f"GPU box); OpenMP: plain `#pragma omp parallel for` (static schedule) at the reference's five sites",
                                     "sample": f"median of 5 frames {W}x{H} after 2 warm-ups, same model, oracle/pbd_oracle.c "
-                                              f"(OpenMP at the reference's five loops: the filter bank is `omp for` over its {len(model.filtersw)} filters on "
-                                              f"{ncores} threads), one thread on each of the {ncores} physical cores",
+                                              f"(the filter bank is `omp parallel for` over its {len(model.filtersw)} filters on "
+                                              f"{ncores} threads, as src/SpatialConvolutionEngine.cpp:114-117), one thread on each of the {ncores} physical cores",
                                     "frame_s": {"median": round(med, 4), "min": round(min(times), 4), "max": round(max(times), 4)},
                                     "stage_ms": [round(x, 1) for x in stage_ms],
                                     "single_thread": {"value": round(1.0 / t1, 4), "unit": "frames/s", "threads": 1,
                                                       "sample": f"1 frame {W}x{H}, same model (OMP_NUM_THREADS=1 equivalent)"}}
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()       # ranks > 0 have been waiting here while rank 0 ran its extra legs
     for hd in handles:
         hd.close()
     if world > 1:

@@ -345,6 +345,7 @@ static int upload_model(pbd_handle* h) {
 // ---------------------------------------------------------------------------
 // frame plan
 // ---------------------------------------------------------------------------
+static const int kFirstCopy = PBD_FIRST_COPY;  // records fetched together with the count (per frame of the plan; grows, pbd_i_finish_frame)
 template <typename T>
 static int dev_alloc(pbd_handle* h, T** p, size_t n) {
   void* q = nullptr;
@@ -455,6 +456,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
                                 "(src/HOGFeatures.cpp:99,114)");
   const int n1 = n;             // levels of one frame
   h->nlevels = n1; h->batch = batch; h->nvl = n1 * batch;
+  h->first_copy = kFirstCopy * batch;
   h->lv.resize(h->nvl);
   for (int f = 1; f < batch; ++f)
     for (int l = 0; l < n1; ++l) h->lv[f * n1 + l] = h->lv[l];
@@ -991,8 +993,6 @@ static int run_dp_min(pbd_handle* h) {
   return PBD_OK;
 }
 
-static const int kFirstCopy = PBD_FIRST_COPY;  // records fetched together with the count
-
 static int run_argmin_enqueue(pbd_handle* h) {
   if (h->root_dirty) {   // root tables injected since min(): the hits are those of the tables now on the device
     hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
@@ -1005,7 +1005,9 @@ static int run_argmin_enqueue(pbd_handle* h) {
                    h->d_depth, h->max_depth, (int)h->parts.size(), h->d_scr_base, h->d_dt_ixT, h->d_dt_iy,
                    h->opt.dt_correct_ptr, h->ext_ptr ? h->d_extx : nullptr, h->d_exty, h->d_ext_base, h->stream);
   LAUNCHCHK(h, "argmin");
-  const int first = std::min(kFirstCopy * h->batch, h->opt.max_candidates);
+  // members of an RCCL-gathering group send a fixed block (pbd_group.cpp sizes its buffers for PBD_FIRST_COPY records)
+  if (h->d_gsend || h->first_copy < kFirstCopy * h->batch) h->first_copy = kFirstCopy * h->batch;
+  const int first = std::min(h->first_copy, h->opt.max_candidates);
   if (h->d_gsend) {   // member of an RCCL-gathering pbd_group: pack {count, first records} for the all-gather instead of the D2H
     HIPCHK(h, hipMemcpyAsync(h->d_gsend, h->d_cand_count, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_gsend + 16, h->d_cand_out, h->cand_stride * first, hipMemcpyDeviceToDevice, h->stream));
@@ -1026,11 +1028,18 @@ int pbd_i_finish_frame(pbd_handle* h, int found) {
     if (hipEventElapsedTime(&ms, h->ev_dp0, h->ev_dp1) == hipSuccess) { h->dp_ms_sum += ms; h->dp_frames++; }
   }
   const int n = std::min(found, h->opt.max_candidates);
-  const int first = std::min(kFirstCopy * h->batch, h->opt.max_candidates);
+  const int first = std::min(h->first_copy, h->opt.max_candidates);
   if (n > first) {
     HIPCHK(h, hipMemcpyAsync(h->h_cand_out + h->cand_stride * first, h->d_cand_out + h->cand_stride * first,
                              h->cand_stride * (n - first), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!h->d_gsend) {
+      // this geometry / threshold yields more records than the first copy carries: size it for what was seen (+25 %), so
+      // that the following frames need no second copy and no second synchronisation.  The copy's size is baked into a
+      // captured graph: drop it, the next frame captures again (host cost of one capture, once).
+      h->first_copy = std::min(h->opt.max_candidates, n + n / 4 + 16);
+      if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    }
   }
   if (found > h->opt.max_candidates) return fail(h, PBD_ERR_CAPACITY, "device candidate capacity exceeded; raise pbd_options.max_candidates");
   return PBD_OK;

@@ -202,6 +202,8 @@ struct pbd_handle {
   char* d_cand_out = nullptr; char* h_cand_out = nullptr; int* h_cand_count = nullptr;
   size_t cand_stride = 0;
   bool pending = false;
+  int first_copy = 0;        // candidate records copied back together with the count (records): starts at PBD_FIRST_COPY per frame of the
+                             // plan and grows to 1.25 x the largest count seen, so that the steady state is ONE D2H and no second sync
   char* d_gsend = nullptr;   // set by an RCCL-gathering pbd_group: {count, pad to 16 B, first records} block sent by ncclAllGather
 
   hipStream_t stream = nullptr;

@@ -1135,16 +1135,44 @@ def test_detect_batch_person_model_640x480(gpu_required, orc):
     for got, f in zip(outs, frames):
         assert_candidates_equal(got, orc.detect(m, f)[:3])
     h.close()
-    # bench.py's unit of work: batches of 8 through PBD_CONV_AUTO (-> the MFMA bank), graph replay — frame by frame what the
-    # same handle returns for the frame on its own (the single-frame MFMA path is held to the oracle, every difference
-    # classified, by test_detect_person_timed_configuration_classified)
+
+
+def test_benched_unit_batch8_mfma_graph_vs_oracle(gpu_required, orc):
+    """bench.py's unit of work held to the ORACLE: a batch of 8 person-model frames at 640x480 through
+    PBD_CONV_AUTO (-> the MFMA bank), graph replay, 3 repetitions; every frame of the batch against orc.detect
+    (src/PartsBasedDetector.cpp:69-95) with every part-location difference classified (north_star: "argmax part locations
+    exact, scores within 1e-4") — plus 8 further seeds frame by frame, so that the flip rate of the MFMA bank is a number
+    with a denominator: printed, and asserted < 0.5 % of > 1 000 candidates.
+    The classification itself (_classified_compare): root scores within 1e-4; a location difference counts as explained
+    only if (i) the oracle's DP replayed on the GPU's OWN responses back-tracks to exactly the GPU's locations — i.e. the
+    distance transform, the message passing and the back-tracking are bit-exact and the flip comes from the <= 2e-5
+    response perturbation alone: THIS is what carries the classification — and (ii) the two alternatives are a near-tie
+    in the oracle's numbers (the bound grows with the subtree: each of its parts can move either alternative)."""
+    m = make_person_model()
     frames8 = [make_image(10 + i, 640, 480) for i in range(8)]
-    ha = capi.Handle(m, graph=1, max_candidates=8 * 4096)
+    m.thresh = thresh_from_oracle(orc, m, make_image(0, 640, 480), 99.9)
+    ha = capi.Handle(m, graph=1, max_candidates=8 * 4096)    # PBD_CONV_AUTO, as in bench.py
     for rep in range(3):
         outs8 = ha.detect_batch(frames8)
-    for got, f in zip(outs8, frames8):
-        assert_candidates_equal(got, ha.detect(f))
-    ha.close()
+    hs = capi.Handle(m)                                      # the same frames on their own: the batch must equal them bit for bit
+    tot_n = tot_flips = tot_ties = 0
+    singles = [make_image(100 + i, 640, 480) for i in range(8)]
+    for idx, im in enumerate(frames8 + singles):
+        rh, rb, rl, _, fr = orc.detect(m, im, keep=True)
+        got = hs.detect(im)
+        if idx < 8:
+            assert_candidates_equal(outs8[idx], got)
+            got = outs8[idx]
+        n, flips, ties, bugs, worst = _classified_compare(orc, m, im, hs, got, (rh, rb, rl), fr)
+        fr.free()
+        assert len(rh) > 30 and n >= 0.95 * len(rh), (idx, len(rh), n)
+        assert not bugs, (idx, bugs)
+        tot_n += n; tot_flips += flips; tot_ties += ties
+    ha.close(); hs.close()
+    rate = tot_flips / max(tot_n, 1)
+    print(f"MFMA bank vs oracle, person 26x6 640x480, 8 frames of a graph-replayed batch + 8 single frames: {tot_n} common candidates, "
+          f"{tot_flips} with different part locations = {100 * rate:.3f} % (all {tot_ties} classified near-ties, 0 bugs)")
+    assert tot_n > 1000 and rate < 0.005, (tot_n, tot_flips)
 
 
 def test_group_batch_configs2_shape(gpu_required, orc):
@@ -1204,7 +1232,23 @@ def test_bench_lines_parse(gpu_required):
         line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["n_gpus"] == ngpu and line["value"] > 0 and line["unit"] == "frames/s"
         if ngpu == 2:
-            assert "every step" in line["config"]["gather"] and line["config"]["candidates_last_frame"] > 0
+            # what makes a multi-GPU line auditable from its JSON: every rank's device, gathered inside the run
+            cfg = line["config"]
+            assert "every step" in cfg["gather"] and cfg["candidates_last_frame"] > 0
+            assert cfg["backend"] == "gloo" and cfg["backend_world"] == 2 and len(cfg["ranks"]) == 2
+            assert [r["rank"] for r in cfg["ranks"]] == [0, 1] and len({r["pid"] for r in cfg["ranks"]}) == 2
+            assert all("device" in r and "pci_bus_id" in r and "uuid" in r for r in cfg["ranks"])
+            assert cfg["distinct_devices"] == 1                      # this box has one GPU: two gloo ranks share it, and the line says so
+            assert line["value_single_frame_calls"] > 0 and line["roofline"]["frac"] > 0   # rank 0's extra legs still ran
+        else:
+            assert line["config"]["group_size"] == 3 and line["config"]["gather_mode"] == "host" and len(line["config"]["devices"]) == 1
+    # profiling form: only batch chains, one at a time (what `roofline` is quoted on); no timed leg -> value null
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--legs", "batchseq", "--graph", "0", "--inflight", "1", "--no-prewarm",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-6000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["value"] is None and line["config"]["legs"] == ["batchseq"] and "cpu_baseline" not in line
+    assert line["roofline"]["units_per_launch"] == 8 and 0.05 < line["roofline"]["frac"] < 1.0
 
 
 def test_group_level_sharding_more_members_than_needed(gpu_required, orc):

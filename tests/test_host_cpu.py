@@ -231,6 +231,26 @@ def test_traffic_file_matches_the_bench_defaults():
     assert abs(b["hbm_bytes_per_frame_corrected"] / tj["hbm_bytes_per_frame_corrected"] - 1.0) < 0.05
 
 
+def test_batch_chain_trace_matches_the_bench_defaults():
+    """The headline `roofline` must be recomputable from profiles/: the latest <tag>_chains_batch8.json (rocprofv3 kernel
+    trace of a run launching only chains of the benched unit, profiles/collect_r04.sh) is for bench.py's default batch
+    size, and the sum of its kernel durations agrees with the HIP-event `launch_ms` of the bench line of the same run."""
+    import glob
+    import json
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_chains_batch8.json")))
+    if not files:
+        pytest.skip("no batch-chain trace collected yet")
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    default_batch = int(re.search(r'os\.environ\.get\("PBD_BATCH", "(\d+)"\)', src).group(1))
+    ch = json.load(open(files[-1]))
+    assert ch["frames_per_launch"] == default_batch
+    g = ch["benched_chain"]
+    assert g["chains"] >= 8 and g["launches_per_chain"] == 19          # 8 fold-x + 10 plain DT passes + k_root for the person tree
+    ev = ch["bench_line_of_this_run"]["roofline.launch_ms (HIP events, same process, under the profiler)"]
+    assert abs(g["sum_of_kernel_durations_ms"] / ev - 1.0) < 0.05, (g["sum_of_kernel_durations_ms"], ev)
+
+
 def test_bench_line_schema_fields():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
