@@ -26,6 +26,13 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/pbd_c.h but not exported"
     assert declared == set(capi.EXPORTS)
+    # the tuning build (same sources, planner knobs enabled; loaded by the tuning-variant parity test through PBD_LIBRARY)
+    # must carry the same ABI: a stale copy fails here, not on the GPU box
+    tune = os.path.join(os.path.dirname(capi.LIB_PATH), "libpbd_hip_tune.so")
+    assert os.path.exists(tune), "libpbd_hip_tune.so missing: `make -C partsbaseddetector_amd/csrc` builds it next to libpbd_hip.so"
+    Lt = C.CDLL(tune)
+    for name in sorted(declared):
+        assert hasattr(Lt, name), f"{name} missing from libpbd_hip_tune.so (stale build)"
 
 
 def test_no_cpu_fallback_create_fails_without_gpu():
