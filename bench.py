@@ -245,11 +245,12 @@ def main():
             hd.set_levels(my_levels)
 
     gathered_last = [None]
+    B_gather = [B]      # frames per step of the leg that is running: a step's records are the candidates of ALL its frames (<= cap each)
 
     def gather(out):
         """The one collective of the path: this step's candidates of every rank -> rank 0 (N = 1: nothing to do)."""
         if world > 1:
-            gathered_last[0] = gather_candidates(out, handles[0].max_parts, capacity=cap, device=cdev, dst=0)
+            gathered_last[0] = gather_candidates(out, handles[0].max_parts, capacity=cap * B_gather[0], device=cdev, dst=0)
 
     def collect_one(hd, B):
         """the step's candidates: one frame's, or the batch's (concatenated: (level, component, root) order inside a frame)"""

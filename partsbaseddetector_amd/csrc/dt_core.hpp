@@ -61,6 +61,20 @@ DT_HD unsigned long long dt_bits(double d) { unsigned long long u; memcpy(&u, &d
 #define DT_COUNT_ITER() ((void)0)   // host-side statistics hook (tests/tools)
 #endif
 template <typename T> struct alignas(2 * sizeof(T)) DtPair { T x, y; };
+// Sticky per-lane "suspect quotient" state: an unsigned MINIMUM accumulated once per intersection (zero = flagged): the two
+// tests of dt_isect are arithmetic zero-tests folded into one three-operand minimum per step — no compares, no mask
+// registers (a wave-wide lane mask OR-ed per step would have to be copied to vector registers on every iteration of a loop
+// the lanes leave at different times).
+typedef unsigned DT_SUSPECT_T;
+#define DT_SUSPECT_INIT 0xFFFFFFFFu
+#define DT_SUSPECT_MINE(acc) ((acc) == 0u)
+#ifdef __HIPCC__
+DT_HD unsigned dt_min3u(unsigned a, unsigned b, unsigned c) { return min(a, min(b, c)); }
+DT_HD unsigned dt_fbits(float f) { return __float_as_uint(f); }
+#else
+DT_HD unsigned dt_min3u(unsigned a, unsigned b, unsigned c) { unsigned m = a < b ? a : b; return m < c ? m : c; }
+DT_HD unsigned dt_fbits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+#endif
 
 // segment p of P over a line of `len` elements: [dt_seg_start(p), dt_seg_start(p + 1)).  p * len < 2^20 (p <= 32, len < 2^15):
 // a 32-bit division; the kernel evaluates it once per block into a table (seg[0..P]) that the routines below take.
@@ -76,83 +90,82 @@ DT_HD int dt_segments(int lanes_per_line, int len) {
 // narrowed to T like `T s = f(...)` at :161:
 //   num = ((y1 - y0) - b*(x1-x0)) + a*(x1^2 - x0^2)      (same fp64 operations, same order)
 //   s   = (T)(num / den),  den = (2a)*(x1-x0)
-// EXACT = false (float only): the fp64 division is replaced by ONE multiplication on the dependent chain,
-// q1 = RN(num * r) with r = RN(i2a * RDX[dx]), i2a = RN(1/(2a)) (per map, computed once on the host) and
-// RDX[dx] = RN(1/dx) (a table shared by every line of a block, whatever its map): den = (2a)*dx is exact (a
-// comes from a float, dx < 2^15), so r = (1/den)(1+e1)(1+e2)(1+e3) and q1 = (num/den)(1+e1)..(1+e4), |ei| <= 2^-53:
-// |q1 - num/den| <= 4.01 * 2^-53 * |num/den| <= 4.01 ulp(q1), hence q1 and RN(num/den) are doubles at most
-// 4 ulp apart, and (float)q1 can differ from (float)RN(num/den) only if a float rounding boundary (a double
-// whose low 29 mantissa bits are 0x10000000) lies within 4 ulp of q1 — low 29 bits in 0x0FFFFFFA..0x10000006
-// (+-6) are flagged — or the value leaves the normal float range.  A flagged line is redone with EXACT = true
-// (IEEE division), so the result is always bit-identical to the reference's.
+// EXACT = false (float only): the fp64 division is replaced by TWO multiplications,
+//   q1 = RN(RN(num * i2a) * rdx),  i2a = RN(1/(2a)) (per map, an IEEE division on the host),  rdx = RN(1/dx) (a table shared by
+// every line of a block, whatever its map).  den = (2a)*dx is exact (a comes from a float, dx < 2^15), so
+// q1 = (num/den)(1+e1)(1+e2)(1+e3)(1+e4), |ei| <= 2^-53 (the roundings of i2a, of rdx and of the two products; no
+// intermediate under- or overflows unless the result itself leaves the float range): |q1 - num/den| < 4.01 ulp(q1), hence q1
+// and RN(num/den) are doubles at most 5 ulp apart, and (float)q1 can differ from (float)RN(num/den) only if a float
+// rounding boundary — a double whose low 29 mantissa bits are 0x10000000 — lies between them or on one of them.  The test
+// flags every q1 whose low 29 bits lie in [0x0FFFFFF8, 0x10000007] (a boundary within 8 ulp; a power of two next to q1 halves
+// the ulp on one side, still inside the window), and every result outside [2^-124, 2^128) in magnitude (the 29-bit spacing
+// holds only where (float)q1 is a normal float; the smallest normal binade is left out with a margin, so a q1 just below
+// the normal range that rounds up into it is flagged too).  A flagged line is redone with EXACT = true (IEEE division), so
+// the result is always bit-identical to the reference's.
 template <bool EXACT, typename T>
-DT_HD T dt_isect(double yk, int vk, double yq, int q, double a, double b, double twoa, double r, unsigned& suspect) {
+DT_HD T dt_isect(T yk, int vk, T yq, int q, double a, double b, double twoa, double i2a, double rdx, DT_SUSPECT_T& suspect) {
   const int dx = q - vk;
   const double dxd = (double)dx;
-  const double num = ((yq - yk) - b * dxd) + a * (double)DT_MUL24(dx, q + vk);   // x1^2 - x0^2 < 2^31, operands < 2^16
-  const double den = twoa * dxd;
-  double q1;
+  const double num = (((double)yq - (double)yk) - b * dxd) + a * (double)DT_MUL24(dx, q + vk);   // x1^2 - x0^2 < 2^31, operands < 2^16
   if (EXACT) {
-    q1 = num / den;
+    return (T)(num / (twoa * dxd));
   } else {
-    q1 = num * r;
-    const unsigned long long bits = dt_bits(q1);
-    const unsigned lo29 = (unsigned)bits & 0x1FFFFFFFu;
-    const unsigned ex = (unsigned)(bits >> 52) & 0x7FFu;
-    suspect = (((lo29 - 0x0FFFFFFAu) <= 12u) | ((ex - 897u) > 252u)) ? 1u : suspect;
+    const double q1 = (num * i2a) * rdx;
+    const float s = (float)q1;
+    // window: ((lo29 ^ 0x10000000) + 8) mod 2^29 < 16  <=>  lo29 in [0x0FFFFFF8, 0x10000007];  range: exponent field of s in
+    // {255, 0, 1, 2} (inf / NaN, zero / denormal, |s| < 2^-124: over-covers [2^-125, 2^-124), harmless)  <=>  ((field + 1) & 0xFC) == 0
+    const unsigned t = (((unsigned)dt_bits(q1) ^ 0x10000000u) + 8u) & 0x1FFFFFF0u;
+    const unsigned r = (dt_fbits(s) + 0x00800000u) & 0x7E000000u;
+    suspect = dt_min3u(suspect, t, r);
+    return (T)s;
   }
-  return (T)q1;
 }
 
 // Local scan of elements [s0, s1) (:156-170 with an empty initial stack).  The reference's nested loops
 // (for q { while (pop) }) are flattened into a state machine doing exactly one intersection per iteration, so the
 // lanes of a wavefront never wait for the slowest lane's pop count and every line sees the reference's sequence
-// of intersections / `s <= z[k]` tests in order.  Branch-free body: the stack top and the entry below it live in
-// registers; the entry two below (addressed through the top's "below of below" kept in a register), the
-// reciprocal a pop would need and the next line element are loaded at the top of an iteration and consumed at
-// its end; the z store goes unconditionally to q's own slot (dead when the step pops).
+// of intersections / `s <= z[k]` tests in order.  Branch-free body; the state is the stack top (element, y, z), the
+// ELEMENT below it, and the element being inserted: what a pop needs of the entry below the top — its (y, z) and its
+// own link — is read from LDS at the top of the iteration (the address is known then), together with the reciprocal
+// 1/(q - top) and the next line element, and consumed at its end.  The z store goes unconditionally to q's own slot
+// (dead when the step pops: q is inserted again).  VALU issue is what bounds the kernel in batches (SQ counters:
+// every issue slot of the SIMDs is taken while a pass runs), so the loop carries the fewest selects that do the job.
 // RDX[dx] = RN(1 / dx), i2a = RN(1 / (2a)) (EXACT = false only).  Returns the sticky "suspect" flag.
 template <bool EXACT, typename T, typename IT>
 DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a,
                        int s0, int s1, double a, double b) {
   const double twoa = 2 * a;
   YZ[s0].y = (T)-INFINITY;                  // z[0] = -inf (:158): the bottom of a stack is never popped (`k > 0`, :162)
-  B[s0] = (IT)s0;
+  B[s0] = (IT)s0;                           // ... and links to itself
   if (s1 - s0 < 2) return false;
-  const double r1 = EXACT ? 0.0 : i2a * RDX[1];
-  int vk = s0, nv = s0, nb = s0;            // top, the entry below it, the entry below that (element indices)
-  T zk = (T)-INFINITY, nz = (T)-INFINITY;
-  T yk = YZ[s0].x, ny = yk;                 // kept in T: one select each per step (the widening to double is exact and free of state)
-  double r_top = r1;
+  int vk = s0, nv = s0;                     // top of the stack, the entry below it (element indices)
+  T zk = (T)-INFINITY;
+  T yk = YZ[s0].x;
   int q = s0 + 1;
-  T yq_f = YZ[q].x;
-  unsigned suspect = 0;
+  T yq = YZ[q].x;
+  DT_SUSPECT_T suspect = DT_SUSPECT_INIT;
   while (q < s1) {
-    // prefetches (addresses known now, values used after the arithmetic below)
-    const DtPair<T> pyz = YZ[nb];
-    const int pb = (int)B[nb];
-    const double r_nxt = EXACT ? 0.0 : i2a * RDX[q - nv];  // reciprocal for the entry below the top (used if this step pops)
-    const T ynext_f = YZ[q + 1].x;          // q + 1 == s1 <= len: the slot exists (the stride is >= len + 1) and the value is never used
-    const T s = dt_isect<EXACT, T>((double)yk, vk, (double)yq_f, q, a, b, twoa, r_top, suspect);
+    // everything this step may need from LDS (addresses known now, values used after the arithmetic below)
+    const DtPair<T> below = YZ[nv];
+    const int below_link = (int)B[nv];
+    const double rdx = EXACT ? 0.0 : RDX[q - vk];
+    const T ynext = YZ[q + 1].x;            // q + 1 == s1 <= len: the slot exists (the stride is >= len + 1) and the value is never used
+    const T s = dt_isect<EXACT, T>(yk, vk, yq, q, a, b, twoa, i2a, rdx, suspect);
     // :162.  EXACT = false: the bottom's z is -inf, so only s = -inf could pop it — an out-of-range quotient, which
     // dt_isect flags (the line is redone with EXACT = true): no `k > 0` test on this path
     const bool pop = EXACT ? ((s <= zk) && (vk != s0)) : (s <= zk);
     // push: B[q] = top (:166-169).  pop: the popped top's slot is dead from now on and records its popper.
     B[pop ? vk : q] = (IT)(pop ? q : vk);
-    YZ[q].y = s;                                         // dead if this step pops
-    const int vk_o = vk; const T yk_o = yk; const T zk_o = zk; const int nv_o = nv;
+    YZ[q].y = s;                            // dead if this step pops
+    const int vk_o = vk;
     vk = pop ? nv : q;
-    yk = pop ? ny : yq_f;
-    zk = pop ? nz : s;
-    r_top = pop ? r_nxt : r1;
-    nv = pop ? nb : vk_o;
-    ny = pop ? pyz.x : yk_o;
-    nz = pop ? pyz.y : zk_o;
-    nb = pop ? pb : nv_o;
-    yq_f = pop ? yq_f : ynext_f;
+    nv = pop ? below_link : vk_o;
+    yk = pop ? below.x : yq;
+    zk = pop ? below.y : s;
+    yq = pop ? yq : ynext;
     q = pop ? q : q + 1;
   }
-  return suspect != 0;
+  return DT_SUSPECT_MINE(suspect);
 }
 
 // Stitch ONE boundary: replay what the global run does when it reaches segment [s0, s1) with the stack left by
@@ -172,18 +185,21 @@ template <bool EXACT, typename T, typename IT>
 DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a,
                       int s0, int s1, double a, double b, int& f_out, int& dmin_out, T& zsave, int& bsave) {
   const double twoa = 2 * a;
-  unsigned suspect = 0;
+  DT_SUSPECT_T suspect = DT_SUSPECT_INIT;
   bool bad = false;
   int q = s0;                                // the global run reaches the segment's first element: top of the stack = s0 - 1
   int e = s0 - 1;
   bool testf = false;                        // false: popping below the segment for q; true: e == F, q is the next element whose local scan reached F
-  int f = s0, fb = 0, dmin = s0;
+  int f = s0, fb = 0, dmin = s0, bf = 0;     // bf: F's LOCAL link / popper (B[f] as the local scan left it: nothing rewrites it before the patch below)
   T zf = (T)0;
-  for (;;) {
+  // One step per iteration, branch-free but for the skip of the intersection: the lanes of a wavefront are different
+  // stitches in different states, and a divergent branch costs every lane both sides.
+  bool done;
+  do {
     DT_COUNT_ITER();
     const DtPair<T> ez = YZ[e];
     const DtPair<T> qz = YZ[q];
-    const int eb = (int)B[e], bq = (int)B[q], bf = (int)B[f];
+    const int eb = (int)B[e], bq = (int)B[q];
     // An event whose local scan STOPPED at F (q sits on F locally: F's popper link does not name q) needs no
     // arithmetic: the intersection the global run tests, s(F, q), is the z the local scan stored for q.  Most
     // steps of a stitch are of this kind, and the lanes of a wavefront reach them together (each stitch starts
@@ -192,37 +208,36 @@ DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const doub
     const bool cheap = testf && bf != q;
     T s = qz.y;
     if (DT_ANY(!cheap)) {
-      const double r = EXACT ? 0.0 : i2a * RDX[q - e];
-      const T si = dt_isect<EXACT, T>((double)ez.x, e, (double)qz.x, q, a, b, twoa, r, suspect);
+      const double rdx = EXACT ? 0.0 : RDX[q - e];
+      const T si = dt_isect<EXACT, T>(ez.x, e, qz.x, q, a, b, twoa, i2a, rdx, suspect);   // (a lane that does not need it may flag itself: harmless)
       s = cheap ? s : si;
     }
-    if (!testf) dmin = e < dmin ? e : dmin;
+    dmin = (!testf && e < dmin) ? e : dmin;
     const bool pass = (s <= (testf ? zf : ez.y)) && (e != 0);      // :162; only the bottom of the whole stack is protected
-    if (pass) {
-      e = testf ? fb : eb;                   // F popped: continue below it; otherwise one more pop below the segment
-      testf = false;
-      continue;
-    }
-    int nq;
-    if (!testf) {                            // q is pushed on e: the new F, top of the segment's part of the stack
-      f = q; zf = s; fb = e;
-      nq = q + 1;                            // F is the top: the next element tests it
-    } else {                                 // F survives q
-      if (!cheap) bad = true;                // ... although the local scan popped it (bf == q): invariant lost
-      nq = bq > q ? bq : s1;                 // q popped locally: its popper is the next element to reach F; else none
-    }
-    if (nq >= s1) break;
-    q = nq;
-    e = f;
-    testf = true;
-  }
+    // pass: F popped (continue below it) or one more pop below the segment; q unchanged, explicit tests from now on.
+    // fail, !testf: q is pushed on e: the new F, top of the segment's part of the stack; the next element tests it.
+    // fail, testf: F survives q — if the local scan popped it (bf == q: not cheap) the invariant is lost —; q's popper is
+    //              the next element to reach F (else none).
+    const bool newf = !pass && !testf;
+    bad = bad || (!pass && testf && !cheap);
+    const int e_pass = testf ? fb : eb;
+    const int nq = testf ? (bq > q ? bq : s1) : q + 1;
+    f = newf ? q : f;
+    zf = newf ? s : zf;
+    fb = newf ? e : fb;
+    bf = newf ? bq : bf;
+    done = !pass && nq >= s1;                // the segment's last event has been handled (the updates below are then unused)
+    e = pass ? e_pass : f;
+    q = pass ? q : nq;
+    testf = !pass;
+  } while (!done);
   zsave = YZ[f].y;
-  bsave = (int)B[f];
+  bsave = bf;
   YZ[f].y = zf;
   B[f] = (IT)fb;
   f_out = f;
   dmin_out = dmin;
-  return bad || suspect != 0;
+  return bad || DT_SUSPECT_MINE(suspect);
 }
 
 // Validation of the speculative stitches of one line, left to right (one lane per line).  The only elements whose

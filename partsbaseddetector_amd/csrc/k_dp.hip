@@ -94,8 +94,8 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // branch costs one full scalar-memory round trip per branch, which is what made a first version's loader 5x slower
 // than the plain one.  Everything below is branch-free except the loop over the children.
 template <typename T, int M, int U>
-__device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ /*biasw*/, const size_t (&off)[U],
-                                              size_t HW, int L, const bool (&valid)[U], T (&acc)[U][M]) {
+__device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ /*biasw*/, const unsigned (&off)[U],
+                                              unsigned HW, int L, const bool (&valid)[U], T (&acc)[U][M]) {
   const int nch = J->nch;
   for (int c = 0; c < nch; ++c) {
     const FoldChild& C = J->ch[c];
@@ -109,7 +109,7 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
     for (int k = 0; k < M; ++k) {
       GP(T) pl = (GP(T))C.sdt[k];                      // entries beyond K repeat plane K - 1 (plan): never predicated
 #pragma unroll
-      for (int u = 0; u < U; ++u) sd[u][k] = pl[off[u]];
+      for (int u = 0; u < U; ++u) sd[u][k] = pl[off[u]];   // (uniform base + 32-bit cell offset: no 64-bit vector arithmetic per load)
     }
     float bias[M][M];
 #pragma unroll
@@ -141,7 +141,7 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         if (m < L) {
-          if (valid[u]) okp[(size_t)m * HW + off[u]] = (uint8_t)bi[m];   // Ik (:150)
+          if (valid[u]) (okp + (size_t)m * HW)[off[u]] = (uint8_t)bi[m];   // Ik (:150); plane base uniform
           acc[u][m] = acc[u][m] + v[m];                                                  // parent.score += maxv (:156), child order kept
         }
       }
@@ -203,22 +203,27 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     constexpr int U = sizeof(T) == 8 ? 1 : 3;
     const FoldJob* J = folds + g.fold;
     const int L = g.nmaps;
-    const size_t HW = (size_t)g.nlines * len;
+    const unsigned HW = (unsigned)g.nlines * (unsigned)len;     // cells of the level (< 2^31, plan_frame)
     const void* srcp[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) srcp[m] = maps[g.map0 + (m < L ? m : L - 1)].src;   // the part's raw response planes
     const int n = nrows * len;
+    // the block's cells are rows t.g0 .. t.g0 + nrows - 1 of the level: CONTIGUOUS in every plane, cell ec of the block at
+    // plane offset t.g0 * len + ec (no division for the loads); its (row, column) — the LDS slot — by multiply-high
+    const unsigned cell0 = (unsigned)t.g0 * (unsigned)len;
+    const unsigned magic = len > 1 ? (0xFFFFFFFFu / (unsigned)len + 1u) : 0u;   // ec / len = umulhi(ec, magic), exact for ec * len < 2^32 (len = 1: ec itself)
     for (int e0 = 0; e0 < n; e0 += NT * U) {
       T acc[U][M];
-      size_t off[U];
-      int jj[U], qq[U];
+      unsigned off[U];
+      int slot[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int ec = min(e0 + u * NT + lane, n - 1);
-        jj[u] = (int)((unsigned)ec / (unsigned)len); qq[u] = ec - jj[u] * len;
-        off[u] = (size_t)(t.g0 + jj[u]) * len + qq[u];
+        off[u] = cell0 + (unsigned)ec;
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[u][m] = ((GP(T))srcp[m])[off[u]];
+        const int jj = len > 1 ? (int)__umulhi((unsigned)ec, magic) : ec;
+        slot[u] = __mul24(jj, S) + (ec - __mul24(jj, len));        // LDS element of mixture 0's line of that row
       }
       // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
       if constexpr (!EX) {
@@ -229,12 +234,13 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 #pragma unroll
       for (int u = 0; u < U; ++u) valid[u] = e0 + u * NT + lane < n;
       fold_children<T, M, U>(J, biasw, off, HW, L, valid, acc);
+      const int mstride = nrows * S;                                 // LDS elements between the lines of consecutive mixtures of a row
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (valid[u]) {
 #pragma unroll
           for (int m = 0; m < M; ++m)
-            if (m < L) YZ[(m * nrows + jj[u]) * S + qq[u]].x = acc[u][m];
+            if (m < L) YZ[m * mstride + slot[u]].x = acc[u][m];
         }
       }
     }
@@ -243,32 +249,38 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     // map are contiguous in memory, so the loads stay coalesced across line ends and short lines — 100+ lines of
     // 6-20 elements on the small levels — fill the lanes like long ones).  Batches of LB independent loads are
     // issued before the first wait (addresses are clamped instead of predicated: a predicated load makes hipcc
-    // branch and wait per element, which serialises one full memory round trip per 256 B).
+    // branch and wait per element, which serialises one full memory round trip per 256 B).  The kernel is bound by
+    // vector-instruction issue, so an element's (line, position) is worked out ONCE — its LDS address waits in a register
+    // for the value (the kernel's occupancy is set by LDS, not by registers) — and the division is a multiply-high.
     const int n = nl * len;
-    // f / len = umulhi(f, magic), magic = ceil(2^32 / len): exact for f * len < 2^32 (len = 1: the quotient is f itself)
-    const unsigned magic = len > 1 ? (0xFFFFFFFFu / (unsigned)len + 1u) : 0u;
     constexpr int LB = sizeof(T) == 8 ? 12 : 24;   // loads in flight per lane (a 25 KB block of float lines: <= 22 elements per lane)
-    for (int f0 = 0; f0 < n; f0 += LB * NT) {
-      T r[LB];
+    if (len > 1) {
+      // f / len = umulhi(f, magic), magic = ceil(2^32 / len): exact for f * len < 2^32
+      const unsigned magic = 0xFFFFFFFFu / (unsigned)len + 1u;
+      for (int f0 = 0; f0 < n; f0 += LB * NT) {
+        T r[LB];
+        int la[LB];
 #pragma unroll
-      for (int j = 0; j < LB; ++j) {
-        const int f = min(f0 + j * NT + lane, n - 1);
-        const int i = len > 1 ? (int)__umulhi((unsigned)f, magic) : f;
-        r[j] = ((GP(T))lptr[i])[f - i * len];
-      }
-      // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
-      if constexpr (!EX) {
-        if (f0 == 0)
-          for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
-      }
-      // (unpredicated: a lane past the block's last element holds that element's value again — its load address was
-      // clamped — and stores it once more; a predicate per element made hipcc emit 24 nested exec-mask regions)
+        for (int j = 0; j < LB; ++j) {
+          const int f = min(f0 + j * NT + lane, n - 1);
+          const int i = (int)__umulhi((unsigned)f, magic);
+          const unsigned pos = (unsigned)(f - __mul24(i, len));
+          r[j] = ((GP(T))lptr[i])[pos];
+          la[j] = __mul24(i, S) + (int)pos;
+        }
+        // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
+        if constexpr (!EX) {
+          if (f0 == 0)
+            for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
+        }
+        // (unpredicated: a lane past the block's last element holds that element's value again — its load address was
+        // clamped — and stores it once more; a predicate per element made hipcc emit 24 nested exec-mask regions)
 #pragma unroll
-      for (int j = 0; j < LB; ++j) {
-        const int fc = min(f0 + j * NT + lane, n - 1);
-        const int i = len > 1 ? (int)__umulhi((unsigned)fc, magic) : fc;
-        YZ[i * S + (fc - i * len)].x = r[j];
+        for (int j = 0; j < LB; ++j) YZ[la[j]].x = r[j];
       }
+    } else {   // lines of ONE element (a 1-wide level, or pbd_dt2d on a vector): element f is line f
+      for (int f = lane; f < n; f += NT) YZ[f * S].x = ((GP(T))lptr[f])[0];
+      if constexpr (!EX) { if (lane == 0) RDX[0] = 0.0; }
     }
   }
   __syncthreads();
@@ -544,12 +556,12 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
     // fold mode: the root's accumulated score is built here from its raw responses and its children's messages
     constexpr int M = PBD_FOLD_MAXMIX;
     T acc[1][M];
-    const size_t offs[1] = {cell};
+    const unsigned offs[1] = {cell};
     const bool valids[1] = {true};
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[0][m] = ((GP(T))J.score[m < J.K ? m : J.K - 1])[cell];
     // (acc is [1][M]: one cell per lane)
-    fold_children<T, M, 1>(folds + J.fold, biasw, offs, (size_t)J.H * J.W, J.K, valids, acc);
+    fold_children<T, M, 1>(folds + J.fold, biasw, offs, (unsigned)J.H * (unsigned)J.W, J.K, valids, acc);
     if (J.K == 1) {
       v = acc[0][0] + bias;
     } else {
