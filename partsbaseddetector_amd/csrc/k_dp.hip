@@ -93,57 +93,96 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // block of the child (wave-uniform: scalar loads) is fetched in one straight-line batch — a load inside a (uniform)
 // branch costs one full scalar-memory round trip per branch, which is what made a first version's loader 5x slower
 // than the plain one.  Everything below is branch-free except the loop over the children.
+typedef float fold_f32x4 __attribute__((ext_vector_type(4)));
 template <typename T, int M, int U>
 __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ /*biasw*/, const unsigned (&off)[U],
-                                              unsigned HW, int L, const bool (&valid)[U], T (&acc)[U][M]) {
+                                              unsigned HW, int L, T (&acc)[U][M]) {
   const int nch = J->nch;
+  // a vector register that holds 0, opaque to the compiler: added to the (wave-uniform) address of the bias block it turns
+  // the fetch into VECTOR loads.  As scalar loads the K x L block (36 values for 6 x 6 mixtures) + the plane pointers
+  // overflow the scalar register file: the compiler spilled them to vector-register lanes and read them back with one
+  // v_readlane each (46 per child and cell batch) — vector-instruction slots, which is what this kernel is short of.
+  unsigned vzero = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+#endif
+  unsigned ob[U];                                        // byte offsets of the cells inside a plane of T (< 2^32, plan_frame)
+#pragma unroll
+  for (int u = 0; u < U; ++u) ob[u] = off[u] * (unsigned)sizeof(T);
   for (int c = 0; c < nch; ++c) {
     const FoldChild& C = J->ch[c];
     // everything the child contributes is fetched up front, in straight-line code: the K planes' values of the U
-    // cells (vector loads), the plane pointers, the Ik plane and the dense K x L bias block (wave-uniform: wide
-    // scalar loads, one wait)
-    const int K = C.K;
+    // cells (uniform base + 32-bit byte offset: no vector arithmetic per load) and the dense K x L bias block
     GPW(uint8_t) okp = (GPW(uint8_t))C.ok;
     T sd[U][M];
 #pragma unroll
     for (int k = 0; k < M; ++k) {
-      GP(T) pl = (GP(T))C.sdt[k];                      // entries beyond K repeat plane K - 1 (plan): never predicated
+      GP(char) pl = (GP(char))C.sdt[k];                  // entries beyond K repeat plane K - 1 (plan): never predicated
 #pragma unroll
-      for (int u = 0; u < U; ++u) sd[u][k] = pl[off[u]];   // (uniform base + 32-bit cell offset: no 64-bit vector arithmetic per load)
+      for (int u = 0; u < U; ++u) sd[u][k] = *(GP(T))(pl + ob[u]);
     }
     float bias[M][M];
+    {
+      GP(char) bp = (GP(char))&C.bias[0][0] + vzero;
 #pragma unroll
-    for (int k = 0; k < M; ++k)
+      for (int k = 0; k < M; ++k) {
+        if constexpr (M > 4) {
+          const fold_f32x4 lo = *(GP(fold_f32x4))(bp + k * PBD_FOLD_MAXMIX * 4), hi = *(GP(fold_f32x4))(bp + k * PBD_FOLD_MAXMIX * 4 + 16);
+          const float r[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-      for (int m = 0; m < M; ++m) bias[k][m] = C.bias[k][m];
+          for (int m = 0; m < M; ++m) bias[k][m] = r[m];
+        } else {
+          const fold_f32x4 lo = *(GP(fold_f32x4))(bp + k * PBD_FOLD_MAXMIX * 4);
+          const float r[4] = {lo[0], lo[1], lo[2], lo[3]};
+#pragma unroll
+          for (int m = 0; m < M; ++m) bias[k][m] = r[m];
+        }
+      }
+    }
+    unsigned okoff[M];                                   // offset of plane m of the child's Ik planes (uniform).  Columns beyond L repeat column
+#pragma unroll                                           // L - 1 (plan) and land on plane L - 1 again: the same byte stored twice, no predicate
+    for (int m = 0; m < M; ++m) okoff[m] = (unsigned)min(m, L - 1) * HW;
+    if (C.K == 1) {
+      // Math::reduceMax's K == 1 shortcut copies (Math.hpp:154-158): maxv = the one weighted map, maxi = 0 (a wave-uniform branch)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          *(okp + (okoff[m] + off[u])) = (uint8_t)0;                                     // Ik (:150)
+          acc[u][m] = acc[u][m] + (sd[u][0] + bias[0][m]);                               // DynamicProgram.cpp:139, :156
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       T v[M];
       int bi[M];
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        // k = 0 first: Math::reduceMax starts from -inf and takes strict > (first maximum wins); its K == 1 shortcut
-        // copies (Math.hpp:154-158), which differs from the loop only for a NaN / -inf score: keep the copy
+        // k = 0 first: Math::reduceMax starts from -inf and takes strict > (first maximum wins): a NaN score leaves -inf
         const T w0 = sd[u][0] + bias[0][m];               // DynamicProgram.cpp:139
-        v[m] = (K == 1 || w0 > (T)-INFINITY) ? w0 : (T)-INFINITY;
+        v[m] = w0 > (T)-INFINITY ? w0 : (T)-INFINITY;
         bi[m] = 0;
       }
 #pragma unroll
       for (int k = 1; k < M; ++k) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
+          // (no `k < K` test: planes / bias rows beyond K repeat mixture K - 1, whose value cannot be strictly greater than the
+          // maximum it has already been folded into)
           const T wv = sd[u][k] + bias[k][m];
-          const bool take = (k < K) && (wv > v[m]);     // strict >: first max wins
+          const bool take = wv > v[m];                  // strict >: first max wins
           bi[m] = take ? k : bi[m];
           v[m] = take ? wv : v[m];
         }
       }
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        if (m < L) {
-          if (valid[u]) (okp + (size_t)m * HW)[off[u]] = (uint8_t)bi[m];   // Ik (:150); plane base uniform
-          acc[u][m] = acc[u][m] + v[m];                                                  // parent.score += maxv (:156), child order kept
-        }
+        // Ik (:150).  Unpredicated: a lane past the block's last cell works on that cell again (its offset was clamped) and
+        // stores the same byte once more
+        *(okp + (okoff[m] + off[u])) = (uint8_t)bi[m];                 // (cells * planes < 2^32, plan_frame)
+        acc[u][m] = acc[u][m] + v[m];                                  // parent.score += maxv (:156), child order kept
       }
     }
   }
@@ -180,19 +219,26 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   const int nrows = FOLD ? nl / g.nmaps : 0;   // FOLD: rows of this block
   P2* YZ = (P2*)(RDX + ((S + 1) & ~1));        // [lpb][S] (16-byte aligned) .x: line values (never modified); .y: z of the element when pushed
   IT* B = (IT*)(YZ + lpb * S);                 // [lpb][S] element below on the stack when pushed; later: element above (read-out)
+  // line i of a plain block = line (t.l0 + i) mod nlines of map t.m0 + (t.l0 + i) / nlines; the quotients by wave-uniform numbers
+  // come as multiply-high constants from the plan (DtGroup)
+  auto map_line = [&](int i, int& mi, int& li) {
+    const int x = t.l0 + i;
+    const int q = g.nlines > 1 ? (int)__umulhi((unsigned)x, g.magic_nlines) : x;
+    mi = t.m0 + q; li = x - __mul24(q, g.nlines);
+  };
   if (lane < nl) {
     if (!FOLD) {
-      const int gi = t.g0 + lane;
-      const int mi = gi / g.nlines, li = gi - mi * g.nlines;
+      int mi, li;
+      map_line(lane, mi, li);
       const DtMap& mp0 = maps[g.map0 + mi];
       lptr[lane] = (const T*)mp0.src + (size_t)li * len;
     }
     FLAG[lane] = 0;
     FIX[lane] = 0;
   }
-  const int nsub = NT / lpb;                     // lanes per line
-  const int P = dt_segments(nsub, len);          // segments per line
-  if (lane <= P) SEG[lane] = dt_seg_start(lane, P, len);
+  const int nsub = g.nsub;                       // lanes per line
+  const int P = g.P;                             // segments per line (dt_segments(nsub, len))
+  if (lane <= P) SEG[lane] = P > 1 ? (int)__umulhi((unsigned)__mul24(lane, len), g.magic_P) : lane * len;   // dt_seg_start(lane, P, len)
   if (lane == 0) { SEG[DT_SEGS - 2] = 0; SEG[DT_SEGS - 1] = len; }
   if (!FOLD) __syncthreads();
   DT_STAMP(1);
@@ -220,8 +266,9 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       for (int u = 0; u < U; ++u) {
         const int ec = min(e0 + u * NT + lane, n - 1);
         off[u] = cell0 + (unsigned)ec;
+        const unsigned obu = off[u] * (unsigned)sizeof(T);             // byte offset inside a plane (< 2^32, plan_frame): uniform base + 32-bit offset
 #pragma unroll
-        for (int m = 0; m < M; ++m) acc[u][m] = ((GP(T))srcp[m])[off[u]];
+        for (int m = 0; m < M; ++m) acc[u][m] = *(GP(T))((GP(char))srcp[m] + obu);
         const int jj = len > 1 ? (int)__umulhi((unsigned)ec, magic) : ec;
         slot[u] = __mul24(jj, S) + (ec - __mul24(jj, len));        // LDS element of mixture 0's line of that row
       }
@@ -230,18 +277,14 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         if (e0 == 0)
           for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
-      bool valid[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) valid[u] = e0 + u * NT + lane < n;
-      fold_children<T, M, U>(J, biasw, off, HW, L, valid, acc);
+      fold_children<T, M, U>(J, biasw, off, HW, L, acc);
       const int mstride = nrows * S;                                 // LDS elements between the lines of consecutive mixtures of a row
+      // (unpredicated like the plain loader: a lane past the last cell holds the last cell's values and stores them once more)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (valid[u]) {
 #pragma unroll
-          for (int m = 0; m < M; ++m)
-            if (m < L) YZ[m * mstride + slot[u]].x = acc[u][m];
-        }
+        for (int m = 0; m < M; ++m)
+          if (m < L) YZ[m * mstride + slot[u]].x = acc[u][m];
       }
     }
   } else {
@@ -286,13 +329,18 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   __syncthreads();
   DT_STAMP(2);
 
-  const int line = lane % lpb, p = lane / lpb;
+  const int p = lpb > 1 ? (int)__umulhi((unsigned)lane, g.magic_lpb) : lane, line = lane - __mul24(p, lpb);
   const bool mine = line < nl && p < nsub;
   // line -> (map, line of the map): plain: map-major; FOLD: mixture-major inside the block's rows
   int mi = 0, li = 0;
   if (mine) {
-    if (FOLD) { mi = line / nrows; li = t.g0 + (line - mi * nrows); }
-    else { const int gi = t.g0 + line; mi = gi / g.nlines; li = gi - mi * g.nlines; }
+    if (FOLD) {
+      const unsigned mrows = nrows > 1 ? (0xFFFFFFFFu / (unsigned)nrows + 1u) : 0u;   // (wave-uniform: scalar arithmetic)
+      mi = nrows > 1 ? (int)__umulhi((unsigned)line, mrows) : line;
+      li = t.g0 + (line - __mul24(mi, nrows));
+    } else {
+      map_line(line, mi, li);
+    }
   }
   DtMap mp;
   P2* YZl = YZ + line * S;
@@ -359,7 +407,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const bool nat = mp.ptr_natural != 0;
     int16_t* pp = mp.ptr + (nat ? (size_t)li * len : (size_t)li);
     const int pst = nat ? 1 : g.nlines;
-    const int chunk = (len + nsub - 1) / nsub;
+    const int chunk = g.chunk;                   // ceil(len / nsub)
     const int q0 = p * chunk, q1 = min(len, q0 + chunk);
     if (q0 < q1) {
       int os = mp.os + q1 - 1;
@@ -557,11 +605,10 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
     constexpr int M = PBD_FOLD_MAXMIX;
     T acc[1][M];
     const unsigned offs[1] = {cell};
-    const bool valids[1] = {true};
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[0][m] = ((GP(T))J.score[m < J.K ? m : J.K - 1])[cell];
     // (acc is [1][M]: one cell per lane)
-    fold_children<T, M, 1>(folds + J.fold, biasw, offs, (unsigned)J.H * (unsigned)J.W, J.K, valids, acc);
+    fold_children<T, M, 1>(folds + J.fold, biasw, offs, (unsigned)J.H * (unsigned)J.W, J.K, acc);
     if (J.K == 1) {
       v = acc[0][0] + bias;
     } else {

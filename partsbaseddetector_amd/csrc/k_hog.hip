@@ -5,18 +5,21 @@
 //
 // Bit-exactness plan (compiled with -ffp-contract=off):
 //  * the reference SCATTERS each pixel into <=4 block histograms in raster
-//    order (:262-265); every histogram bin is an independent float
-//    accumulator, so a GATHER in which one thread owns one (block, orientation)
-//    bin and adds its contributing pixels in the same raster order produces
-//    the same bits, with no atomics;
-//  * weights are (wy*wx)*|g| exactly as (:262-265) evaluate them (float
-//    products commute);
+//    order (:262-265); every histogram bin is an independent accumulator of type T,
+//    so a GATHER in which one thread owns one block's bins and adds its contributing
+//    pixels in the same raster order produces the same bits, with no atomics;
+//  * weights are (wy*wx)*|g| exactly as (:262-265) evaluate them (products of T
+//    commute);
+//  * the orientation snap (:243-249) is a pure function of the winning channel's integer
+//    differences (dx, dy) in [-255, 255]^2: it is TABULATED once per handle by k_hog_binlut,
+//    which runs the reference's own chain of T multiply-adds and comparisons for all 511 x 511
+//    pairs (one table per T: the dot products are evaluated in T), and looked up per pixel;
 //  * the four normalisers are evaluated in double like the reference's
 //    `1.0f / sqrt(float_sum + eps)` (:293-299), texture gains in double (:331).
-// HBM-bound and small (25 MB algorithmic per 640x480 frame): pixels are read
-// through L2 (each level image is a few hundred KB), per-pixel (|g|, bin) and
-// the tile's histograms live in LDS, the output is written cell-major with 32
-// consecutive lanes covering one cell's 128 B.
+// The chip-wide bound of this kernel is vector-instruction issue (SQ counters: 25 M wave-instructions per 640x480
+// frame before round 4, 60 % of the issue slots of its run time), so the phases are organised around instruction count:
+// wide staging loads, the tabulated snap, one thread per BLOCK for the histograms and one thread per CELL for the 32
+// features (the 18 contrast-sensitive features, the texture sums and the normalisers are shared work inside a cell).
 #include "pbd_internal.hpp"
 
 // debug: per-phase wall-clock stamps (100 MHz) of block 0 of the last k_hog launch
@@ -29,13 +32,46 @@ void hog_debug_read(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMB
 void hog_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i] = 0; }
 #endif
 
+// ---- orientation snap table ------------------------------------------------------------------------------------
+// lut[(dy + 255) * 511 + (dx + 255)] = best_o of src/HOGFeatures.cpp:243-249 for the gradient (dx, dy), evaluated in T
+#define HOG_LUT_SIDE 511
+template <typename T>
+__device__ __forceinline__ int hog_snap(T dx, T dy) {
+  const T uu[9] = {1.000, 0.9397, 0.7660, 0.5000, 0.1736, -0.1736, -0.5000, -0.7660, -0.9397};
+  const T vv[9] = {0.000, 0.3420, 0.6428, 0.8660, 0.9848, 0.9848, 0.8660, 0.6428, 0.3420};
+  T best_dot = 0;
+  int best_o = 0;
+#pragma unroll
+  for (int o = 0; o < 9; ++o) {
+    T dot = uu[o] * dx + vv[o] * dy;
+    if (dot > best_dot) { best_dot = dot; best_o = o; }
+    else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
+  }
+  return best_o;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_hog_binlut(uint8_t* __restrict__ lut) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HOG_LUT_SIDE * HOG_LUT_SIDE) return;
+  const int iy = i / HOG_LUT_SIDE, ix = i - iy * HOG_LUT_SIDE;
+  lut[i] = (uint8_t)hog_snap<T>((T)(ix - 255), (T)(iy - 255));
+}
+size_t hog_binlut_bytes() { return (size_t)HOG_LUT_SIDE * HOG_LUT_SIDE; }
+void launch_hog_binlut(uint8_t* lut, int ts, hipStream_t s) {
+  const int n = HOG_LUT_SIDE * HOG_LUT_SIDE;
+  if (ts == 8) hipLaunchKernelGGL(k_hog_binlut<double>, dim3((n + 255) / 256), dim3(256), 0, s, lut);
+  else hipLaunchKernelGGL(k_hog_binlut<float>, dim3((n + 255) / 256), dim3(256), 0, s, lut);
+}
+
 struct HogLds {
   int PT;        // pixel window side
   int NB;        // blocks per side (TC+2)
   int P0;        // window rows / columns kept before the first pixel that contributes to the tile's first block
   int MG;        // raw-tile margin before the window (source clamping can reach back sbin/2 pixels)
-  int RT;        // raw tile side
-  size_t mag_off, bin_off, hist_off, norm_off, ninv_off, tab_off, raw_off, total;
+  int RT;        // raw tile side (pixels)
+  int RP;        // raw tile row pitch in bytes (multiple of 4: rows are staged with 4-byte loads)
+  int MP;        // (|g|, bin) plane row pitch in elements (odd multiple... see hog_lds_layout)
+  size_t mag_off, bin_off, hist_off, norm_off, ninv_off, tab_off, raw_off, out_off, total;
 };
 
 __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int cn, int ts) {   // ts = sizeof(T)
@@ -43,28 +79,30 @@ __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int cn, int t
   L.NB = tc + 2;
   // A pixel y feeds the blocks floor((y + 0.5) / sbin - 0.5) and the next one (:252-255): block b receives exactly the
   // 2*sbin pixels from b*sbin - sbin/2 on when sbin is even, so NB blocks need (NB + 1) * sbin window rows.  Odd cell
-  // sizes keep one spare row on either side.  (For sbin 4 / 16-cell tiles: 76 instead of 78 rows — with the
-  // overlays below 52.8 KB of LDS per workgroup, i.e. THREE workgroups per CU: the 604 tiles of a 640x480 pyramid
-  // are then resident at once instead of in two generations.)
+  // sizes keep one spare row on either side.
   L.P0 = (sbin & 1) ? 1 : 0;
   L.PT = L.NB * sbin + sbin + 2 * L.P0;
   L.MG = sbin / 2 + 2;
   L.RT = L.PT + L.MG + 1;
+  L.RP = (L.RT * cn + 3) & ~3;
+  L.MP = L.PT;
   size_t o = 0;
-  // (|g|, bin) per window pixel are dead once the histograms are complete: the block energies and the normalisers
-  // are written over them (a barrier separates the phases)
+  // (|g|, bin) per window pixel are dead once the histograms are complete: the block energies, the normalisers and the
+  // staging area of the finished features (half a tile of cells at a time) are written over them (barriers separate the phases)
+  const size_t nn = (size_t)ts * (L.NB * L.NB + (tc + 1) * (tc + 1));
   L.mag_off = o; L.norm_off = o; L.ninv_off = o + (size_t)ts * L.NB * L.NB;
+  L.out_off = (o + nn + 15) & ~(size_t)15;
   {
-    const size_t a = (size_t)ts * L.PT * L.PT, b = (size_t)ts * (L.NB * L.NB + (tc + 1) * (tc + 1));
-    o += ((a > b ? a : b) + 7) & ~(size_t)7;
+    const size_t a = (size_t)ts * L.PT * L.MP, b = L.out_off + (size_t)ts * ((tc * tc + 1) / 2) * (PBD_FLEN + 1);
+    o += ((a > b ? a : b) + 15) & ~(size_t)15;
   }
   // the staged source pixels (raw) are dead once (|g|, bin) are computed and the histograms are not live
   // before: they share one region (one barrier more)
-  const size_t hist_bytes = (size_t)ts * L.NB * L.NB * PBD_NORIENT, raw_bytes = (size_t)L.RT * L.RT * cn;
+  const size_t hist_bytes = (size_t)ts * L.NB * L.NB * PBD_NORIENT, raw_bytes = (size_t)L.RT * L.RP;
   L.hist_off = o; L.raw_off = o;
-  o += ((hist_bytes > raw_bytes ? hist_bytes : raw_bytes) + 7) & ~(size_t)7;
+  o += ((hist_bytes > raw_bytes ? hist_bytes : raw_bytes) + 15) & ~(size_t)15;
   L.tab_off = o; o += ((size_t)ts * 2 + sizeof(int)) * 2 * L.PT;  // w0,w1,ip for y and x
-  L.bin_off = o; o += L.PT * L.PT;
+  L.bin_off = (o + 3) & ~(size_t)3; o = L.bin_off + (size_t)L.PT * L.MP;
   L.total = (o + 15) & ~(size_t)15;
   return L;
 }
@@ -75,16 +113,16 @@ size_t hog_lds_bytes(int sbin, int tc, int ts) { return hog_lds_layout(sbin, tc,
 // SBIN_T / TC_T > 0: compile-time cell size / tile side (index divisions become shifts, loops unroll);
 // 0: taken from the runtime arguments (generic fallback).
 template <typename T, int SBIN_T, int TC_T>
-__global__ __launch_bounds__(HOG_NT) void k_hog(const HogTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
+__global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
                                                 const uint8_t* __restrict__ pyr, T* __restrict__ feat, int cn,
-                                                int sbin_rt, int tc_rt) {
+                                                int sbin_rt, int tc_rt, const uint8_t* __restrict__ binlut) {
   const int sbin = SBIN_T > 0 ? SBIN_T : sbin_rt;
   const int tc = TC_T > 0 ? TC_T : tc_rt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   HOG_STAMP(0);
   const HogTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
-  const HogLds L = hog_lds_layout(sbin, tc, 3, (int)sizeof(T));
+  const HogLds L = hog_lds_layout(sbin, tc, cn, (int)sizeof(T));
   T* mag = (T*)(smem + L.mag_off);
   uint8_t* bin = (uint8_t*)(smem + L.bin_off);
   uint8_t* raw = (uint8_t*)(smem + L.raw_off);
@@ -97,31 +135,54 @@ __global__ __launch_bounds__(HOG_NT) void k_hog(const HogTile* __restrict__ tile
   T* wx1 = wx0 + L.PT;
   int* ipy = (int*)(wx1 + L.PT);
   int* ipx = ipy + L.PT;
-  const int PT = L.PT, NB = L.NB, RT = L.RT, tid = threadIdx.x;
+  const int PT = L.PT, NB = L.NB, RT = L.RT, RP = L.RP, tid = threadIdx.x;
   const int w = lv.iw, h = lv.ih, bw = lv.bw, bh = lv.bh;
   const int vw = bw * sbin, vh = bh * sbin;  // :176 visible
   const uint8_t* im = pyr + lv.img_off;
   const int stride = w * cn;
   // pixel window origin: first pixel that can touch block (cy0, cx0) (one more before it for odd cell sizes)
   const int py0 = t.cy0 * sbin - (sbin + 1) / 2 - L.P0, px0 = t.cx0 * sbin - (sbin + 1) / 2 - L.P0;
-  const int ry0 = py0 - L.MG, rx0 = px0 - L.MG;  // raw tile origin (source coordinates, clamped on load)
+  const int ry0 = py0 - L.MG, rx0 = px0 - L.MG;  // raw tile origin (source coordinates)
 
-  // ---- stage the source pixels of the window (+margins) in LDS, coalesced byte rows ----
-  const int rowb = RT * cn;
-  for (int cb = tid; cb < rowb; cb += HOG_NT) {  // one byte column per thread, 32 independent row loads in flight
-    const int xc = cb / cn, chn = cb - xc * cn;
-    const int sx = min(max(rx0 + xc, 0), w - 1);
-    const uint8_t* col = im + sx * cn + chn;
-    for (int r0 = 0; r0 < RT; r0 += 32) {
-      uint8_t rr[32];
+  // ---- stage the source pixels of the window (+margins) in LDS: row r of the raw tile = the RT * cn source bytes from
+  //      pixel (ry0 + r, rx0) on, fetched as 4-byte words wherever the word lies inside the source row (the level images
+  //      are tightly packed byte rows: no alignment to rely on, the hardware takes unaligned dword loads); the few words
+  //      that straddle the row's ends are fetched byte by byte.  Rows / bytes outside the image are never READ by the
+  //      gradient pass (it clamps to [1, w - 2] x [1, h - 2], :208,218): rows are clamped to keep the addresses valid,
+  //      bytes outside the row are left as they are. ----
+  {
+    const int wpr = RP >> 2;                          // words per raw row
+    const int nword = RT * wpr;
+    const int rowbytes = stride;                      // bytes of a source row
+    const int b00 = rx0 * cn;                         // source byte of the raw row's first byte (may be negative)
+    constexpr int LBW = 4;                            // words in flight per thread and batch
+    for (int i0 = tid; i0 < nword; i0 += HOG_NT * LBW) {
+      unsigned wv[LBW];
+      int ok[LBW], la[LBW];
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        const int sy = min(max(ry0 + min(r0 + j, RT - 1), 0), h - 1);
-        rr[j] = col[(size_t)sy * stride];
+      for (int j = 0; j < LBW; ++j) {
+        const int i = min(i0 + j * HOG_NT, nword - 1);
+        const int r = i / wpr, k = i - r * wpr;
+        const int sy = min(max(ry0 + r, 0), h - 1);
+        const int b0 = b00 + 4 * k;
+        ok[j] = (b0 >= 0 && b0 + 3 < rowbytes) ? 1 : 0;
+        const uint8_t* src = im + (size_t)sy * stride;
+        la[j] = r * RP + 4 * k;
+        if (ok[j]) {
+          wv[j] = *(const __attribute__((aligned(1))) unsigned*)(src + b0);
+        } else {
+          unsigned v = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int b = min(max(b0 + q, 0), rowbytes - 1);
+            v |= (unsigned)src[b] << (8 * q);
+          }
+          wv[j] = v;
+        }
       }
 #pragma unroll
-      for (int j = 0; j < 32; ++j)
-        if (r0 + j < RT) raw[(r0 + j) * rowb + cb] = rr[j];
+      for (int j = 0; j < LBW; ++j)
+        if (i0 + j * HOG_NT < nword) *(unsigned*)(raw + la[j]) = wv[j];
     }
   }
   // ---- interpolation tables per window row / column (:252-260) ----
@@ -140,47 +201,38 @@ __global__ __launch_bounds__(HOG_NT) void k_hog(const HogTile* __restrict__ tile
   HOG_STAMP(1);
 
   // ---- per-pixel gradient magnitude + orientation bin (:202-249) ----
-  const T uu[9] = {1.000, 0.9397, 0.7660, 0.5000, 0.1736, -0.1736, -0.5000, -0.7660, -0.9397};
-  const T vv[9] = {0.000, 0.3420, 0.6428, 0.8660, 0.9848, 0.9848, 0.8660, 0.6428, 0.3420};
   for (int i = tid; i < PT * PT; i += HOG_NT) {
     const int wy = i / PT, wx = i - wy * PT;
     const int y = py0 + wy, x = px0 + wx;
+    // outside the visible range (:202-203 loops over 1 <= x, y <= visible - 2): |g| = +0 in bin 0 — a histogram bin starts at +0
+    // and only ever receives non-negative terms, and x + (+0) == x bit for bit for every x >= +0, so the pixel needs no
+    // predicate in the histogram walk
     T m = (T)0;
-    int b = 255;
+    int b = 0;
     if (y >= 1 && y < vh - 1 && x >= 1 && x < vw - 1) {
       const int sx = min(x, w - 2), sy = min(y, h - 2);  // :208,218 source clamp
-      const uint8_t* s = raw + ((sy - ry0) * RT + (sx - rx0)) * cn;
-      T dx, dy, v;
+      const uint8_t* s = raw + (sy - ry0) * RP + (sx - rx0) * cn;
+      int dxi, dyi, vi;
       if (cn == 1) {
-        dy = (T)((int)s[rowb] - (int)s[-rowb]);
-        dx = (T)((int)s[1] - (int)s[-1]);
-        v = dx * dx + dy * dy;
+        dyi = (int)s[RP] - (int)s[-RP];
+        dxi = (int)s[1] - (int)s[-1];
       } else {
-        T dyb = (T)((int)s[rowb] - (int)s[-rowb]);
-        T dxb = (T)((int)s[3] - (int)s[-3]);
-        T vb = dxb * dxb + dyb * dyb;
-        T dyg = (T)((int)s[rowb + 1] - (int)s[-rowb + 1]);
-        T dxg = (T)((int)s[4] - (int)s[-2]);
-        T vg = dxg * dxg + dyg * dyg;
-        dy = (T)((int)s[rowb + 2] - (int)s[-rowb + 2]);
-        dx = (T)((int)s[5] - (int)s[-1]);
-        v = dx * dx + dy * dy;
-        if (vg > v) { v = vg; dx = dxg; dy = dyg; }
-        if (vb > v) { v = vb; dx = dxb; dy = dyb; }
+        // the squared norms are integers <= 2 * 255^2: exact in T, so the reference's comparisons of T values (:238-239) are
+        // comparisons of these integers
+        const int dyb = (int)s[RP] - (int)s[-RP], dxb = (int)s[3] - (int)s[-3];
+        const int dyg = (int)s[RP + 1] - (int)s[-RP + 1], dxg = (int)s[4] - (int)s[-2];
+        dyi = (int)s[RP + 2] - (int)s[-RP + 2]; dxi = (int)s[5] - (int)s[-1];
+        vi = dxi * dxi + dyi * dyi;
+        const int vg = dxg * dxg + dyg * dyg, vb = dxb * dxb + dyb * dyb;
+        if (vg > vi) { vi = vg; dxi = dxg; dyi = dyg; }
+        if (vb > vi) { vi = vb; dxi = dxb; dyi = dyb; }
       }
-      T best_dot = 0;
-      int best_o = 0;
-#pragma unroll
-      for (int o = 0; o < 9; ++o) {
-        T dot = uu[o] * dx + vv[o] * dy;
-        if (dot > best_dot) { best_dot = dot; best_o = o; }
-        else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
-      }
-      m = t_sqrt(v);
-      b = best_o;
+      vi = dxi * dxi + dyi * dyi;
+      b = binlut[(dyi + 255) * HOG_LUT_SIDE + (dxi + 255)];
+      m = t_sqrt((T)vi);
     }
-    mag[i] = m;
-    bin[i] = (uint8_t)b;
+    mag[wy * L.MP + wx] = m;
+    bin[wy * L.MP + wx] = (uint8_t)b;
   }
   __syncthreads();                                       // every thread is done with the staged pixels ...
   for (int i = tid; i < NB * NB * PBD_NORIENT; i += HOG_NT) hist[i] = (T)0;   // ... whose LDS the histograms take over
@@ -194,23 +246,41 @@ __global__ __launch_bounds__(HOG_NT) void k_hog(const HogTile* __restrict__ tile
     const int by = t.cy0 + lby, bx = t.cx0 + lbx;
     if (by >= bh || bx >= bw) continue;
     T* hb = hist + bl * PBD_NORIENT;
-    const int wy_lo = lby * sbin, wx_lo = lbx * sbin, span = 2 * sbin + 2;
+    if constexpr (SBIN_T > 0 && (SBIN_T & 1) == 0) {
+      // even cell size: block b receives exactly the 2 * sbin window rows / columns from b * sbin on, the first sbin of them
+      // with the "upper" weight (the pixel's iy is b - 1: weight vy0), the rest with the "lower" one (iy == b: vy1)
+      const int wy_lo = lby * SBIN_T, wx_lo = lbx * SBIN_T;
+      T fxv[2 * SBIN_T];
+#pragma unroll
+      for (int dx = 0; dx < 2 * SBIN_T; ++dx) fxv[dx] = dx < SBIN_T ? wx0[wx_lo + dx] : wx1[wx_lo + dx];
 #pragma unroll 2
-    for (int dy = 0; dy < span; ++dy) {
-      const int wy = wy_lo + dy;
-      if (wy >= PT) break;
-      const int iy = ipy[wy];
-      T fy;
-      if (iy == by) fy = wy1[wy]; else if (iy == by - 1) fy = wy0[wy]; else continue;
-      for (int dx = 0; dx < span; ++dx) {
-        const int wx = wx_lo + dx;
-        if (wx >= PT) break;
-        const int ix = ipx[wx];
-        T fx;
-        if (ix == bx) fx = wx1[wx]; else if (ix == bx - 1) fx = wx0[wx]; else continue;
-        const int o = bin[wy * PT + wx];
-        if (o == 255) continue;
-        hb[o] += (fy * fx) * mag[wy * PT + wx];
+      for (int dy = 0; dy < 2 * SBIN_T; ++dy) {
+        const int wy = wy_lo + dy;
+        const T fy = dy < SBIN_T ? wy0[wy] : wy1[wy];
+        const uint8_t* brow = bin + wy * L.MP + wx_lo;
+        const T* mrow = mag + wy * L.MP + wx_lo;
+#pragma unroll
+        for (int dx = 0; dx < 2 * SBIN_T; ++dx) {
+          hb[brow[dx]] += (fy * fxv[dx]) * mrow[dx];
+        }
+      }
+    } else {
+      const int wy_lo = lby * sbin, wx_lo = lbx * sbin, span = 2 * sbin + 2;
+#pragma unroll 2
+      for (int dy = 0; dy < span; ++dy) {
+        const int wy = wy_lo + dy;
+        if (wy >= PT) break;
+        const int iy = ipy[wy];
+        T fy;
+        if (iy == by) fy = wy1[wy]; else if (iy == by - 1) fy = wy0[wy]; else continue;
+        for (int dx = 0; dx < span; ++dx) {
+          const int wx = wx_lo + dx;
+          if (wx >= PT) break;
+          const int ix = ipx[wx];
+          T fx;
+          if (ix == bx) fx = wx1[wx]; else if (ix == bx - 1) fx = wx0[wx]; else continue;
+          hb[bin[wy * L.MP + wx]] += (fy * fx) * mag[wy * L.MP + wx];
+        }
       }
     }
   }
@@ -241,45 +311,67 @@ __global__ __launch_bounds__(HOG_NT) void k_hog(const HogTile* __restrict__ tile
   __syncthreads();
 
   HOG_STAMP(4);
-  // ---- 32 features per cell, one lane per feature (:301-338) ----
+  // ---- 32 features per cell (:301-338), ONE thread per cell: the 18 products val * n_i are computed once and feed the
+  //      contrast-sensitive features AND the four texture sums (sequential adds in orientation order, as the reference's
+  //      loop accumulates t1..t4); a lane-per-feature mapping recomputed them and ran every wavefront through all three
+  //      feature kinds.  Half a tile of cells at a time: the finished features are staged in LDS (row of 33 per cell) and
+  //      written out with 32 consecutive lanes per cell (128 B, coalesced). ----
   T* out = feat + lv.cell_off * PBD_FLEN;
-  for (int i = tid; i < tc * tc * PBD_FLEN; i += HOG_NT) {
-    const int k = i & 31;
-    const int cell = i >> 5;
-    const int ly = cell / tc, lx = cell - ly * tc;
-    const int cy = t.cy0 + ly, cx = t.cx0 + lx;
-    if (cy >= lv.ch || cx >= lv.cw) continue;
-    const T n1 = ninv[(ly + 1) * NC + lx + 1], n2 = ninv[ly * NC + lx + 1];
-    const T n3 = ninv[(ly + 1) * NC + lx], n4 = ninv[ly * NC + lx];
-    const T* hsrc = hist + ((ly + 1) * NB + lx + 1) * PBD_NORIENT;
-    T r;
-    if (k < 27) {
-      T val = (k < 18) ? hsrc[k] : hsrc[k - 18] + hsrc[k - 9];
-      T h1 = t_fmin(val * n1, (T)0.2), h2 = t_fmin(val * n2, (T)0.2);
-      T h3 = t_fmin(val * n3, (T)0.2), h4 = t_fmin(val * n4, (T)0.2);
-      r = (T)(0.5 * (double)(h1 + h2 + h3 + h4));
-    } else if (k < 31) {
-      const T n = (k == 27) ? n1 : (k == 28) ? n2 : (k == 29) ? n3 : n4;
-      T tsum = (T)0;
-#pragma unroll
-      for (int o = 0; o < PBD_NORIENT; ++o) tsum += t_fmin(hsrc[o] * n, (T)0.2);
-      r = (T)(0.2357 * (double)tsum);
-    } else {
-      r = (T)0;
+  T* stg = (T*)(smem + L.out_off);
+  const int ncell = tc * tc, half = (ncell + 1) / 2;
+  for (int c0 = 0; c0 < ncell; c0 += half) {
+    const int cell = c0 + tid;
+    if (tid < half && cell < ncell) {
+      const int ly = cell / tc, lx = cell - ly * tc;
+      if (t.cy0 + ly < lv.ch && t.cx0 + lx < lv.cw) {
+        const T n1 = ninv[(ly + 1) * NC + lx + 1], n2 = ninv[ly * NC + lx + 1];
+        const T n3 = ninv[(ly + 1) * NC + lx], n4 = ninv[ly * NC + lx];
+        const T* hsrc = hist + ((ly + 1) * NB + lx + 1) * PBD_NORIENT;
+        T* d = stg + tid * (PBD_FLEN + 1);
+        T t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#pragma unroll 6
+        for (int o = 0; o < PBD_NORIENT; ++o) {                    // :305-317
+          const T val = hsrc[o];
+          const T h1 = t_fmin(val * n1, (T)0.2), h2 = t_fmin(val * n2, (T)0.2);
+          const T h3 = t_fmin(val * n3, (T)0.2), h4 = t_fmin(val * n4, (T)0.2);
+          d[o] = (T)(0.5 * (double)(h1 + h2 + h3 + h4));
+          t1 += h1; t2 += h2; t3 += h3; t4 += h4;
+        }
+#pragma unroll 3
+        for (int o = 0; o < PBD_NORIENT / 2; ++o) {                // :320-328
+          const T sum = hsrc[o] + hsrc[o + PBD_NORIENT / 2];
+          const T h1 = t_fmin(sum * n1, (T)0.2), h2 = t_fmin(sum * n2, (T)0.2);
+          const T h3 = t_fmin(sum * n3, (T)0.2), h4 = t_fmin(sum * n4, (T)0.2);
+          d[PBD_NORIENT + o] = (T)(0.5 * (double)(h1 + h2 + h3 + h4));
+        }
+        d[27] = (T)(0.2357 * (double)t1);                          // :331-334
+        d[28] = (T)(0.2357 * (double)t2);
+        d[29] = (T)(0.2357 * (double)t3);
+        d[30] = (T)(0.2357 * (double)t4);
+        d[31] = (T)0;                                              // :337
+      }
     }
-    out[((size_t)cy * lv.cw + cx) * PBD_FLEN + k] = r;
+    __syncthreads();
+    for (int i = tid; i < half * PBD_FLEN; i += HOG_NT) {
+      const int k = i & 31, lc = i >> 5;
+      const int cl = c0 + lc;
+      const int ly = cl / tc, lx = cl - ly * tc;
+      const int cy = t.cy0 + ly, cx = t.cx0 + lx;
+      if (cl < ncell && cy < lv.ch && cx < lv.cw) out[((size_t)cy * lv.cw + cx) * PBD_FLEN + k] = stg[lc * (PBD_FLEN + 1) + k];
+    }
+    __syncthreads();
   }
   HOG_STAMP(5);
 }
 
 template <typename T>
 static void launch_hog_t(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, T* feat,
-                         int cn, int sbin, int tc, hipStream_t s) {
+                         int cn, int sbin, int tc, const uint8_t* binlut, hipStream_t s) {
   const size_t lds = hog_lds_bytes(sbin, tc, (int)sizeof(T));
   auto go = [&](auto kern) {
     static LdsOptIn optin;  // one per instantiation (the lambda is instantiated per kernel), per-device state inside
     optin.ensure((const void*)kern, lds);
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(HOG_NT), lds, s, tiles, levels, pyr, feat, cn, sbin, tc);
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(HOG_NT), lds, s, tiles, levels, pyr, feat, cn, sbin, tc, binlut);
   };
   if (sbin == 4 && tc == 16) go(k_hog<T, 4, 16>);
   else if (sbin == 4 && tc == 8) go(k_hog<T, 4, 8>);
@@ -287,10 +379,11 @@ static void launch_hog_t(const HogTile* tiles, int ntiles, const LevelDev* level
   else go(k_hog<T, 0, 0>);
 }
 
-// ts = sizeof(T) of the handle's instantiation (HOGFeatures<float> / HOGFeatures<double>, src/HOGFeatures.cpp:51-52)
+// ts = sizeof(T) of the handle's instantiation (HOGFeatures<float> / HOGFeatures<double>, src/HOGFeatures.cpp:51-52);
+// binlut: the orientation-snap table of the same T (launch_hog_binlut)
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
-                int cn, int sbin, int tc, hipStream_t s) {
+                int cn, int sbin, int tc, const uint8_t* binlut, hipStream_t s) {
   if (ntiles <= 0) return;
-  if (ts == 8) launch_hog_t<double>(tiles, ntiles, levels, pyr, (double*)feat, cn, sbin, tc, s);
-  else launch_hog_t<float>(tiles, ntiles, levels, pyr, (float*)feat, cn, sbin, tc, s);
+  if (ts == 8) launch_hog_t<double>(tiles, ntiles, levels, pyr, (double*)feat, cn, sbin, tc, binlut, s);
+  else launch_hog_t<float>(tiles, ntiles, levels, pyr, (float*)feat, cn, sbin, tc, binlut, s);
 }

@@ -300,6 +300,12 @@ static int upload_model(pbd_handle* h) {
   } else {
     HIPCHK(h, hipMemcpy(h->d_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  // orientation-snap table of the HOG kernel (k_hog.hip): 511 x 511 bytes, computed on the device by the reference's own
+  // comparison chain in T
+  HIPCHK(h, hipMalloc(&h->d_hog_lut, hog_binlut_bytes()));
+  launch_hog_binlut(h->d_hog_lut, h->ts, h->stream);
+  LAUNCHCHK(h, "HOG orientation table");
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   // biasw plus one trailing 0 (used by the stand-alone pbd_dt2d)
   std::vector<float> bw(h->biasw);
   bw.push_back(0.f);
@@ -337,7 +343,7 @@ static int upload_model(pbd_handle* h) {
   HIPCHK(h, hipMalloc(&h->d_cand_out, h->cand_stride * cap));
   HIPCHK(h, hipHostMalloc((void**)&h->h_cand_out, h->cand_stride * cap));
   HIPCHK(h, hipHostMalloc((void**)&h->h_cand_count, sizeof(int) * 4));
-  h->model_bytes = wT.size() * h->ts + bw.size() * sizeof(float) + (par.size() * 4 + npv.size()) * sizeof(int) + sizeof(int) +
+  h->model_bytes = wT.size() * h->ts + hog_binlut_bytes() + bw.size() * sizeof(float) + (par.size() * 4 + npv.size()) * sizeof(int) + sizeof(int) +
                    sizeof(CandRec) * cap + h->cand_stride * cap;
   return PBD_OK;
 }
@@ -422,15 +428,22 @@ static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget,
   g.map0 = map0; g.nmaps = nmaps; g.nlines = nlines; g.len = len; g.fold = fold;
   g.stride = dt_stride_for(len);
   g.lpb = dt_lpb_for(g.stride, len, fold >= 0 ? nmaps : 1, budget, ts, nt, seg, round_lanes);
+  // wave-uniform quotients of the block's index arithmetic, as constants (pbd_internal.hpp)
+  g.nsub = nt / g.lpb;
+  g.P = std::max(1, std::min(g.nsub, len / 8));          // dt_segments (dt_core.hpp)
+  g.chunk = (len + g.nsub - 1) / g.nsub;
+  g.magic_lpb = dt_magic((unsigned)g.lpb);
+  g.magic_nlines = dt_magic((unsigned)nlines);
+  g.magic_P = dt_magic((unsigned)g.P);
   return g;
 }
 static void dt_add_tasks(const DtGroup& g, std::vector<DtTask>& out) {
   if (g.fold >= 0) {
     const int R = g.lpb / g.nmaps;
-    for (int r0 = 0; r0 < g.nlines; r0 += R) out.push_back(DtTask{r0, std::min(R, g.nlines - r0) * g.nmaps, g});
+    for (int r0 = 0; r0 < g.nlines; r0 += R) out.push_back(DtTask{r0, std::min(R, g.nlines - r0) * g.nmaps, 0, r0, g});
   } else {
     const int total = g.nmaps * g.nlines;
-    for (int g0 = 0; g0 < total; g0 += g.lpb) out.push_back(DtTask{g0, std::min(g.lpb, total - g0), g});
+    for (int g0 = 0; g0 < total; g0 += g.lpb) out.push_back(DtTask{g0, std::min(g.lpb, total - g0), g0 / g.nlines, g0 % g.nlines, g});
   }
 }
 static DtMap dt_map(const void* src, void* dst, int16_t* ptr, float wq, float wl, int os, int natural) {
@@ -918,7 +931,7 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
 }
 
 static int run_hog(pbd_handle* h) {
-  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->stream);
+  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->d_hog_lut, h->stream);
   LAUNCHCHK(h, "HOG");
   h->have_feat = true;
   compact_mark_feat(h, true);
@@ -1201,7 +1214,7 @@ int pbd_destroy(pbd_handle* h) {
   if (!h) return PBD_ERR_ARG;
   if (h->stream) hipStreamSynchronize(h->stream);
   free_frame(h);
-  hipFree(h->d_wT); hipFree(h->d_biasw); hipFree(h->d_parent); hipFree(h->d_plane0); hipFree(h->d_nparts);
+  hipFree(h->d_wT); hipFree(h->d_biasw); hipFree(h->d_hog_lut); hipFree(h->d_parent); hipFree(h->d_plane0); hipFree(h->d_nparts);
   hipFree(h->d_flat); hipFree(h->d_depth);
   hipFree(h->d_cand_count); hipFree(h->d_cand_rec); hipFree(h->d_cand_out);
   if (h->h_cand_out) hipHostFree(h->h_cand_out);
@@ -1766,7 +1779,7 @@ static int hog_u8_(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
   HIPCHK(h, hipMemcpy2D(d_im, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_lv, &L, sizeof(L), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_tiles, tiles.data(), sizeof(HogTile) * tiles.size(), hipMemcpyHostToDevice));
-  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, ts, cn, sbin, tc, h->stream);
+  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, ts, cn, sbin, tc, h->d_hog_lut, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, d_feat, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyDeviceToHost));
   hipFree(d_im); hipFree(d_feat); hipFree(d_lv); hipFree(d_tiles);

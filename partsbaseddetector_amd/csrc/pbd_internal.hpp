@@ -60,8 +60,22 @@ struct DtMap {       // one 1-D pass over one score map
 //   fold:   the group is ONE part at one level (nmaps = its K mixtures, the lines of a row are its K mixtures): a
 //           block = nrows consecutive rows x K mixtures, and its loader builds the lines on the fly from the part's raw
 //           responses and its children's distance-transformed scores (FoldJob).
-struct DtGroup { int map0, nmaps, nlines, len, stride, lpb, fold, pad; };  // stride: LDS elements per line (odd); lpb: lines per block; fold: FoldJob index or -1
-struct DtTask { int g0, nl; DtGroup g; };   // g0: first line (plain) / first row (fold); nl: lines of this block; the group travels with the task
+// The block's index arithmetic divides by wave-uniform numbers (lines per block, lines per map, segments per line): the plan
+// supplies them as multiply-high constants — a division by a run-time value is ~20 vector instructions per lane, and vector
+// instruction issue is what bounds k_dt_pass.  magic_d = ceil(2^32 / d): x / d == umulhi(x, magic_d) exactly for x * d < 2^32.
+struct DtGroup {
+  int map0, nmaps, nlines, len, stride, lpb, fold;   // stride: LDS elements per line (odd); lpb: lines per block; fold: FoldJob index or -1
+  int nsub;                  // lanes per line = block lanes / lpb
+  int P;                     // segments per line = dt_segments(nsub, len)
+  int chunk;                 // read-out: outputs per lane = ceil(len / nsub)
+  unsigned magic_lpb;        // lane / lpb              (lane < 2^8)
+  unsigned magic_nlines;     // (l0 + lane) / nlines    (numerator < nlines + 2^8, nlines < 2^15)
+  unsigned magic_P;          // (p * len) / P           (p * len < 2^21, P <= 64)
+  int pad;
+};
+struct DtTask { int g0, nl, m0, l0; DtGroup g; };   // g0: first line (plain) / first row (fold); nl: lines of this block; plain: g0 = m0 * nlines + l0
+                                                    // (first map of the block, first line inside it); the group travels with the task
+static inline unsigned dt_magic(unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }   // d == 1: the quotient is the numerator itself (callers test)
 #ifndef PBD_DT_NT_DEFAULT
 #define PBD_DT_NT_DEFAULT 128   // lanes of a k_dt_pass block
 #endif
@@ -140,6 +154,7 @@ struct pbd_handle {
   int ncu = 256;
   int nfpad = 0;
   float* d_biasw = nullptr;
+  uint8_t* d_hog_lut = nullptr;   // orientation-snap table of HOGFeatures<T>::features (src/HOGFeatures.cpp:243-249), built once per handle on the device
   int* d_parent = nullptr;   // [ncomp][max_parts] parent of each part
   int* d_plane0 = nullptr;   // [ncomp][max_parts] local plane0 of each part
   int* d_nparts = nullptr;
@@ -279,8 +294,10 @@ int pbd_i_emit(pbd_handle* h, const std::vector<const char*>& recs, pbd_candidat
 void launch_resize(const PyrJob* jobs, int njobs, int maxpix, int cn, int sstride, const uint8_t* src, uint8_t* pyr, hipStream_t s);
 void launch_pyrdown(const PyrJob* jobs, int njobs, int maxpix, int cn, uint8_t* pyr, hipStream_t s);
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
-                int cn, int sbin, int tc, hipStream_t s);
+                int cn, int sbin, int tc, const uint8_t* binlut, hipStream_t s);
 size_t hog_lds_bytes(int sbin, int tc, int ts);
+size_t hog_binlut_bytes();                                        // orientation-snap table: best_o for every (dx, dy) in [-255, 255]^2
+void launch_hog_binlut(uint8_t* lut, int ts, hipStream_t s);      // evaluated in T (ts = sizeof(T)) with the reference's own chain (k_hog.hip)
 void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const void* feat,
                        const void* wT, void* resp, int ts, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
