@@ -491,14 +491,17 @@ template <> struct Mfma16<float> {
 // B4 (float, two channel halves; double, four 8-channel groups): wT is the [tap][group][k][nfpad][u] copy of the filters (channel
 // CH group + 4 u + k): a lane reads the k-steps of a tap and n-tile with ONE 16-byte load instead of four global_load_dword (which cost the MFMA pipe a quarter of its
 // issue rate with two waves per SIMD: tests/tools/mfma_rate_probe.hip)
-template <typename T, int KH, int KW, int NHALF, int WPE, int NTW = 1, bool B4 = false>   // WPE: waves per SIMD the register allocation must allow; NTW: 16-filter n-tiles per workgroup
+// KH_T / KW_T > 0: compile-time filter size (the 5x5 bank of the person / face models: tap loops and tile geometry fold);
+// 0: the size comes from the kernel arguments (any kh x kw <= 9 x 9, src/SpatialConvolutionEngine.cpp:133-159 takes any).
+template <typename T, int KH_T, int KW_T, int NHALF, int WPE, int NTW = 1, bool B4 = false>   // WPE: waves per SIMD the register allocation must allow; NTW: 16-filter n-tiles per workgroup
 __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __restrict__ tiles,
                                                      const LevelDev* __restrict__ levels,
                                                      const T* __restrict__ feat, const T* __restrict__ wT,
-                                                     T* __restrict__ resp, int nf, int nfpad, int ntiles_total) {
+                                                     T* __restrict__ resp, int nf, int nfpad, int ntiles_total, int kh_rt, int kw_rt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Mfma16<T> MM;
-  constexpr int TW = CT + KW - 1, TH = CT + KH - 1, NTAP = KH * KW;
+  const int KH = KH_T > 0 ? KH_T : kh_rt, KW = KW_T > 0 ? KW_T : kw_rt;
+  const int TW = CT + KW - 1, TH = CT + KH - 1, NTAP = KH * KW;
   // channels per pass, LDS cell stride, k-steps per tap.  Float: stride CH + 2 = 18 dwords: the 32 lanes of one LDS
   // access group (16 cells x 2 channels) then hit 32 different banks (16 * 18 mod 32 are the 16 even residues); with
   // 17 the cell 15 / channel 1 lane fell on cell 0's bank (SQ_LDS_BANK_CONFLICT was twice SQ_ACTIVE_INST_LDS)
@@ -577,7 +580,8 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
     };
     load_tap(b0, 0);   // tap 0, issued before the staging
     {  // stage CH channels of every cell: LPC lanes x 16 B per cell, batches of independent loads
-      constexpr int N = TH * TW * LPC, NB = (N + 255) / 256, BATCH = 7;
+      const int N = TH * TW * LPC, NB = (N + 255) / 256;
+      constexpr int BATCH = 7;
       for (int j0 = 0; j0 < NB; j0 += BATCH) {
         V r[BATCH];
 #pragma unroll
@@ -606,34 +610,43 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
     }
     __syncthreads();
     CONV_STAMP(1 + 2 * half);
-    auto mma_tap = [&](const T (&bw)[NTW][KS], int tap) {
-      const int ti = tap / KW, tj = tap - ti * KW;
-      const T* a = ft + (ti * TW + tj) * CS;
+    // The K loop of one channel group, instantiated per number of M-tiles the wave owns (MV = 1..4, wave-uniform: a ragged
+    // tile leaves some waves with fewer).  With the count tested inside the loop (`if (m < mvalid)`) hipcc guarded EVERY MFMA
+    // with its own scalar branch — 32 branches per tap between instructions that should issue back to back.
+    auto k_loop = [&](auto mv_tag) {
+      constexpr int MV = decltype(mv_tag)::value;
+      auto mma_tap = [&](const T (&bw)[NTW][KS], int tap) {
+        const int ti = tap / KW, tj = tap - ti * KW;
+        const T* a = ft + (ti * TW + tj) * CS;
 #pragma unroll
-      for (int u = 0; u < KS; ++u) {
-        T av[4];
+        for (int u = 0; u < KS; ++u) {
+          T av[MV];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) av[m] = a[aoff[m] + 4 * u];    // one A element per M-tile, shared by the workgroup's n-tiles
+          for (int m = 0; m < MV; ++m) av[m] = a[aoff[m] + 4 * u];    // one A element per M-tile, shared by the workgroup's n-tiles
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+          for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
-            if (m < mvalid) acc[nt][m] = MM::mma(av[m], bw[nt][u], acc[nt][m]);   // wave-uniform: rows past the level's last row do no MFMA work
+            for (int m = 0; m < MV; ++m) acc[nt][m] = MM::mma(av[m], bw[nt][u], acc[nt][m]);
+        }
+      };
+      auto tap_pair = [&](int tap) {
+        load_tap(b1, tap + 1);
+        mma_tap(b0, tap);
+        if (tap + 1 < NTAP) {
+          load_tap(b0, tap + 2);
+          mma_tap(b1, tap + 1);
+        }
+      };
+      if constexpr (NHALF == 1 && NTW == 1 && KH_T > 0) {
+        for (int tap = 0; tap < NTAP; tap += 2) tap_pair(tap);
+      } else {   // with half the k-steps per tap hipcc would unroll all taps and run out of registers
+        _Pragma("unroll 1") for (int tap = 0; tap < NTAP; tap += 2) tap_pair(tap);
       }
     };
-    auto tap_pair = [&](int tap) {
-      load_tap(b1, tap + 1);
-      mma_tap(b0, tap);
-      if (tap + 1 < NTAP) {
-        load_tap(b0, tap + 2);
-        mma_tap(b1, tap + 1);
-      }
-    };
-    if constexpr (NHALF == 1 && NTW == 1) {
-      for (int tap = 0; tap < NTAP; tap += 2) tap_pair(tap);
-    } else {   // with half the k-steps per tap hipcc would unroll all taps and run out of registers
-      _Pragma("unroll 1") for (int tap = 0; tap < NTAP; tap += 2) tap_pair(tap);
-    }
+    if (mvalid == 4) k_loop(std::integral_constant<int, 4>());
+    else if (mvalid == 3) k_loop(std::integral_constant<int, 3>());
+    else if (mvalid == 2) k_loop(std::integral_constant<int, 2>());
+    else if (mvalid == 1) k_loop(std::integral_constant<int, 1>());   // (0: M-tiles past the tile's last valid cell: no MFMA work)
     CONV_STAMP(2 + 2 * half);
   }
   __syncthreads();  // all waves are done reading the feature tile: reuse it for the epilogue
@@ -664,16 +677,17 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
 }
 
 int g_conv_lds_req_kb = 0;   // set by pbd_api.cpp from PBD_CONV_LDS_KB in probe / tuning builds
-template <typename T, int NHALF, int WPE, int NTW = 1, bool B4 = false>
+// KH_T = KW_T = 5: the compile-time 5x5 instantiation; 0: any kh x kw (run-time tap loop)
+template <typename T, int NHALF, int WPE, int NTW = 1, bool B4 = false, int KH_T = 5, int KW_T = 5>
 static void launch_conv_mfma16_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const T* feat,
-                                 const T* wT, T* resp, int nf, int nfpad, hipStream_t s) {
-  size_t lds = std::max(sizeof(T) * (CT + 4) * (CT + 4) * (PBD_FLEN / NHALF + (sizeof(T) == 4 ? 2 : 1)), sizeof(T) * 4 * 16 * 65);
+                                 const T* wT, T* resp, int nf, int nfpad, hipStream_t s, int kh = 5, int kw = 5) {
+  size_t lds = std::max(sizeof(T) * (CT + kh - 1) * (CT + kw - 1) * (PBD_FLEN / NHALF + (sizeof(T) == 4 ? 2 : 1)), sizeof(T) * 4 * 16 * 65);
   if (g_conv_lds_req_kb > 0) lds = std::max(lds, (size_t)g_conv_lds_req_kb * 1024);   // tuning builds: occupancy cap by LDS request
   static LdsOptIn optin;   // one per instantiation
-  optin.ensure((const void*)k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW, B4>, lds);
+  optin.ensure((const void*)k_conv_mfma16<T, KH_T, KW_T, NHALF, WPE, NTW, B4>, lds);
   dim3 grid((ntiles + 7) / 8 * 8, (nf + 16 * NTW - 1) / (16 * NTW));   // tiles padded to a multiple of 8 (XCD-aware mapping in the kernel)
   static const int prio_mode = PBD_PROBE_ENV("PBD_CONV_PRIO") ? atoi(PBD_PROBE_ENV("PBD_CONV_PRIO")) : 0;   // probe build only
-  hipLaunchKernelGGL((k_conv_mfma16<T, 5, 5, NHALF, WPE, NTW, B4>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles);
+  hipLaunchKernelGGL((k_conv_mfma16<T, KH_T, KW_T, NHALF, WPE, NTW, B4>), grid, dim3(256), lds, s, tiles, levels, feat, wT, resp, nf, nfpad | (prio_mode << 16), ntiles, kh, kw);
 }
 
 // ---------------------------------------------------------------------------
@@ -902,7 +916,10 @@ void launch_conv_glds_f32(const ConvTile* tiles, int ntiles, const LevelDev* lev
 void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* levels, const double* feat,
                           const double* wT, const double* w4u, double* resp, int nf, int nfpad, int kh, int kw, hipStream_t s) {
   if (ntiles <= 0) return;
-  if (kh != 5 || kw != 5) { launch_conv_exact(tiles, ntiles, levels, feat, wT, resp, 8, nf, nfpad, kh, kw, s); return; }
+  if (kh != 5 || kw != 5) {   // any other filter size: the same kernel with a run-time tap loop (16-byte B loads from the [tap][group][k][n][u] copy)
+    launch_conv_mfma16_t<double, 4, 2, 1, true, 0, 0>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s, kh, kw);
+    return;
+  }
   // four 8-channel passes (27 KB of LDS per workgroup) measured 7 % faster than two 16-channel halves (54 KB)
   static const int q = PBD_PROBE_ENV("PBD_MFMA64_QUARTERS") ? atoi(PBD_PROBE_ENV("PBD_MFMA64_QUARTERS")) : 1;   // probe-build knob
   if (q == 2) launch_conv_mfma16_t<double, 4, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);                // 8-byte B loads
@@ -921,8 +938,12 @@ void launch_conv_mfma_f64(const ConvTile* tiles, int ntiles, const LevelDev* lev
 // double-buffered staging (next channel group prefetched into registers across the K loop, second LDS buffer):
 // 0.51-0.71 ms vs 0.39 ms.
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
-                            const float* wT, const float* w4u, float* resp, int nf, int nfpad, int nhalf, hipStream_t s) {
+                            const float* wT, const float* w4u, float* resp, int nf, int nfpad, int nhalf, hipStream_t s, int kh, int kw) {
   if (ntiles <= 0) return;
+  if (kh != 5 || kw != 5) {   // any other filter size (3x3 .. 9x9): the default configuration (two n-tiles, 16-byte B loads) with a run-time tap loop
+    launch_conv_mfma16_t<float, 2, 3, 2, true, 0, 0>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s, kh, kw);
+    return;
+  }
   if (nhalf == 20) launch_conv_mfma16_t<float, 2, 3, 2, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // two n-tiles per workgroup, 16-byte B loads
   else if (nhalf == 21) launch_conv_mfma16_t<float, 2, 3, 1, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // one n-tile, 16-byte B loads
   else if (nhalf == 22) launch_conv_mfma16_t<float, 2, 2, 2, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // two n-tiles, 2 waves/SIMD allocation

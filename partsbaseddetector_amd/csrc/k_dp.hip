@@ -93,19 +93,10 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // block of the child (wave-uniform: scalar loads) is fetched in one straight-line batch — a load inside a (uniform)
 // branch costs one full scalar-memory round trip per branch, which is what made a first version's loader 5x slower
 // than the plain one.  Everything below is branch-free except the loop over the children.
-typedef float fold_f32x4 __attribute__((ext_vector_type(4)));
 template <typename T, int M, int U>
 __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ /*biasw*/, const unsigned (&off)[U],
                                               unsigned HW, int L, T (&acc)[U][M]) {
   const int nch = J->nch;
-  // a vector register that holds 0, opaque to the compiler: added to the (wave-uniform) address of the bias block it turns
-  // the fetch into VECTOR loads.  As scalar loads the K x L block (36 values for 6 x 6 mixtures) + the plane pointers
-  // overflow the scalar register file: the compiler spilled them to vector-register lanes and read them back with one
-  // v_readlane each (46 per child and cell batch) — vector-instruction slots, which is what this kernel is short of.
-  unsigned vzero = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-#endif
   unsigned ob[U];                                        // byte offsets of the cells inside a plane of T (< 2^32, plan_frame)
 #pragma unroll
   for (int u = 0; u < U; ++u) ob[u] = off[u] * (unsigned)sizeof(T);
@@ -122,23 +113,13 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
       for (int u = 0; u < U; ++u) sd[u][k] = *(GP(T))(pl + ob[u]);
     }
     float bias[M][M];
-    {
-      GP(char) bp = (GP(char))&C.bias[0][0] + vzero;
+    // (wave-uniform: scalar loads.  Fetching the block with vector loads instead — it overflows the scalar register file and
+    // part of it is spilled to vector-register lanes — was measured 9 % slower per fold launch: twelve more vector-memory
+    // instructions per child in front of the block's dependent chain)
 #pragma unroll
-      for (int k = 0; k < M; ++k) {
-        if constexpr (M > 4) {
-          const fold_f32x4 lo = *(GP(fold_f32x4))(bp + k * PBD_FOLD_MAXMIX * 4), hi = *(GP(fold_f32x4))(bp + k * PBD_FOLD_MAXMIX * 4 + 16);
-          const float r[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    for (int k = 0; k < M; ++k)
 #pragma unroll
-          for (int m = 0; m < M; ++m) bias[k][m] = r[m];
-        } else {
-          const fold_f32x4 lo = *(GP(fold_f32x4))(bp + k * PBD_FOLD_MAXMIX * 4);
-          const float r[4] = {lo[0], lo[1], lo[2], lo[3]};
-#pragma unroll
-          for (int m = 0; m < M; ++m) bias[k][m] = r[m];
-        }
-      }
-    }
+      for (int m = 0; m < M; ++m) bias[k][m] = C.bias[k][m];
     unsigned okoff[M];                                   // offset of plane m of the child's Ik planes (uniform).  Columns beyond L repeat column
 #pragma unroll                                           // L - 1 (plan) and land on plane L - 1 again: the same byte stored twice, no predicate
     for (int m = 0; m < M; ++m) okoff[m] = (unsigned)min(m, L - 1) * HW;

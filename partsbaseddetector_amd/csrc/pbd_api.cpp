@@ -962,9 +962,9 @@ static int run_pdf(pbd_handle* h) {
         launch_conv_glds_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat,
                              (const float*)h->d_wT + (size_t)m.kh * m.kw * m.flen * h->nfpad + m.flen /* [tap][half][k][n][s] copy */, (float*)h->d_resp, m.nfilters, h->nfpad,
                              (const float*)h->d_wT + (size_t)m.kh * m.kw * m.flen * h->nfpad /* border cell */, variant == 19 ? 1 : variant == 18 ? 0 : variant - 8, h->ncu, h->stream);
-      else if (variant && m.kh == 5 && m.kw == 5)
+      else if (variant || m.kh != 5 || m.kw != 5)   // (filters other than 5 x 5: the same kernel with a run-time tap loop)
         launch_conv_mfma16_f32(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT,
-                               (const float*)h->d_wT + 2 * (size_t)m.kh * m.kw * m.flen * h->nfpad + m.flen, (float*)h->d_resp, m.nfilters, h->nfpad, variant, h->stream);
+                               (const float*)h->d_wT + 2 * (size_t)m.kh * m.kw * m.flen * h->nfpad + m.flen, (float*)h->d_resp, m.nfilters, h->nfpad, variant, h->stream, m.kh, m.kw);
       else
         launch_conv_mfma(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const float*)h->d_feat, (const float*)h->d_wT, (float*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
     }
@@ -1196,8 +1196,9 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
     // measured on MI355X for N = 26 .. 312 5x5x32 filters at 640x480 (profiles/r02b_conv_modes.json): the fp32 MFMA
     // implicit GEMM beats the direct VALU correlation at every N (26 filters: 0.11 vs 0.38 ms; 156: 0.40 vs 1.62;
     // 312: 0.76 vs 2.89) — the contraction is K = 800 deep whatever N is, so one 16-filter n-tile already pays.
-    // The VALU kernel remains the bit-exact parity path (PBD_CONV_EXACT) and the fallback for other filter sizes.
-    h->conv_mode = (model->kh == 5 && model->kw == 5 && model->nfilters >= 16) ? PBD_CONV_MFMA : PBD_CONV_EXACT;
+    // The VALU kernel remains the bit-exact parity path (PBD_CONV_EXACT) and what banks of fewer than 16 filters get.
+    // Any filter size goes the same way (3x3 .. 9x9: the contraction is kh * kw * 32 >= 288 deep; run-time tap loop of the same kernel).
+    h->conv_mode = model->nfilters >= 16 ? PBD_CONV_MFMA : PBD_CONV_EXACT;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(h, PBD_ERR_HIP, "no HIP device visible");
   if (o.device < 0 || o.device >= ndev) return fail(h, PBD_ERR_ARG, "bad device ordinal");

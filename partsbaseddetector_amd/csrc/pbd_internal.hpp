@@ -308,7 +308,7 @@ extern int g_conv_lds_req_kb;
 void launch_conv_glds_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat, const float* wT,
                           float* resp, int nf, int nfpad, const float* border, int wg_per_cu, int ncu, hipStream_t s);
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
-                            const float* wT, const float* w4u, float* resp, int nf, int nfpad, int nhalf, hipStream_t s);
+                            const float* wT, const float* w4u, float* resp, int nf, int nfpad, int nhalf, hipStream_t s, int kh, int kw);
 void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw, size_t lds,
                     int ts, int nt, int fm, hipStream_t s);
 size_t dt_lds_bytes(int stride, int lpb, int ts, int nt);

@@ -925,6 +925,52 @@ def test_pdf_mfma_all_levels_random_sizes(gpu_required, orc, dtype, tol):
     h.close()
 
 
+@pytest.mark.parametrize("kh,kw,dtype,tol", [(3, 3, np.float32, 2e-5), (7, 7, np.float32, 4e-5), (9, 9, np.float32, 6e-5), (3, 7, np.float32, 3e-5),
+                                            (6, 4, np.float32, 3e-5), (7, 7, np.float64, 1e-12), (3, 3, np.float64, 1e-12)])
+def test_pdf_mfma_any_filter_size(gpu_required, orc, kh, kw, dtype, tol):
+    """SpatialConvolutionEngine::setFilters takes any kh x kw per bank (src/SpatialConvolutionEngine.cpp:133-159): the MFMA
+    filter bank (run-time tap loop of k_conv_mfma16) against the oracle's tap-ordered sums on every level of two pyramids —
+    odd, even and rectangular sizes (anchor = kernel centre kh / 2, kw / 2: include/filterengine.hpp:310-317), partial tiles,
+    a partial last n-tile (21 filters), borders wider than a tile on the small levels.  PBD_CONV_AUTO picks it from 16 filters on.
+    The tolerance grows with the contraction depth kh * kw * 32 (a k-ordered fma chain against the reference's per-channel sums)."""
+    m = make_tree_model([-1] + [0] * 20, 1, seed=31, kh=kh, kw=kw)      # 21 filters: one full 16-filter n-tile + 5
+    h = capi.Handle(m, dtype=dtype)                                      # PBD_CONV_AUTO
+    he = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dtype=dtype)
+    for i, (w, hh) in enumerate([(97, 70), (210, 163)]):
+        im = make_image(400 + i, w, hh)
+        h.pyramid(im); he.pyramid(im)
+        g = h._geo
+        h.pdf(); he.pdf()
+        for l in range(g["nlevels"]):
+            if g["cell_w"][l] == 0 or g["cell_h"][l] == 0:
+                continue
+            ref = orc.pdf_level(h.level_features(l), m.filtersw, dtype=dtype)
+            for n in (0, 15, 16, 20):
+                got = h.level_response(l, n)
+                assert np.abs(got - ref[n]).max() < tol, (w, hh, l, n)
+                assert np.array_equal(he.level_response(l, n), ref[n])      # the exact bank stays bit-identical at every size
+                assert not np.array_equal(got, ref[n]) or got.size < 4      # ... and AUTO really took the MFMA path (k-ordered sums differ in the last bits)
+    h.close(); he.close()
+
+
+def test_detect_7x7_filters_mfma_classified(gpu_required, orc):
+    """End to end with a 7 x 7 bank: PBD_CONV_AUTO -> MFMA, every part-location difference classified (argmin's boxes use
+    xsize = ysize = filter rows, src/DynamicProgram.cpp:238-240, include/Parts.hpp:185-187)."""
+    m = make_tree_model([-1, 0, 1, 1, 0, 4], 3, seed=12, kh=7, kw=7)    # 18 filters
+    im = make_image(6, 320, 240)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.7)
+    rh, rb, rl, _, fr = orc.detect(m, im, keep=True)
+    assert len(rh) > 40
+    he = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    assert_candidates_equal(he.detect(im), (rh, rb, rl))
+    he.close()
+    hm = capi.Handle(m)
+    got = hm.detect(im)
+    n, flips, ties, bugs, worst = _classified_compare(orc, m, im, hm, got, (rh, rb, rl), fr)
+    hm.close(); fr.free()
+    assert n >= 0.95 * len(rh) and not bugs, (n, flips, ties, bugs)
+
+
 # ---------------------------------------------------------------- the timed configuration, classified (VERDICT r01 #1)
 def _classified_compare(orc, model, im, hd, got, ref, fr, dtype=np.float32, tol=1e-4):
     """MFMA filter bank vs the oracle on one frame.  Root scores within `tol`; candidates on one side only sit on the
