@@ -163,7 +163,7 @@ DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const dou
     yk = pop ? below.x : yq;
     zk = pop ? below.y : s;
     yq = pop ? yq : ynext;
-    q = pop ? q : q + 1;
+    q += pop ? 0 : 1;
   }
   return DT_SUSPECT_MINE(suspect);
 }

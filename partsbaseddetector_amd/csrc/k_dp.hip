@@ -22,6 +22,7 @@
 // k_root      root bias + reduceMax (:163-171), strict threshold (:208) and
 //             compaction of the hits.
 // k_backtrack argmin (:219-245): one block per candidate, one lane per part, depth by depth.
+#include <algorithm>
 #include <type_traits>
 #include "pbd_internal.hpp"
 #include "dt_core.hpp"
@@ -652,9 +653,12 @@ __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count,
                                                   int correct_ptr, const int16_t* __restrict__ extx,
                                                   const int16_t* __restrict__ exty, const unsigned long long* __restrict__ ext_base) {
   __shared__ int lx[BT_MAXP], ly[BT_MAXP], lm[BT_MAXP];
-  const int idx = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
   const int n = min(*count, capacity);
-  if (idx >= n) return;
+  // grid-stride over the candidates: the launch is sized for the chip, not for the capacity (the count is only known on the
+  // device; one block per record of a 32 768-record buffer meant ~30 000 blocks that exit at once, every frame)
+  for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
+  __syncthreads();                                   // the previous candidate's lx / ly / lm are done with
   const CandRec r = rec[idx];
   const BackLevel B = back[r.level * ncomp + r.comp];
   const size_t HW = (size_t)B.H * B.W;
@@ -706,6 +710,7 @@ __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count,
       for (int k = 0; k < 3; ++k) locs[p * 3 + k] = 0;
     }
   }
+  }
 }
 
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
@@ -713,8 +718,9 @@ void launch_backtrack(const int* count, const CandRec* rec, int capacity, const 
                       size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,
                       const unsigned long long* scr_base, const int16_t* ix, const int16_t* iy, int correct_ptr,
                       const int16_t* extx, const int16_t* exty, const unsigned long long* ext_base, hipStream_t s) {
-  if (ts == 8) hipLaunchKernelGGL(k_backtrack<double>, dim3(capacity), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base);
-  else hipLaunchKernelGGL(k_backtrack<float>, dim3(capacity), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base);
+  const int nblk = std::min(capacity, 2048);   // 8 blocks of one wavefront per CU; more candidates than that are taken in further sweeps
+  if (ts == 8) hipLaunchKernelGGL(k_backtrack<double>, dim3(nblk), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base);
+  else hipLaunchKernelGGL(k_backtrack<float>, dim3(nblk), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base);
 }
 
 // ---------------------------------------------------------------------------

@@ -493,7 +493,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   {  // image pyramid jobs: the first octave of every frame from the frame (tightly packed, back to back), then the chains
     std::vector<PyrJob> jobs;
     h->pyr_launches.clear();
-    pbd_handle::PyrLaunch R{0, 0, 1};
+    pbd_handle::PyrLaunch R{0, 0, 1, 1, 1};
     for (int f = 0; f < batch; ++f)
       for (int i = 0; i < m.interval; ++i) {
         const Level& L = h->lv[f * n1 + i];
@@ -503,12 +503,13 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
     R.njobs = (int)jobs.size();
     h->pyr_launches.push_back(R);
     for (int base = m.interval; base < n1; base += m.interval) {
-      pbd_handle::PyrLaunch D{(int)jobs.size(), 0, 1};
+      pbd_handle::PyrLaunch D{(int)jobs.size(), 0, 1, 1, 1};
       for (int f = 0; f < batch; ++f)
         for (int j = base; j < std::min(base + m.interval, n1); ++j) {
           const Level &S = h->lv[f * n1 + j - m.interval], &L = h->lv[f * n1 + j];
           jobs.push_back(PyrJob{(unsigned long long)S.img_off, (unsigned long long)L.img_off, S.iw, S.ih, L.iw, L.ih});
           D.maxpix = std::max(D.maxpix, L.iw * L.ih);
+          D.maxw = std::max(D.maxw, L.iw); D.maxh = std::max(D.maxh, L.ih);
         }
       D.njobs = (int)jobs.size() - D.job0;
       h->pyr_launches.push_back(D);
@@ -922,7 +923,7 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
   for (size_t i = 0; i < h->pyr_launches.size(); ++i) {
     const pbd_handle::PyrLaunch& P = h->pyr_launches[i];
     if (i == 0) launch_resize(h->d_pyrjobs + P.job0, P.njobs, P.maxpix, h->fcn, stride, d_src, h->d_pyr, h->stream);
-    else launch_pyrdown(h->d_pyrjobs + P.job0, P.njobs, P.maxpix, h->fcn, h->d_pyr, h->stream);
+    else launch_pyrdown(h->d_pyrjobs + P.job0, P.njobs, P.maxw, P.maxh, h->fcn, h->d_pyr, h->stream);
   }
   LAUNCHCHK(h, "image pyramid");
   h->have_pyr = true;
@@ -1819,7 +1820,7 @@ int pbd_pyrdown_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
   PyrJob job{0, (unsigned long long)sb, w, hgt, (w + 1) / 2, (hgt + 1) / 2}, *d_job;
   HIPCHK(h, hipMalloc(&d_job, sizeof(job)));
   HIPCHK(h, hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice));
-  launch_pyrdown(d_job, 1, job.dw * job.dh, cn, d_buf, h->stream);
+  launch_pyrdown(d_job, 1, job.dw, job.dh, cn, d_buf, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, d_buf + sb, db, hipMemcpyDeviceToHost));
   hipFree(d_buf); hipFree(d_job);

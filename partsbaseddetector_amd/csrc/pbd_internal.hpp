@@ -167,7 +167,7 @@ struct pbd_handle {
   int batch = 1, nvl = 0;                       // frames per plan, virtual levels = batch * nlevels
   std::vector<Level> lv;                        // [nvl]
   PyrJob* d_pyrjobs = nullptr;                  // resize jobs, then the pyrDown jobs octave by octave
-  struct PyrLaunch { int job0, njobs, maxpix; };
+  struct PyrLaunch { int job0, njobs, maxpix, maxw, maxh; };   // maxpix / maxw / maxh: the largest destination level of the launch
   std::vector<PyrLaunch> pyr_launches;          // [0]: resize, [1..]: pyrDown octave steps
   size_t cells = 0, pyr_bytes = 0;
   bool have_pyr = false, have_feat = false, have_resp = false, have_dp = false;
@@ -292,7 +292,7 @@ int pbd_i_emit(pbd_handle* h, const std::vector<const char*>& recs, pbd_candidat
 
 // ---- kernel launchers (k_*.hip) ----------------------------------------------
 void launch_resize(const PyrJob* jobs, int njobs, int maxpix, int cn, int sstride, const uint8_t* src, uint8_t* pyr, hipStream_t s);
-void launch_pyrdown(const PyrJob* jobs, int njobs, int maxpix, int cn, uint8_t* pyr, hipStream_t s);
+void launch_pyrdown(const PyrJob* jobs, int njobs, int maxw, int maxh, int cn, uint8_t* pyr, hipStream_t s);
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
                 int cn, int sbin, int tc, const uint8_t* binlut, hipStream_t s);
 size_t hog_lds_bytes(int sbin, int tc, int ts);
