@@ -107,11 +107,21 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
     // cells (uniform base + 32-bit byte offset: no vector arithmetic per load) and the dense K x L bias block
     GPW(uint8_t) okp = (GPW(uint8_t))C.ok;
     T sd[U][M];
+    // (the offsets pass through an empty asm: hoisted out of the loop over the children they would be kept zero-extended to
+    // 64 bits, and every load / store would pay a 64-bit vector add instead of using the scalar-base + 32-bit-offset form)
+    unsigned obc[U], offc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      obc[u] = ob[u]; offc[u] = off[u];
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(obc[u]), "+v"(offc[u]));
+#endif
+    }
 #pragma unroll
     for (int k = 0; k < M; ++k) {
       GP(char) pl = (GP(char))C.sdt[k];                  // entries beyond K repeat plane K - 1 (plan): never predicated
 #pragma unroll
-      for (int u = 0; u < U; ++u) sd[u][k] = *(GP(T))(pl + ob[u]);
+      for (int u = 0; u < U; ++u) sd[u][k] = *(GP(T))(pl + obc[u]);
     }
     float bias[M][M];
     // (wave-uniform: scalar loads.  Fetching the block with vector loads instead — it overflows the scalar register file and
@@ -130,7 +140,7 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
       for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-          *(okp + (okoff[m] + off[u])) = (uint8_t)0;                                     // Ik (:150)
+          *(okp + (okoff[m] + offc[u])) = (uint8_t)0;                                    // Ik (:150)
           acc[u][m] = acc[u][m] + (sd[u][0] + bias[0][m]);                               // DynamicProgram.cpp:139, :156
         }
       }
@@ -163,7 +173,7 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
       for (int m = 0; m < M; ++m) {
         // Ik (:150).  Unpredicated: a lane past the block's last cell works on that cell again (its offset was clamped) and
         // stores the same byte once more
-        *(okp + (okoff[m] + off[u])) = (uint8_t)bi[m];                 // (cells * planes < 2^32, plan_frame)
+        *(okp + (okoff[m] + offc[u])) = (uint8_t)bi[m];                // (cells * planes < 2^32, plan_frame)
         acc[u][m] = acc[u][m] + v[m];                                  // parent.score += maxv (:156), child order kept
       }
     }
@@ -405,7 +415,8 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       const int nlines = g.nlines;
       GPW(T) dp = (GPW(T))mp.dst + li + (size_t)(q1 - 1) * nlines;      // running output pointers: no 64-bit multiply per element
       GPW(int16_t) ppq = (GPW(int16_t))pp + (size_t)(q1 - 1) * pst;
-      for (int q = q1 - 1; q >= q0; --q) {
+      const int os_end = mp.os + q0;           // the sub-range's first output (the loop counts the shifted position down to it)
+      for (; os >= os_end;) {
         const T fos = (T)os;                   // `z[k+1] < os`: int promoted to T (:174)
         while (!(eyz.y < fos)) { e = nx; eyz = nyz; nx = nnx; nyz = YZl[nx]; nnx = (int)Bl[nx]; }
         const int d = os - e;
