@@ -568,18 +568,16 @@ void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks
 // ---------------------------------------------------------------------------
 // root: bias + max over root mixtures, threshold, compaction
 // ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, int njobs, double thresh,
+// One 256-thread block = 256 consecutive cells of ONE job (level, component): block -> (job, first cell) comes from a host-built
+// table, so the job descriptor is wave-uniform (scalar loads; rounds 1-3 had every thread binary-search the job list: nine
+// dependent global loads in front of the fold).  FM: register-array bound of the fold (the model's largest mixture count).
+template <typename T, int FM>
+__global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, const ReduceBlock* __restrict__ blocks, double thresh,
                                               int* __restrict__ count, CandRec* __restrict__ rec, int capacity,
                                               const FoldJob* __restrict__ folds, const float* __restrict__ biasw, int rescan) {
-  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
-  int lo = 0, hi = njobs - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].cell0 <= gid) lo = mid; else hi = mid - 1;
-  }
-  const RootJob& J = jobs[lo];
-  const unsigned cell = gid - J.cell0;
+  const ReduceBlock rb = blocks[blockIdx.x];
+  const RootJob& J = jobs[rb.job];
+  const unsigned cell = rb.cell0 + threadIdx.x;
   if (cell >= (unsigned)J.H * J.W) return;
   T v;
   int bi = 0;
@@ -593,32 +591,32 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
     }
     return;
   }
+  const int K = J.K;
   if (J.fold >= 0) {
     // fold mode: the root's accumulated score is built here from its raw responses and its children's messages
-    constexpr int M = PBD_FOLD_MAXMIX;
+    constexpr int M = FM;
     T acc[1][M];
     const unsigned offs[1] = {cell};
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[0][m] = ((GP(T))J.score[m < J.K ? m : J.K - 1])[cell];
-    // (acc is [1][M]: one cell per lane)
-    fold_children<T, M, 1>(folds + J.fold, biasw, offs, (unsigned)J.H * (unsigned)J.W, J.K, acc);
-    if (J.K == 1) {
+    for (int m = 0; m < M; ++m) acc[0][m] = ((GP(T))J.score[m])[cell];       // (entries beyond K repeat mixture K - 1: plan_frame)
+    fold_children<T, M, 1>(folds + J.fold, biasw, offs, (unsigned)J.H * (unsigned)J.W, K, acc);
+    if (K == 1) {
       v = acc[0][0] + bias;
     } else {
       v = -INFINITY;
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        if (m < J.K) {
+        if (m < K) {
           const T wv = acc[0][m] + bias;                   // DynamicProgram.cpp:169
           if (wv > v) { bi = m; v = wv; }
         }
       }
     }
-  } else if (J.K == 1) {
+  } else if (K == 1) {
     v = ((const T*)J.score[0])[cell] + bias;
   } else {
     v = -INFINITY;
-    for (int m = 0; m < J.K; ++m) {
+    for (int m = 0; m < K; ++m) {
       const T wv = ((const T*)J.score[m])[cell] + bias;  // DynamicProgram.cpp:169
       if (wv > v) { bi = m; v = wv; }
     }
@@ -635,11 +633,21 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
   }
 }
 
-void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
-                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, hipStream_t s) {
-  if (njobs <= 0 || total_cells == 0) return;
-  if (ts == 8) hipLaunchKernelGGL(k_root<double>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity, folds, biasw, rescan);
-  else hipLaunchKernelGGL(k_root<float>, dim3((total_cells + 255) / 256), dim3(256), 0, s, jobs, njobs, thresh, count, rec, capacity, folds, biasw, rescan);
+template <typename T>
+static void launch_root_t(const RootJob* jobs, const ReduceBlock* blocks, int nblocks, double thresh, int* count, CandRec* rec,
+                          int capacity, const FoldJob* folds, const float* biasw, int rescan, int fm, hipStream_t s) {
+  const dim3 g(nblocks), b(256);
+  if (fm <= 1) hipLaunchKernelGGL((k_root<T, 1>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan);
+  else if (fm <= 4) hipLaunchKernelGGL((k_root<T, 4>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan);
+  else if (fm <= 6) hipLaunchKernelGGL((k_root<T, 6>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan);
+  else hipLaunchKernelGGL((k_root<T, PBD_FOLD_MAXMIX>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan);
+}
+// fm: largest mixture count of a part (only the fold reads it); blocks: one entry per 256 cells of a job
+void launch_root(const RootJob* jobs, const ReduceBlock* blocks, int nblocks, double thresh, int* count, CandRec* rec,
+                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, int fm, hipStream_t s) {
+  if (nblocks <= 0) return;
+  if (ts == 8) launch_root_t<double>(jobs, blocks, nblocks, thresh, count, rec, capacity, folds, biasw, rescan, fm, s);
+  else launch_root_t<float>(jobs, blocks, nblocks, thresh, count, rec, capacity, folds, biasw, rescan, fm, s);
 }
 
 // ---------------------------------------------------------------------------

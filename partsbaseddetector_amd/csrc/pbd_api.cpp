@@ -869,6 +869,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
 
   // root jobs + backtracking info
   std::vector<RootJob> rj;
+  std::vector<ReduceBlock> rootblk;   // k_root's blocks: (job, first cell)
   std::vector<BackLevel> bl((size_t)n * m.ncomponents);
   unsigned rcells = 0;
   for (int l = 0; l < n; ++l) {
@@ -884,15 +885,18 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
       if (!L.active || HW == 0) continue;
       const PartInfo& R0 = h->parts[h->part_offset[c]];
       RootJob J{};
-      for (int k = 0; k < R0.K; ++k)
-        J.score[k] = (!fold && slot_init[R0.slot[k]]) ? h->d_acc + (L.cell_off * h->nslots + (size_t)R0.slot[k] * HW) * ts
-                                                      : resp_plane(l, R0.filterid[k]);
+      for (int kk = 0; kk < PBD_MAX_MIX; ++kk) {   // entries beyond K repeat mixture K - 1 (the fold's register arrays are never predicated)
+        const int k = std::min(kk, R0.K - 1);
+        J.score[kk] = (!fold && slot_init[R0.slot[k]]) ? h->d_acc + (L.cell_off * h->nslots + (size_t)R0.slot[k] * HW) * ts
+                                                       : resp_plane(l, R0.filterid[k]);
+      }
       J.rootv = (void*)B.rootv; J.rooti = (int*)B.rooti;
       J.H = L.ch; J.W = L.cw; J.K = R0.K; J.level = l; J.comp = c;
       J.bias = h->biasw[R0.biasid[0]];  // root.bias(0)[0], DynamicProgram.cpp:165
       J.cell0 = rcells;
       J.fold = fold ? make_fold(h->part_offset[c], l) : -1;   // fold: the root's messages are folded by k_root
       rcells += (unsigned)HW;
+      for (unsigned c0 = 0; c0 < (unsigned)HW; c0 += 256) rootblk.push_back(ReduceBlock{(int)rj.size(), c0});
       rj.push_back(J);
     }
   }
@@ -904,6 +908,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   h->n_rootjobs = (int)rj.size();
   h->root_cells = rcells;
   if ((rc = dev_upload(h, &h->d_rootjobs, rj))) return rc;
+  h->n_rootblocks = (int)rootblk.size();
+  if ((rc = dev_upload(h, &h->d_rootblocks, rootblk))) return rc;
   if ((rc = dev_upload(h, &h->d_back, bl))) return rc;
   // where the DT pointer planes of (level, part) live: back-tracking composes Ix / Iy from them on the fly
   h->scr_base.assign((size_t)n * h->parts.size(), 0);
@@ -990,8 +996,8 @@ static int run_dp_min(pbd_handle* h) {
       launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
   }
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
-  launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
-              h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 0, h->stream);
+  launch_root(h->d_rootjobs, h->d_rootblocks, h->n_rootblocks, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
+              h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 0, h->fold_mix, h->stream);
   if (dpt) hipEventRecord(h->ev_dp1, h->stream);
   h->dp_timed = dpt;
   LAUNCHCHK(h, "DP min");
@@ -1010,8 +1016,8 @@ static int run_dp_min(pbd_handle* h) {
 static int run_argmin_enqueue(pbd_handle* h) {
   if (h->root_dirty) {   // root tables injected since min(): the hits are those of the tables now on the device
     hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
-    launch_root(h->d_rootjobs, h->n_rootjobs, h->root_cells, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
-                h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 1, h->stream);
+    launch_root(h->d_rootjobs, h->d_rootblocks, h->n_rootblocks, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
+                h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 1, h->fold_mix, h->stream);
     h->root_dirty = false;
   }
   launch_backtrack(h->d_cand_count, h->d_cand_rec, h->opt.max_candidates, h->d_back, h->md.ncomponents, h->d_parent,

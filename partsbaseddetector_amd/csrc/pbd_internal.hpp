@@ -109,7 +109,7 @@ struct ReduceJob {       // one (level, parent): fold the messages of nch childr
 };
 struct ReduceBlock { int job; unsigned cell0; };  // one 256-thread block of k_reduce
 struct RootJob {
-  const void* score[PBD_MAX_MIX];  // T: root mixture m current score
+  const void* score[PBD_MAX_MIX];  // T: root mixture m current score (entries beyond K repeat mixture K - 1)
   void* rootv; int* rooti;         // rootv: T
   int H, W, K, level, comp;
   float bias;
@@ -212,6 +212,7 @@ struct pbd_handle {
   int xcd_chunk = 16;                                // consecutive k_dt_pass tasks kept on one XCD (0: table order)
   std::vector<RoundLaunch> rl;
   int n_rootjobs = 0; unsigned root_cells = 0;
+  ReduceBlock* d_rootblocks = nullptr; int n_rootblocks = 0;   // k_root: one 256-thread block per 256 cells of a root job
   // candidates
   int* d_cand_count = nullptr; CandRec* d_cand_rec = nullptr;
   char* d_cand_out = nullptr; char* h_cand_out = nullptr; int* h_cand_count = nullptr;
@@ -314,8 +315,8 @@ void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const Fo
 size_t dt_lds_bytes(int stride, int lpb, int ts, int nt);
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
                    int ts, hipStream_t s);
-void launch_root(const RootJob* jobs, int njobs, unsigned total_cells, double thresh, int* count, CandRec* rec,
-                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, hipStream_t s);
+void launch_root(const RootJob* jobs, const ReduceBlock* blocks, int nblocks, double thresh, int* count, CandRec* rec,
+                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, int fm, hipStream_t s);
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
                       char* out, size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,
