@@ -483,6 +483,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
     const int l = vl % n1;
     L.active = (l >= lb && l < le) && (h->level_set.empty() || (l < (int)h->level_set.size() && h->level_set[l]));
     if (L.cw > 32767 || L.ch > 32767) return fail(h, PBD_ERR_UNSUPPORTED, "level too large for 16-bit pointers");
+    // the fold loader addresses a level's planes with 32-bit offsets: cell * sizeof(T) and plane * cells + cell (<= 8 planes of a child)
+    if ((size_t)L.cw * L.ch >= ((size_t)1 << 28)) return fail(h, PBD_ERR_UNSUPPORTED, "level too large (2^28 cells)");
     L.img_off = pyr; pyr += (size_t)L.iw * L.ih * cn;
     L.cell_off = cells; cells += (size_t)L.cw * L.ch;
   }
