@@ -453,7 +453,7 @@ def main():
                   "launch": "hipGraph replay (one hipGraphLaunch per step)" if args.graph else "eager (~30 launches per step)",
                   "legs": sorted(legs), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                   "prewarm_s": 0.0 if args.no_prewarm else PREWARM_S, "prewarm_frames": prewarm_frames,
-                  "candidates_last_frame": int(ncand_all), "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}"),
+                  "candidates_last_step": int(ncand_all), "candidates_last_step_is": "records of the last timed step, all its frames (and all ranks: the gathered list)", "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}"),
                   "gather": (f"every step, inside the timed region: torch.distributed gather to rank 0, backend {args.backend}, "
                              f"counts first, then the records padded to the longest list" if world > 1 else "none (one rank)")}
         if world > 1:

@@ -77,7 +77,7 @@ typedef struct pbd_model_desc {
 /* ---- options -------------------------------------------------------------- */
 enum {
   PBD_CONV_AUTO = 0,  /* MFMA filter bank from 16 filters on, any kh x kw (measured faster than the direct
-                         correlation from 26 to 312 filters: profiles/r03b_conv_modes.json), else EXACT     */
+                         correlation from 26 to 312 filters: profiles/archive/r03b_conv_modes.json), else EXACT     */
   PBD_CONV_EXACT = 1, /* VALU direct correlation, reference summation order:
                          bit-identical to src/filter.cpp:3899-3922 + pdf+=pdfc */
   PBD_CONV_MFMA = 2   /* MFMA implicit GEMM (k-ordered fma chain) for any kh x kw: fp32

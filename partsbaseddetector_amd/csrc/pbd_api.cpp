@@ -1202,7 +1202,7 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   if (rc) return rc;
   h->conv_mode = o.conv_mode;
   if (h->conv_mode == PBD_CONV_AUTO)
-    // measured on MI355X for N = 26 .. 312 5x5x32 filters at 640x480 (profiles/r02b_conv_modes.json): the fp32 MFMA
+    // measured on MI355X for N = 26 .. 312 5x5x32 filters at 640x480 (profiles/archive/r03b_conv_modes.json): the fp32 MFMA
     // implicit GEMM beats the direct VALU correlation at every N (26 filters: 0.11 vs 0.38 ms; 156: 0.40 vs 1.62;
     // 312: 0.76 vs 2.89) — the contraction is K = 800 deep whatever N is, so one 16-filter n-tile already pays.
     // The VALU kernel remains the bit-exact parity path (PBD_CONV_EXACT) and what banks of fewer than 16 filters get.

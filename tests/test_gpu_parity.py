@@ -1297,7 +1297,7 @@ def test_bench_lines_parse(gpu_required):
         if ngpu == 2:
             # what makes a multi-GPU line auditable from its JSON: every rank's device, gathered inside the run
             cfg = line["config"]
-            assert "every step" in cfg["gather"] and cfg["candidates_last_frame"] > 0
+            assert "every step" in cfg["gather"] and cfg["candidates_last_step"] > 0
             assert cfg["backend"] == "gloo" and cfg["backend_world"] == 2 and len(cfg["ranks"]) == 2
             assert [r["rank"] for r in cfg["ranks"]] == [0, 1] and len({r["pid"] for r in cfg["ranks"]}) == 2
             assert all("device" in r and "pci_bus_id" in r and "uuid" in r for r in cfg["ranks"])
