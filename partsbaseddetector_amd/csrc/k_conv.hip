@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
     load_tap(b0, 0);   // tap 0, issued before the staging
     {  // stage CH channels of every cell: LPC lanes x 16 B per cell, batches of independent loads
       const int N = TH * TW * LPC, NB = (N + 255) / 256;
-      constexpr int BATCH = 7;
+      constexpr int BATCH = WPE >= 4 ? 4 : 7;   // (a tighter register allocation stages in smaller batches)
       for (int j0 = 0; j0 < NB; j0 += BATCH) {
         V r[BATCH];
 #pragma unroll
@@ -949,6 +949,9 @@ void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* l
   else if (nhalf == 22) launch_conv_mfma16_t<float, 2, 2, 2, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // two n-tiles, 2 waves/SIMD allocation
   else if (nhalf == 23) launch_conv_mfma16_t<float, 2, 2, 5, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // five n-tiles (80 filters), 16-byte B loads
   else if (nhalf == 24) launch_conv_mfma16_t<float, 2, 2, 3, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // three n-tiles (48 filters)
+  else if (nhalf == 25) launch_conv_mfma16_t<float, 2, 4, 2, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // two n-tiles, register allocation for 4 waves per SIMD
+  else if (nhalf == 26) launch_conv_mfma16_t<float, 2, 4, 1, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // one n-tile, 4 waves per SIMD
+  else if (nhalf == 27) launch_conv_mfma16_t<float, 2, 5, 1, true>(tiles, ntiles, levels, feat, w4u, resp, nf, nfpad, s);   // one n-tile, 5 waves per SIMD
   else if (nhalf == 5) launch_conv_mfma16_t<float, 2, 3, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);        // two n-tiles (32 filters) per workgroup
   else if (nhalf == 6) launch_conv_mfma16_t<float, 2, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);
   else if (nhalf == 7) launch_conv_mfma16_t<float, 1, 2, 2>(tiles, ntiles, levels, feat, wT, resp, nf, nfpad, s);   // whole tile, 32 filters
