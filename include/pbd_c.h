@@ -53,7 +53,9 @@ enum {
  */
 typedef struct pbd_model_desc {
   int32_t nfilters;      /* Model::filters().size()                            */
-  int32_t kh, kw;        /* filter rows / cols (uniform over the bank)         */
+  int32_t kh, kw;        /* filter rows / cols, 1..9, UNIFORM over the bank: the reference allows a size per filter
+                            (include/Parts.hpp:185-187) but every model its tools write is uniform; a mixed bank is
+                            not representable here (the C++ adaptor refuses it with PBD_ERR_UNSUPPORTED)             */
   int32_t flen;          /* Model::flen()  (32)                                */
   int32_t norient;       /* Model::norient() (18)                              */
   int32_t sbin;          /* Model::binsize()                                   */

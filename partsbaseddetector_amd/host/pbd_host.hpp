@@ -287,6 +287,12 @@ class Device {
   Device(Model& m, int device, int conv_mode, int scalar_type = PBD_SCALAR_F32, int max_cand = 4096) {
     pbd_model_desc d{};
     const int kh = m.filters()[0].rows, kw = m.filters()[0].cols / m.flen();
+    // The reference's engine takes a size per filter (src/SpatialConvolutionEngine.cpp:133-159, include/Parts.hpp:185-187); the
+    // C ABI describes a bank by ONE kh x kw (every model the reference's tools write is uniform: matlab/modelTransfer.m): a bank of
+    // mixed sizes is refused here instead of being read with the first filter's size
+    for (Mat& f : m.filters())
+      if (f.rows != kh || f.cols != kw * m.flen())
+        throw Exception(PBD_ERR_UNSUPPORTED, "distributeModel: filters of different sizes in one bank (pbd_model_desc carries one kh x kw)");
     for (Mat& f : m.filters()) filters.insert(filters.end(), f.ptr<float>(), f.ptr<float>() + (size_t)kh * kw * m.flen());
     for (vectorf& w : m.def()) defw.insert(defw.end(), w.begin(), w.begin() + 4);
     for (Point& a : m.anchors()) { anchors.push_back(a.x); anchors.push_back(a.y); }
