@@ -101,7 +101,9 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
   unsigned ob[U];                                        // byte offsets of the cells inside a plane of T (< 2^32, plan_frame)
 #pragma unroll
   for (int u = 0; u < U; ++u) ob[u] = off[u] * (unsigned)sizeof(T);
-  for (int c = 0; c < nch; ++c) {
+  int c = 0;
+  do {                                                   // (a fold job has at least one child: a loop that may run zero times made the
+                                                         // compiler wait, after it, for the children's Ik STORES before the LDS stores)
     const FoldChild& C = J->ch[c];
     // everything the child contributes is fetched up front, in straight-line code: the K planes' values of the U
     // cells (uniform base + 32-bit byte offset: no vector arithmetic per load) and the dense K x L bias block
@@ -134,27 +136,20 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
     unsigned okoff[M];                                   // offset of plane m of the child's Ik planes (uniform).  Columns beyond L repeat column
 #pragma unroll                                           // L - 1 (plan) and land on plane L - 1 again: the same byte stored twice, no predicate
     for (int m = 0; m < M; ++m) okoff[m] = (unsigned)min(m, L - 1) * HW;
-    if (C.K == 1) {
-      // Math::reduceMax's K == 1 shortcut copies (Math.hpp:154-158): maxv = the one weighted map, maxi = 0 (a wave-uniform branch)
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          *(okp + (okoff[m] + offc[u])) = (uint8_t)0;                                    // Ik (:150)
-          acc[u][m] = acc[u][m] + (sd[u][0] + bias[0][m]);                               // DynamicProgram.cpp:139, :156
-        }
-      }
-      continue;
-    }
+    // Math::reduceMax's K == 1 shortcut copies (Math.hpp:154-158): maxv = the one weighted map — NaN and -inf included —,
+    // maxi = 0.  A wave-uniform SELECT at the end, not a branch: a branch here made the compiler wait for plane 0's loads
+    // (the code both sides share) before it issued the loads of the other planes — two memory round trips per child.
+    const bool copy1 = C.K == 1;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       T v[M];
       int bi[M];
+      T w0[M];
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         // k = 0 first: Math::reduceMax starts from -inf and takes strict > (first maximum wins): a NaN score leaves -inf
-        const T w0 = sd[u][0] + bias[0][m];               // DynamicProgram.cpp:139
-        v[m] = w0 > (T)-INFINITY ? w0 : (T)-INFINITY;
+        w0[m] = sd[u][0] + bias[0][m];                    // DynamicProgram.cpp:139
+        v[m] = w0[m] > (T)-INFINITY ? w0[m] : (T)-INFINITY;
         bi[m] = 0;
       }
 #pragma unroll
@@ -173,11 +168,11 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
       for (int m = 0; m < M; ++m) {
         // Ik (:150).  Unpredicated: a lane past the block's last cell works on that cell again (its offset was clamped) and
         // stores the same byte once more
-        *(okp + (okoff[m] + offc[u])) = (uint8_t)bi[m];                // (cells * planes < 2^32, plan_frame)
-        acc[u][m] = acc[u][m] + v[m];                                  // parent.score += maxv (:156), child order kept
+        *(okp + (okoff[m] + offc[u])) = (uint8_t)bi[m];                // (cells * planes < 2^32, plan_frame; K == 1: rows beyond 0 repeat row 0, bi stays 0)
+        acc[u][m] = acc[u][m] + (copy1 ? w0[m] : v[m]);                // parent.score += maxv (:156), child order kept
       }
     }
-  }
+  } while (++c < nch);
 }
 
 // One block = NT lanes (one or two wavefronts) = up to g.lpb lines of one group (lpb chosen per group so that every
@@ -232,6 +227,25 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   const int P = g.P;                             // segments per line (dt_segments(nsub, len))
   if (lane <= P) SEG[lane] = P > 1 ? (int)__umulhi((unsigned)__mul24(lane, len), g.magic_P) : lane * len;   // dt_seg_start(lane, P, len)
   if (lane == 0) { SEG[DT_SEGS - 2] = 0; SEG[DT_SEGS - 1] = len; }
+  const int p = lpb > 1 ? (int)__umulhi((unsigned)lane, g.magic_lpb) : lane, line = lane - __mul24(p, lpb);
+  const bool mine = line < nl && p < nsub;
+  // line -> (map, line of the map): plain: map-major; FOLD: mixture-major inside the block's rows
+  int mi = 0, li = 0;
+  if (mine) {
+    if (FOLD) {
+      const unsigned mrows = nrows > 1 ? (0xFFFFFFFFu / (unsigned)nrows + 1u) : 0u;   // (wave-uniform: scalar arithmetic)
+      mi = nrows > 1 ? (int)__umulhi((unsigned)line, mrows) : line;
+      li = t.g0 + (line - __mul24(mi, nrows));
+    } else {
+      map_line(line, mi, li);
+    }
+  }
+  // the lane's map descriptor (weights, destination, pointer plane): fetched HERE, in front of the loader, so that its memory
+  // round trip overlaps the loader's instead of standing between the loader's barrier and the scan
+  DtMap mp;
+  P2* YZl = YZ + line * S;
+  IT* Bl = B + line * S;
+  if (mine) mp = maps[g.map0 + mi];
   if (!FOLD) __syncthreads();
   DT_STAMP(1);
   if constexpr (FOLD) {
@@ -275,8 +289,8 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 #pragma unroll
       for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int m = 0; m < M; ++m)
-          if (m < L) YZ[m * mstride + slot[u]].x = acc[u][m];
+        for (int m = 0; m < M; ++m)      // (columns beyond L repeat mixture L - 1: the same value stored to its slot once more, no branch)
+          YZ[min(m, L - 1) * mstride + slot[u]].x = acc[u][m];
       }
     }
   } else {
@@ -321,23 +335,6 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   __syncthreads();
   DT_STAMP(2);
 
-  const int p = lpb > 1 ? (int)__umulhi((unsigned)lane, g.magic_lpb) : lane, line = lane - __mul24(p, lpb);
-  const bool mine = line < nl && p < nsub;
-  // line -> (map, line of the map): plain: map-major; FOLD: mixture-major inside the block's rows
-  int mi = 0, li = 0;
-  if (mine) {
-    if (FOLD) {
-      const unsigned mrows = nrows > 1 ? (0xFFFFFFFFu / (unsigned)nrows + 1u) : 0u;   // (wave-uniform: scalar arithmetic)
-      mi = nrows > 1 ? (int)__umulhi((unsigned)line, mrows) : line;
-      li = t.g0 + (line - __mul24(mi, nrows));
-    } else {
-      map_line(line, mi, li);
-    }
-  }
-  DtMap mp;
-  P2* YZl = YZ + line * S;
-  IT* Bl = B + line * S;
-  if (mine) mp = maps[g.map0 + mi];
   // ---- local scans: the envelope of every segment (DistanceTransform.hpp:156-170 on the segment alone) ----
   if (mine && p < P) {
     if (dt_seg_scan<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b)) FLAG[line] = 1;
@@ -406,25 +403,27 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       const bool whole = FLAG[line] != 0;
       int e = dt_cover<T, IT>(YZl, Bl, whole ? SEG + DT_SEGS - 2 : SEG, whole ? 1 : P, BELOW + line, ZLO + line, lpb, os);
       P2 eyz = YZl[e];
-      // the piece below the current one is kept in registers, so stepping to it costs no LDS round trip on the
-      // spot: the read of the piece below THAT overlaps this output's arithmetic.  The bottom of the stack
-      // (z = -inf, linked to itself) ends every walk.
+      // the link below the current piece waits in a register, so a step down issues its two LDS reads (the piece and ITS
+      // link) at once: one round trip per step.  (Rounds 1-3 kept the whole piece below in registers as well — a step then
+      // starts without a wait, but rotating that state costs five register moves per step.  Measured and rejected in round 4:
+      // the read-out as a flat state machine like the scans, one output OR one step per iteration — 0.371 ms per frame
+      // instead of 0.329: most outputs need no step, and the flat form makes every one of them wait for a speculative read.)
+      // The bottom of the stack (z = -inf, linked to itself) ends every walk.
       int nx = (int)Bl[e];
-      P2 nyz = YZl[nx];
-      int nnx = (int)Bl[nx];
       const int nlines = g.nlines;
       GPW(T) dp = (GPW(T))mp.dst + li + (size_t)(q1 - 1) * nlines;      // running output pointers: no 64-bit multiply per element
       GPW(int16_t) ppq = (GPW(int16_t))pp + (size_t)(q1 - 1) * pst;
       const int os_end = mp.os + q0;           // the sub-range's first output (the loop counts the shifted position down to it)
-      for (; os >= os_end;) {
+      ++os;
+      do {                                     // (q0 < q1: at least one output)
+        --os;
         const T fos = (T)os;                   // `z[k+1] < os`: int promoted to T (:174)
-        while (!(eyz.y < fos)) { e = nx; eyz = nyz; nx = nnx; nyz = YZl[nx]; nnx = (int)Bl[nx]; }
-        const int d = os - e;
-        *dp = (T)(a * (double)__mul24(d, d) + b * (double)d + (double)eyz.x);   // |d| < 2^15
+        while (!(eyz.y < fos)) { e = nx; eyz = YZl[e]; nx = (int)Bl[e]; }
+        const double d = (double)(os - e);     // |d| < 2^15: d * d is exact in fp64 (the reference squares the int)
+        *dp = (T)(a * (d * d) + b * d + (double)eyz.x);
         *ppq = (int16_t)e;
         dp -= nlines; ppq -= pst;
-        os--;
-      }
+      } while (os > os_end);
     }
   }
   DT_STAMP(5);

@@ -1,4 +1,8 @@
-"""Ad-hoc probe (not a test): per-block (start, end, CU) trace of every k_dt_pass launch of one person-model frame."""
+"""Ad-hoc probe (not a test): per-block (start, end, CU) trace of every k_dt_pass launch of one person-model frame.
+
+    python tests/tools_dt_trace.py [W H [launch [B]]]     B > 1: a batch of B frames (the first 4096 blocks of every launch are traced;
+                                                          the phase table then covers blocks 1536.., which start on a loaded chip)
+"""
 import os
 os.environ.setdefault("PBD_LIBRARY", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "partsbaseddetector_amd", "libpbd_hip_probes.so"))  # `make -C partsbaseddetector_amd/csrc probes`
 os.environ["PBD_DT_TRACE"] = "1"
@@ -11,10 +15,17 @@ from partsbaseddetector_amd import capi
 from partsbaseddetector_amd.model import make_image, make_person_model
 
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (640, 480)
+NBATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 model = make_person_model(K=6)
 model.thresh = 1e9
 h = capi.Handle(model, conv_mode=capi.PBD_CONV_MFMA, graph=0)
 img = torch.from_numpy(make_image(0, W, H)).cuda()
+frames = [make_image(i, W, H) for i in range(NBATCH)]
+def run():
+    if NBATCH > 1:
+        h.detect_batch(frames, capacity=16)
+    else:
+        h.enqueue_dev(img.data_ptr(), W, H, 3); h.collect(16)
 L = capi.lib()
 NL, NB = 40, 4096
 t = np.zeros((NL, NB, 8), np.uint64)
@@ -23,11 +34,11 @@ nl = C.c_int(0)
 def read():
     L.pbd_debug_dt_trace(t.ctypes.data_as(C.POINTER(C.c_ulonglong)), hw.ctypes.data_as(C.POINTER(C.c_uint)), C.byref(nl))
 for i in range(3):
-    h.enqueue_dev(img.data_ptr(), W, H, 3); h.collect(16)
+    run()
 read()                       # resets the launch counter
 t[:] = 0
 _st = (C.c_ulonglong * 8)(); L.pbd_debug_dt_stamps(_st)     # resets the redo counter
-h.enqueue_dev(img.data_ptr(), W, H, 3); h.collect(16)
+run()
 read()
 st = (C.c_ulonglong * 8)()
 L.pbd_debug_dt_stamps(st)
@@ -56,8 +67,14 @@ if len(sys.argv) > 3:
     names = ["setup", "load", "scan", "stitch", "validate", "readout"]
     order = [0, 1, 2, 3, 6, 4, 5]          # stamp indices in program order
     seg = np.stack([(ph[:, order[i + 1]] - ph[:, order[i]]) / 100.0 for i in range(6)], 1)
-    for b in range(0, nb, 64):
-        print(b, "mean dur %.1f max %.1f |" % (du[b:b + 64].mean(), du[b:b + 64].max()), " ".join(f"{n} {seg[b:b + 64, i].mean():.1f}/{seg[b:b + 64, i].max():.1f}" for i, n in enumerate(names)))
+    BS = 64 if NBATCH == 1 else 512
+    if NBATCH > 1:
+        lo = min(1536, nb // 2)
+        print(f"batch of {NBATCH}: blocks {lo}..{nb - 1} (started on a loaded chip): mean dur %.1f |" % du[lo:].mean(),
+              " ".join(f"{n} {seg[lo:, i].mean():.2f}" for i, n in enumerate(names)), "| blocks 0..%d: mean dur %.1f |" % (lo - 1, du[:lo].mean()),
+              " ".join(f"{n} {seg[:lo, i].mean():.2f}" for i, n in enumerate(names)))
+    for b in range(0, nb, 64 if NBATCH == 1 else 512):
+        print(b, "mean dur %.1f max %.1f |" % (du[b:b + BS].mean(), du[b:b + BS].max()), " ".join(f"{n} {seg[b:b + BS, i].mean():.1f}/{seg[b:b + BS, i].max():.1f}" for i, n in enumerate(names)))
     worst = np.argsort(-du)[:12]
     for b in worst:
         print("slow blk", int(b), "dur %.1f |" % du[b], " ".join(f"{n} {seg[b, i]:.1f}" for i, n in enumerate(names)))
