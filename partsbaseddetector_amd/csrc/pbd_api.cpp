@@ -621,12 +621,17 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   // block geometry, measured on MI355X (profiles/sweep_dt.sh).  float: two wavefronts and 25 KB per
   // block = 6 blocks = 3 wavefronts per SIMD (20 .. 40 KB swept); double (17 B per line element, an IEEE division
   // per intersection): one wavefront and 20 KB = 8 blocks per CU (0.93 ms against 1.28 with the float geometry)
-  h->dt_nt = h->ts == 8 ? 64 : PBD_DT_NT_DEFAULT;
+  // Round 4 (profiles/experiments/README.md, seven frame sizes): while every line of the frame is short enough for byte links
+  // (stride <= 256: 9 B per line element), float blocks of FOUR wavefronts and 40 KB — 4 blocks = 4 wavefronts per SIMD — beat
+  // the two-wavefront / 25 KB blocks by 2-8 % of dp_min in batches (640x480: 0.328 -> 0.314 ms per frame, 0.600 -> 0.581 alone);
+  // with 16-bit links (10 B per element: 1280x720, 1920x1080) they lose 9-12 %, and there the geometry above stays.
+  const bool byte_links = dt_stride_for(maxlen) <= 256;
+  h->dt_nt = h->ts == 8 ? 64 : (byte_links ? 256 : PBD_DT_NT_DEFAULT);
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
   h->dt_nt_x = h->dt_nt;      // lanes of a fold x-pass block
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT_X")) h->dt_nt_x = std::max(64, std::min(256, atoi(e) & ~63));
   if (const char* e = PBD_PROBE_ENV("PBD_DT_SEG")) h->dt_seg = atoi(e);
-  size_t dt_base = (h->ts == 8 ? 20 : 25) * 1024;
+  size_t dt_base = (h->ts == 8 ? 20 : (byte_links ? 40 : 25)) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_B")) dt_base = (size_t)atoi(e);
   int max_mix = 4;
