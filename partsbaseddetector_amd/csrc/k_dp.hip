@@ -4,7 +4,7 @@
 //
 // k_dt_pass   one 1-D generalised distance transform pass (Felzenszwalb &
 //             Huttenlocher upper envelope, DistanceTransform.hpp:151-182) over all
-//             lines of a round: a block = 64 / 128 lanes = the lines that fit its LDS
+//             lines of a round: a block = 64 / 128 / 256 lanes = the lines that fit its LDS
 //             budget, several lanes per line, each scanning one segment of the line;
 //             the segments are stitched into the result of the sequential run
 //             (dt_core.hpp, compiled for the host too: tests/tools/dt_core_test.cpp).
@@ -175,7 +175,7 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
   } while (++c < nch);
 }
 
-// One block = NT lanes (one or two wavefronts) = up to g.lpb lines of one group (lpb chosen per group so that every
+// One block = NT lanes (one, two or four wavefronts) = up to g.lpb lines of one group (lpb chosen per group so that every
 // block of the launch fits the same LDS budget: long lines -> fewer lines per block -> many more blocks).  LDS
 // capacity leaves most lanes without a line of their own, so the NT / lpb lanes that share a line each scan one
 // SEGMENT of it concurrently and the segments are stitched into the sequential result (dt_core.hpp):
@@ -302,7 +302,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     // vector-instruction issue, so an element's (line, position) is worked out ONCE — its LDS address waits in a register
     // for the value (the kernel's occupancy is set by LDS, not by registers) — and the division is a multiply-high.
     const int n = nl * len;
-    constexpr int LB = sizeof(T) == 8 ? 12 : 24;   // loads in flight per lane (a 25 KB block of float lines: <= 22 elements per lane)
+    constexpr int LB = sizeof(T) == 8 ? 12 : 24;   // loads in flight per lane (a 25 KB / 128-lane block of float lines: <= 22 elements per lane; 40 KB / 256 lanes: <= 18)
     if (len > 1) {
       // f / len = umulhi(f, magic), magic = ceil(2^32 / len): exact for f * len < 2^32
       const unsigned magic = 0xFFFFFFFFu / (unsigned)len + 1u;

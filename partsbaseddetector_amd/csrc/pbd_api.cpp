@@ -618,8 +618,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   // DT LDS budget per block unless the longest line needs more at the minimum number of lines per block
   int maxlen = 1;
   for (int l = 0; l < n; ++l) if (h->lv[l].active) maxlen = std::max(maxlen, std::max(h->lv[l].cw, h->lv[l].ch));
-  // block geometry, measured on MI355X (profiles/sweep_dt.sh).  float: two wavefronts and 25 KB per
-  // block = 6 blocks = 3 wavefronts per SIMD (20 .. 40 KB swept); double (17 B per line element, an IEEE division
+  // block geometry, measured on MI355X (profiles/sweep_dt.sh).  float, lines with 16-bit links: two wavefronts and
+  // 25 KB per block = 6 blocks = 3 wavefronts per SIMD (20 .. 40 KB swept); double (17 B per line element, an IEEE division
   // per intersection): one wavefront and 20 KB = 8 blocks per CU (0.93 ms against 1.28 with the float geometry)
   // Round 4 (profiles/experiments/README.md, seven frame sizes): while every line of the frame is short enough for byte links
   // (stride <= 256: 9 B per line element), float blocks of FOUR wavefronts and 40 KB — 4 blocks = 4 wavefronts per SIMD — beat
