@@ -551,11 +551,14 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   const int vw = min(CT, W - t.x0), vh = min(CT, H - t.y0), ncell = vw * vh;
   const int nmt = (ncell + 15) >> 4;                                                        // M-tiles of the tile
   const int mvalid = __builtin_amdgcn_readfirstlane(max(0, min(4, (nmt - wave + 3) >> 2)));   // M-tiles of this wave
+  // c / vw for c < 256, vw <= 16 as a multiply: floor(c * ceil(2^16 / vw) / 2^16) is exact there (error < c (vw - 1) / (vw 2^16) < 1 / vw);
+  // one wave-uniform division for the constant instead of a full 32-bit division sequence per lane and M-tile
+  const unsigned vw_magic = 65535u / (unsigned)vw + 1u;
   int aoff[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int c = min(16 * (wave + 4 * m) + ai, ncell - 1);
-    const int cy = c / vw, cx = c - cy * vw;
+    const int cy = (int)(((unsigned)c * vw_magic) >> 16), cx = c - cy * vw;
     aoff[m] = (cy * TW + cx) * CS + ak;
   }
 
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
   T* tr = ft + wave * (16 * 65);           // per-wave [16 filters][64 cells + 1]
   // lane -> slot (M-tile lane >> 4, row lane & 15) -> packed cell -> (row, column) of the level
   const int pc = 16 * (wave + 4 * (lane >> 4)) + (lane & 15);
-  const int pcy = pc / vw, py = t.y0 + pcy, pxx = t.x0 + (pc - pcy * vw);
+  const int pcy = (int)(((unsigned)pc * vw_magic) >> 16), py = t.y0 + pcy, pxx = t.x0 + (pc - pcy * vw);   // (pc < 256)
   const bool pvalid = pc < ncell;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
@@ -667,9 +670,17 @@ __global__ __launch_bounds__(256, WPE) void k_conv_mfma16(const ConvTile* __rest
 #pragma unroll
       for (int r = 0; r < 4; ++r) tr[ai * 65 + m * 16 + MM::drow(r, ak)] = acc[nt][m][r];   // D[i][j = ai] of M-tile m
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int j = 0; j < 16; ++j) {
-      const int fn = nbase + 16 * nt + j;
-      if (fn < nf && pvalid) R[(size_t)fn * H * W + (size_t)py * W + pxx] = tr[j * 65 + lane];
+    // (plane base wave-uniform, the lane's cell a 32-bit offset: a store is one LDS read + one store instruction, no address
+    // arithmetic per filter — it was seven vector instructions per store)
+    if (pvalid) {
+      const unsigned cellb = (unsigned)(py * W + pxx) * (unsigned)sizeof(T);      // < 2^31 (plan_frame: a level has < 2^28 cells)
+      for (int j = 0; j < 16; ++j) {
+        const int fn = nbase + 16 * nt + j;
+        if (fn < nf) {
+          char* plane = (char*)(R + (size_t)fn * H * W);
+          *(T*)(plane + cellb) = tr[j * 65 + lane];
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
