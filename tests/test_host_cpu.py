@@ -285,3 +285,22 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
            C.sizeof(desc_t), desc_t.biasid.offset, C.sizeof(capi.pbd_candidate_head)]
     assert got == exp, (got, exp)
     assert capi.PBD_SCALAR_F32 == 0 and capi.PBD_SCALAR_F64 == 1
+
+
+def test_kernel_side_exact_divisions_by_multiplication():
+    """The kernels replace integer divisions by wave-uniform divisors with multiply-high / multiply-shift constants
+    (vector issue is what they have least of); the identities they rely on, over the ranges the sources state:
+      * k_conv.hip: c / vw == (c * (65535 / vw + 1)) >> 16  for c < 256, 1 <= vw <= 16 (tile-local cell -> row);
+      * pbd_internal.hpp dt_magic / k_dp.hip: x / d == umulhi(x, 0xFFFFFFFF / d + 1) for x * d < 2^32, d > 1 (lane -> line,
+        element -> line of a block, segment starts)."""
+    for vw in range(1, 17):
+        m = 65535 // vw + 1
+        assert all(((c * m) >> 16) == c // vw for c in range(256)), vw
+    rng = np.random.default_rng(7)
+    for d in list(range(2, 300)) + [511, 4096, 32767]:
+        m = 0xFFFFFFFF // d + 1
+        hi = (1 << 32) // d                      # x * d < 2^32
+        xs = np.unique(np.concatenate([np.arange(0, min(hi, 2000)), rng.integers(0, hi, 2000), np.array([hi - 1, max(hi - d, 0)])]))
+        for x in xs.tolist():
+            assert (x * m) >> 32 == x // d, (x, d)
+
