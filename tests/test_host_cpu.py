@@ -141,7 +141,7 @@ def test_pack_unpack_roundtrip():
 def test_dt_core_host(tmp_path):
     """partsbaseddetector_amd/csrc/dt_core.hpp — the segment-parallel distance transform k_dt_pass compiles — run on
     the host, lanes one after the other, against the oracle's sequential loop (tests/tools/dt_core_test.cpp): random,
-    smooth, quantised (exact ties), sparse-peak, constant and concave lines, 1..16 lanes per line, lengths 1..700,
+    smooth, quantised (exact ties), sparse-peak, constant and concave lines, 1..64 lanes per line, lengths 1..700,
     float and double, every speculative-stitch order; every output and pointer bit-identical."""
     exe = tmp_path / "dt_core_test"
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "partsbaseddetector_amd", "csrc"),

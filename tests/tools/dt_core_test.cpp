@@ -96,10 +96,10 @@ static int sweep(long nlines, unsigned seed) {
   std::vector<T> src(2048), d0(2048), d1(2048);
   std::vector<int32_t> p0(2048), p1(2048);
   static const int lens[] = {1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 33, 40, 59, 64, 79, 80, 100, 118, 119, 158, 159, 200, 254, 255, 300, 478, 700};
-  static const int lanesv[] = {1, 2, 3, 4, 5, 8, 10, 16, 21, 32};
+  static const int lanesv[] = {1, 2, 3, 4, 5, 8, 10, 11, 16, 21, 32, 48, 64};   // lanes per line (a 256-lane block: up to 64)
   for (long it = 0; it < nlines; ++it) {
     const int len = (rng() % 4 == 0) ? 1 + (int)(rng() % 500) : lens[rng() % (sizeof(lens) / sizeof(int))];
-    const int lanes = lanesv[rng() % 10];
+    const int lanes = lanesv[rng() % (sizeof(lanesv) / sizeof(int))];
     const int kind = g_kind >= 0 ? g_kind : (int)(rng() % 8);
     double scale = 1.5;
     for (int i = 0; i < len; ++i) {
