@@ -1,6 +1,7 @@
 // Ad-hoc probe (not a test): statistics of the segment-parallel DT (dt_core.hpp on the host) on response lines read from lines.bin
 // ([int32 nlines, int32 len, float data[nlines * len]]*): scan steps per segment, stitch iterations per boundary, mean and mean-of-max over groups of 64.
-//   g++ -O2 -std=c++17 -ffp-contract=off -I partsbaseddetector_amd/csrc tests/tools/dt_line_stats.cpp -o /tmp/stat
+//   g++ -O2 -std=c++17 -ffp-contract=off -I partsbaseddetector_amd/csrc tests/tools/dt_line_stats.cpp -o /tmp/stat;  /tmp/stat [budget KB [lanes per block]]
+// (tests/tools_dt_line_stats.py dumps the lines from the oracle's responses and runs both block geometries)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -9,18 +10,21 @@ static long g_iter = 0;
 #define DT_COUNT_ITER() (++g_iter)
 #include "dt_core.hpp"
 int main(int argc, char** argv) {
+  const int budget_kb = argc > 1 ? atoi(argv[1]) : 25, NT = argc > 2 ? atoi(argv[2]) : 128;
   FILE* f = fopen("lines.bin", "rb");
+  if (!f) { fprintf(stderr, "lines.bin not found (tests/tools_dt_line_stats.py writes it)\n"); return 1; }
   const double a = -0.02, b = 0.003;
   int hdr[2];
   while (fread(hdr, 4, 2, f) == 2) {
     const int nl = hdr[0], len = hdr[1];
     std::vector<float> data((size_t)nl * len);
-    fread(data.data(), 4, data.size(), f);
-    // block geometry as the kernel: lanes per line from a 25 KB budget
+    if (fread(data.data(), 4, data.size(), f) != data.size()) break;
+    // block geometry as the planner's (pbd_api.cpp dt_lpb_for, plain groups): lines per block from the LDS budget, rounded to use all lanes
     const int S = (len + 1) | 1;
-    int lpb = std::min(128, (int)((25 * 1024 - 1500 - S * 8) / (S * 9)));
-    lpb = std::max(4, 128 / ((128 + lpb - 1) / lpb));
-    const int nsub = 128 / lpb;
+    const int hdr_bytes = 300 + NT * 12;          // dt_hdr_bytes without the per-line part
+    int lpb = std::min(128, (int)((budget_kb * 1024 - hdr_bytes - S * 8) / (S * 9 + 16)));
+    lpb = std::max(4, NT / ((NT + lpb - 1) / lpb));
+    const int nsub = NT / lpb;
     const int P = dt_segments(nsub, len);
     std::vector<DtPair<float>> YZ(S + 2);
     std::vector<uint8_t> B(S + 2);
