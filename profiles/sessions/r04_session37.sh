@@ -3,4 +3,4 @@
 # with hipcc, not part of the product): does the arithmetic hold on the hardware, and what rate does a first kernel reach?
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04s37
-timeout 60 tests/tools/conv_split_probe 640 512 2>&1 | tee gpurun_out/r04s37/probe5.log
+timeout 60 tests/tools/conv_split_probe 640 512 2>&1 | tee gpurun_out/r04s37/probe6.log

@@ -28,6 +28,7 @@ constexpr int TWO = 16, THO = 8;                       // output tile (cells)
 constexpr int TW = TWO + KW - 1, TH = THO + KH - 1;    // halo tile
 constexpr int CSTR = 208;                              // LDS bytes per cell (3 x 64 + 16 of padding)
 
+__device__ int g_probe_nostore = 0;   // diagnostics: 1 = results are stored only where they are NaN (never): what do the stores cost?
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // NTW: 16-filter n-tiles per workgroup; SWAP: filters as the A operand, cells as B — D[filter][cell]: the 16 lanes of a k-group then
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256, NTW > 2 ? 2 : 3) void k_conv_split(const u16* 
       for (int r = 0; r < 4; ++r) {
         const int fn = nbase + 16 * nt + (SWAP ? 4 * g + r : ai);
         const int x = tx0 + (SWAP ? ai : 4 * g + r);
-        if (fn < nf && y < H && x < W) resp[(size_t)fn * H * W + (size_t)y * W + x] = acc[nt][m][r];
+        if (fn < nf && y < H && x < W && (!g_probe_nostore || acc[nt][m][r] != acc[nt][m][r])) resp[(size_t)fn * H * W + (size_t)y * W + x] = acc[nt][m][r];
       }
     }
 }
@@ -283,5 +284,9 @@ int main(int argc, char** argv) {
   RUN("3 products, 5 n-tiles, D[filter][cell]", 2, 5, true);
   RUNB("3 products, 5 n-tiles, B through LDS", 2, 5);
   RUNB("3 products, 10 n-tiles, B through LDS", 2, 10);
+  { const int one = 1; CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_nostore), &one, sizeof(int))); }
+  printf("-- diagnostics: the same kernels without their stores (the error column is meaningless) --\n");
+  RUN("6 products, 5 n-tiles, NO stores", 3, 5, true);
+  RUN("3 products, 5 n-tiles, NO stores", 2, 5, true);
   return 0;
 }
