@@ -113,7 +113,7 @@ def main_group(args):
     model = make_person_model(K=args.mixtures)
     dtype = np.float64 if args.dtype == "f64" else np.float32
     model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).cuda(), W, H, dtype=dtype)
-    conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA}[args.conv]
+    conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA, "split": capi.PBD_CONV_SPLIT}[args.conv]
     g = capi.Group(model, [d for _ in range(S) for d in range(N)], gather=capi.PBD_GATHER_HOST, conv_mode=conv, dtype=dtype, graph=args.graph)
     pinned = [torch.from_numpy(make_image(i, W, H)).pin_memory() for i in range(8)]
     frames = [t.numpy() for t in pinned]
@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--conv", choices=["auto", "exact", "mfma"], default="auto")
+    ap.add_argument("--conv", choices=["auto", "exact", "mfma", "split"], default="auto")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("PBD_INFLIGHT", "3")),
                     help="steps in flight per GPU on independent handles/streams (default 3 handles x batches of 8 frames: "
                          "best measured throughput); 1 = strictly sequential calls (latency mode)")

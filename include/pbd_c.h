@@ -78,13 +78,20 @@ typedef struct pbd_model_desc {
 
 /* ---- options -------------------------------------------------------------- */
 enum {
-  PBD_CONV_AUTO = 0,  /* MFMA filter bank from 16 filters on, any kh x kw (measured faster than the direct
-                         correlation from 26 to 312 filters: profiles/archive/r03b_conv_modes.json), else EXACT     */
+  PBD_CONV_AUTO = 0,  /* banks of fewer than 16 filters: EXACT.  From 16 filters on, any kh x kw: float handles take SPLIT (round 5:
+                         ABI version 4; rounds 3-4: MFMA), double handles MFMA.  Neither is bit-identical to the reference's
+                         summation order (|delta| <= 2e-5 on HOG features, north_star 1e-4): callers who need the reference's
+                         bits ask for PBD_CONV_EXACT.  pbd_get_conv_mode() tells what a handle resolved to.               */
   PBD_CONV_EXACT = 1, /* VALU direct correlation, reference summation order:
                          bit-identical to src/filter.cpp:3899-3922 + pdf+=pdfc */
-  PBD_CONV_MFMA = 2   /* MFMA implicit GEMM (k-ordered fma chain) for any kh x kw: fp32
+  PBD_CONV_MFMA = 2,  /* MFMA implicit GEMM (k-ordered fma chain) for any kh x kw: fp32
                          v_mfma_f32_16x16x4_f32 for float handles, fp64
                          v_mfma_f64_16x16x4_f64 for double handles             */
+  PBD_CONV_SPLIT = 3  /* float handles, any kh x kw (x 32 channels): the fp32 products on the bf16 matrix units through EXACT
+                         three-way splits (x = h + m + l, three bfloat16 of 8 significant bits; the six partial products above
+                         2^-24 relative on v_mfma_f32_32x32x16_bf16, fp32 accumulators): fp32 in, fp32 out, errors of the size of
+                         PBD_CONV_MFMA's, on hardware the vector ALU does not share.  Weights must be finite
+                         and below 3e38 in magnitude (bfloat16's range)                                          */
 };
 /* Scalar type T of the instantiation (src/PartsBasedDetector.cpp:132-133):
  * PartsBasedDetector<float> (src/demo.cpp:85) or PartsBasedDetector<double>
@@ -107,7 +114,12 @@ typedef struct pbd_options {
                             instead of the float ones                          */
   int32_t graph;         /* 1: capture the ~40 launches of a frame into a hipGraph once per frame geometry and
                             replay it (one hipGraphLaunch per frame instead of ~40 launches); 0: eager launches */
-  int32_t reserved[2];   /* [0]: ignored (rounds 1-2: DP level groups on separate streams, removed);
+  int32_t reserved[2];   /* [0]: nms_sz — 0 (default, the reference's state: its call site is commented out,
+                                 src/PartsBasedDetector.cpp:86): no suppression; sz > 0: nonMaximaSuppression(rootv, sz)
+                                 (src/nms.cpp:84-129) of every (level, component) root-score plane ON THE DEVICE between
+                                 min() and argmin(): only roots that are above the threshold AND the strict maximum of
+                                 their (2 sz + 1)^2 neighbourhood (block rule of nms.cpp) are back-tracked and returned
+                                 (ABI version 4; versions <= 3 ignored the slot);
                             [1]: dp_mode — 0: a part's messages are folded by its own x pass wherever the model allows it
                                  (no filter id shared inside a component, <= 8 mixtures per part, <= 8 children per part),
                                  1: the three-kernel structure (x pass, y pass, reduce + accumulated planes) for every model,
@@ -120,8 +132,11 @@ typedef struct pbd_options {
  * or a new entry point, fields are never inserted.  pbd_abi_version() returns the version the LIBRARY was built with;
  * a binding compares it with the header it was compiled against (round 2 inserted `graph` in front of reserved[],
  * which nothing could detect).                                                                                       */
-#define PBD_ABI_VERSION 3
+#define PBD_ABI_VERSION 4
 int pbd_abi_version(void);
+/* Version history: 3 = rounds 3-4.  4 (round 5) = PBD_CONV_AUTO resolves to PBD_CONV_SPLIT for float handles (numerics of
+ * AUTO change in the last bits: rounds 3-4 resolved to PBD_CONV_MFMA, and before that to EXACT for banks other than 5 x 5),
+ * PBD_CONV_SPLIT, pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state.  Struct layouts unchanged.   */
 
 /* ---- output record: include/Candidate.hpp:56-111 --------------------------
  * One candidate = head + max_parts boxes (x, y, width, height as cv::Rect)
@@ -277,6 +292,10 @@ int pbd_set_dp_pointers(pbd_handle* h, int level, int component, int part, int p
  * again only once EVERY plane of the active levels has been handed in.  A caller that caches what is resident on the
  * device (host/pbd_host.hpp: content fingerprints) must drop that knowledge when a flag reads 0.                      */
 int pbd_get_stage_state(const pbd_handle* h, int32_t state[4]);
+/* The filter bank this handle runs (PBD_CONV_EXACT / _MFMA / _SPLIT): what PBD_CONV_AUTO resolved to at pbd_create
+ * (SpatialConvolutionEngine is the reference's only engine, src/PartsBasedDetector.cpp:111; the choice here is numerical:
+ * see the enum).  Negative: error code.                                                                              */
+int pbd_get_conv_mode(const pbd_handle* h);
 /* DynamicProgram<T>::argmin (src/DynamicProgram.cpp:189-255).  With tables handed in and NO min() of this handle on the
  * frame, every pointer table and every root table of the handle's levels must have been provided (PBD_ERR_STATE else). */
 int pbd_dp_argmin(pbd_handle* h, pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,

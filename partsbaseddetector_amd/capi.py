@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("PBD_LIBRARY") or os.path.join(_HERE, "libpbd_hip.so")
 
 PBD_OK, PBD_ERR_ARG, PBD_ERR_UNSUPPORTED, PBD_ERR_CAPACITY, PBD_ERR_HIP, PBD_ERR_STATE, PBD_ERR_RCCL = range(7)
 PBD_GATHER_AUTO, PBD_GATHER_HOST, PBD_GATHER_RCCL = 0, 1, 2
-PBD_CONV_AUTO, PBD_CONV_EXACT, PBD_CONV_MFMA = 0, 1, 2
+PBD_CONV_AUTO, PBD_CONV_EXACT, PBD_CONV_MFMA, PBD_CONV_SPLIT = 0, 1, 2, 3
 PBD_SCALAR_F32, PBD_SCALAR_F64 = 0, 1
 
 EXPORTS = [
@@ -38,9 +38,9 @@ EXPORTS = [
     "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps",
     "pbd_set_root", "pbd_set_root_f64", "pbd_set_dp_pointers", "pbd_get_footprint", "pbd_abi_version",
     "pbd_detect_batch_u8", "pbd_detect_batch_enqueue_u8", "pbd_detect_batch_enqueue_dev_u8", "pbd_detect_batch_collect",
-    "pbd_get_stage_state",
+    "pbd_get_stage_state", "pbd_get_conv_mode",
 ]
-PBD_ABI_VERSION = 3
+PBD_ABI_VERSION = 4
 
 
 class pbd_options(C.Structure):
@@ -94,8 +94,9 @@ class Handle:
     """Owns one pbd_handle (one GPU, one stream)."""
 
     def __init__(self, model, device=0, conv_mode=PBD_CONV_AUTO, max_candidates=4096, dt_correct_ptr=0,
-                 level_begin=0, level_end=0, dp_groups=0, dtype=np.float32, graph=0, dp_mode=0):
+                 level_begin=0, level_end=0, dp_groups=0, dtype=np.float32, graph=0, dp_mode=0, nms_sz=0):
         """dtype: np.float32 = PartsBasedDetector<float>, np.float64 = PartsBasedDetector<double>.
+        nms_sz > 0: score-map NMS of the root planes on the device in front of the back-tracking (pbd_options.reserved[0]).
         dp_mode: 0 = messages folded by the parent's x pass where the model allows it (default), 1 = the
         three-kernel structure (x pass, y pass, reduce) for every model.  dp_groups: ignored (kept for callers)."""
         self.L = lib()
@@ -107,7 +108,7 @@ class Handle:
         self._f64 = self.dtype == np.dtype(np.float64)
         self._ct = C.c_double if self._f64 else C.c_float
         opt = pbd_options(device, conv_mode, max_candidates, dt_correct_ptr, level_begin, level_end,
-                          PBD_SCALAR_F64 if self._f64 else PBD_SCALAR_F32, graph, (C.c_int32 * 2)(0, dp_mode))
+                          PBD_SCALAR_F64 if self._f64 else PBD_SCALAR_F32, graph, (C.c_int32 * 2)(nms_sz, dp_mode))
         self.h = C.c_void_p()
         rc = self.L.pbd_create(C.byref(self.desc), C.byref(opt), C.byref(self.h))
         if rc != PBD_OK:
@@ -117,6 +118,7 @@ class Handle:
             self.h = None
             raise PbdError(rc, msg)
         self.max_parts = self.L.pbd_max_parts(self.h)
+        self.conv_mode = self.L.pbd_get_conv_mode(self.h)      # what PBD_CONV_AUTO resolved to
 
     def close(self):
         if getattr(self, "h", None):

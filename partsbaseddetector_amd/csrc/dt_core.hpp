@@ -76,11 +76,17 @@ DT_HD unsigned dt_min3u(unsigned a, unsigned b, unsigned c) { unsigned m = a < b
 DT_HD unsigned dt_fbits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 #endif
 
-// segment p of P over a line of `len` elements: [dt_seg_start(p), dt_seg_start(p + 1)).  p * len < 2^20 (p <= 32, len < 2^15):
-// a 32-bit division; the kernel evaluates it once per block into a table (seg[0..P]) that the routines below take.
+// segment p of P over a line of `len` elements: [dt_seg_start(p), dt_seg_start(p + 1)).  p * len < 2^21 (p <= P <= 64: 256-lane
+// blocks at 4 lines per block; len < 2^15): a 32-bit division; the kernel evaluates it once per block into a table
+// (seg[0..P], P + 1 <= 65 <= DT_SEGS - 2 entries) that the routines below take.
 DT_HD int dt_seg_start(int p, int P, int len) { return (int)((unsigned)(p * len) / (unsigned)P); }
-// segments actually used for a line: at least 8 elements each (short lines gain nothing from stitching)
-DT_HD int dt_segments(int lanes_per_line, int len) {
+// segments actually used for a line: at least 8 elements each (short lines gain nothing from stitching).  The ONE definition:
+// the planner (pbd_api.cpp: dt_group) bakes its value into every task, the host test calls it directly.
+#ifdef __HIPCC__
+__host__ __device__ inline int dt_segments(int lanes_per_line, int len) {
+#else
+static inline int dt_segments(int lanes_per_line, int len) {
+#endif
   int P = len / 8;
   if (P > lanes_per_line) P = lanes_per_line;
   return P < 1 ? 1 : P;

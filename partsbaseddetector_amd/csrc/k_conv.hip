@@ -18,6 +18,8 @@
 // Both stage a (T+kh-1)x(T+kw-1)-cell feature tile with halo in LDS once per
 // workgroup (border values materialised there) and write plane-major outputs.
 #include <algorithm>
+#include <vector>
+#include <cstring>
 #include "pbd_internal.hpp"
 #include <type_traits>
 

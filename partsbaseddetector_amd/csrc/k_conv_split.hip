@@ -1,0 +1,293 @@
+// k_conv_split.hip — PBD_CONV_SPLIT: SpatialConvolutionEngine::pdf (reference src/SpatialConvolutionEngine.cpp:70-124,
+// Filter2D src/filter.cpp:3879-3924) with the fp32 products carried by the bf16 matrix units through EXACT splits.
+//
+// An fp32 number is the sum of three bfloat16 (8 significant bits each): x = h + m + l, h = RN16(x), m = RN16(x - h),
+// l = RN16(x - h - m), every subtraction exact.  A product of two bfloat16 is exact in an fp32 accumulator; the six partial
+// products above 2^-24 relative (hh, hm, mh, hl, lh, mm) reproduce the fp32 product to fp32's own rounding
+// (tests/tools_split_products_study.py: max error against fp64 3.1e-7 on the person bank, 9.1e-7 for the fp32 MFMA chain of
+// k_conv_mfma16).  Why: fp32 MFMAs execute at the vector ALU's rate (157.3 TF is both peaks), so the bank and the distance
+// transforms queue for one pipe; v_mfma_f32_32x32x16_bf16 runs on the matrix cores at 16x that rate.
+//
+// Implicit GEMM D[filter][cell] = sum over (tap, channel, product) — filters are the MFMA's A operand (rows), cells its B
+// operand (columns): an accumulator register then holds 32 cells of ONE response plane, and a store writes 64-byte row segments
+// without an LDS transpose.
+//   * features: [cell][split][32 channels] bfloat16 in HBM (192 B per cell: k_feat_split, or k_hog's epilogue);
+//   * filters:  [tap][k-step (16 channels)][split][32-filter n-tile][k-group (8 channels)][32 filters][8] bfloat16 — ONE
+//     16-byte load per lane, k-step, split and n-tile, 1 KB contiguous per wavefront (host, once per model; L2-resident);
+//   * a workgroup = NW wavefronts = a 16 x 4 NW cell unit of a ConvTile; every wavefront owns two 32-cell M-tiles x NT
+//     (<= 5) 32-filter n-tiles = up to 160 accumulator registers, ONE wavefront per SIMD (the register file is the
+//     occupancy bound, two workgroups of two wavefronts per CU): per k-step 15 filter loads + 6 LDS reads feed 60 MFMAs of 32
+//     cycles — the operand traffic of a 64 x 160 register block is half the L1's rate where a 32 x 80 block saturates it
+//     (tests/tools/conv_split_probe.hip, round 4: 45 % of the bf16 peak);
+//   * the unit's halo tile sits in LDS as [split][cell][64 B], the four 16-byte channel groups of a cell XOR-swizzled with
+//     bits 2-3 of the cell index: the 16 lanes of a ds_read_b128 lane group read 16 consecutive cells -> 16 different
+//     16-byte bank slots (MI355X_MICROARCH.md, LDS: the lane groups are {0-3, 12-15, 20-27}, ...: the lane -> cell map of an
+//     M-tile is permuted so that each group IS one row of 16 cells);
+//   * the valid cells of a ragged unit are packed into M-tiles (level edges issue no MFMAs for cells that do not exist).
+#include <algorithm>
+#include <vector>
+#include <cstring>
+#include "pbd_internal.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ static inline unsigned bf16_rn_bits(unsigned u) {   // fp32 bits -> bfloat16 bits, round to nearest even (finite, below bfloat16's overflow threshold)
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// ---- features -> three exact bfloat16 parts ([cell][split][32]); one thread = 8 consecutive channels of a cell ----
+__global__ __launch_bounds__(256) void k_feat_split(const float* __restrict__ feat, uint16_t* __restrict__ out, size_t ngroups) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;    // (cell, channel group g = i & 3)
+  if (i >= ngroups) return;
+  const f32x4 a = *(const f32x4*)(feat + i * 8), b = *(const f32x4*)(feat + i * 8 + 4);
+  float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  unsigned part[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float r = v[e];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      part[s][e] = bf16_rn_bits(__float_as_uint(r));
+      r = r - __uint_as_float(part[s][e] << 16);               // exact: the difference has at most 16 (then 8) significant bits
+    }
+  }
+  const size_t cell = i >> 2, g = i & 3;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    u32x4 w;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w[d] = part[s][2 * d] | (part[s][2 * d + 1] << 16);
+    *(u32x4*)(out + (cell * 3 + s) * PBD_FLEN + g * 8) = w;
+  }
+}
+void launch_feat_split(const float* feat, uint16_t* out, size_t ncells, hipStream_t s) {
+  const size_t ngroups = ncells * 4;
+  if (!ngroups) return;
+  hipLaunchKernelGGL(k_feat_split, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, feat, out, ngroups);
+}
+
+// ---- filters -> [tap][k-step][split][n-tile][k-group][32][8] bfloat16 (host) ----
+int conv_split_ntiles(int nf) { return (nf + 31) / 32; }
+void conv_split_filters(const float* filters, int nf, int kh, int kw, std::vector<uint16_t>& out) {
+  const int ntap = kh * kw, NTL = conv_split_ntiles(nf);
+  out.assign((size_t)ntap * 2 * 3 * NTL * 512, 0);
+  for (int fn = 0; fn < nf; ++fn)
+    for (int tap = 0; tap < ntap; ++tap)
+      for (int c = 0; c < PBD_FLEN; ++c) {
+        float r = filters[((size_t)fn * ntap + tap) * PBD_FLEN + c];
+        const int ks = c >> 4, kg = (c >> 3) & 1, e = c & 7;
+        for (int s = 0; s < 3; ++s) {
+          unsigned u; memcpy(&u, &r, 4);
+          const unsigned hb = bf16_rn_bits(u);
+          out[((((size_t)(tap * 2 + ks) * 3 + s) * NTL + fn / 32) * 2 + kg) * 256 + (size_t)(fn % 32) * 8 + e] = (uint16_t)hb;
+          const unsigned back = hb << 16; float hf; memcpy(&hf, &back, 4);
+          r -= hf;                                              // exact
+        }
+      }
+}
+
+// NT: 32-filter n-tiles per workgroup (1..5); NW: wavefronts per workgroup (2: a 16 x 8 half of a ConvTile, 4: the whole 16 x 16 tile)
+// PIN: the K loop's schedule pinned for ONE wavefront per SIMD (see the loop); false: hipcc's own schedule at two wavefronts per SIMD
+template <int NT, int NW, bool PIN>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN ? 1 : 2))) void k_conv_split32(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
+                                                             const uint16_t* __restrict__ feat, const uint16_t* __restrict__ filt,
+                                                             float* __restrict__ resp, int nf, int ntl_bank, int ntile0, int ngroups,
+                                                             int ntiles_total, int kh, int kw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = 4 * NW, NHALVES = 16 / ROWS, NTHR = 64 * NW;
+  const int TW = 16 + kw - 1, TH = ROWS + kh - 1, NC = TW * TH, PLANE = NC * 64;
+  // workgroup -> (tile, role = (half, n-group)): tile position 8 g + x runs on XCD x (the plan pairs horizontal neighbours on that
+  // convention); the roles of a tile share lin % 8 (one XCD: the halves' common halo rows and the n-groups' common tile come from
+  // HBM once) and are dispatched 8 workgroups apart
+  const int R = NHALVES * ngroups;
+  const int lin = blockIdx.x;
+  const int grp = lin / (8 * R), rem = lin - grp * (8 * R);
+  const int tile_i = grp * 8 + (rem & 7), role = rem >> 3;
+  if (tile_i >= ntiles_total) return;
+  const int half = role & (NHALVES - 1), ngroup = role / NHALVES;
+  const ConvTile t = tiles[tile_i];
+  const LevelDev lv = levels[t.level];
+  const int H = lv.ch, W = lv.cw;
+  const int ty0 = t.y0 + ROWS * half, tx0 = t.x0;
+  if (ty0 >= H) return;                                  // the lower half of a tile on the level's last rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint16_t* F = feat + lv.cell_off * (3 * PBD_FLEN);
+  {  // stage the halo tile: 12 16-byte pieces per cell (piece = 4 split + channel group), batches of independent loads; outside the
+     // level: zeros, and 1.0 (0x3F80, exact in bfloat16: part h) in the truncation channel = element 7 of piece 3 (:147-155)
+    const int NPC = NC * 12, oy = ty0 - kh / 2, ox = tx0 - kw / 2;
+    const unsigned magic_tw = 0xFFFFFFFFu / (unsigned)TW + 1u;     // cell / TW = umulhi(cell, magic) (cell * TW < 2^32)
+    constexpr int BATCH = 12;
+    for (int i0 = 0; i0 < NPC; i0 += NTHR * BATCH) {
+      u32x4 v[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int i = min(i0 + j * NTHR + tid, NPC - 1);
+        const int cell = (int)(((unsigned)i * 43691u) >> 19), piece = i - cell * 12;     // i / 12, exact for i < 2^17
+        const int cy = (int)__umulhi((unsigned)cell, magic_tw), cx = cell - cy * TW;
+        const int y = min(max(oy + cy, 0), H - 1), x = min(max(ox + cx, 0), W - 1);
+        v[j] = *(const u32x4*)(F + ((size_t)(y * W + x) * (3 * PBD_FLEN) + piece * 8));
+      }
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int i = i0 + j * NTHR + tid;
+        if (i < NPC) {
+          const int cell = (int)(((unsigned)i * 43691u) >> 19), piece = i - cell * 12;
+          const int cy = (int)__umulhi((unsigned)cell, magic_tw), cx = cell - cy * TW;
+          const int y = oy + cy, x = ox + cx;
+          const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+          const u32x4 border = u32x4{0u, 0u, 0u, piece == 3 ? 0x3F800000u : 0u};
+          const int q = piece & 3;
+          *(u32x4*)(smem + (piece >> 2) * PLANE + cell * 64 + ((q ^ ((cell >> 2) & 3)) << 4)) = inside ? v[j] : border;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // lane -> (cell position inside a 32-cell M-tile, k-group).  ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27},
+  // {4-11, 16-19, 28-31} (+32): positions are dealt so that each group is 16 consecutive positions = one row of a full-width unit
+  const int c = lane & 31, kg = lane >> 5;
+  const int mid = ((c & 15) >= 4 && (c & 15) < 12) ? 1 : 0;
+  const int pos = (c & 15) + 16 * (mid ^ (c >> 4));
+  // packed M-tiles: valid cell number 32 j + pos of the vh x vw valid region, j = wave + NW m (round robin: a ragged unit's
+  // M-tiles spread over the wavefronts); positions past the last cell repeat it (never stored)
+  const int vw = min(16, W - tx0), vh = min(ROWS, H - ty0), ncell = vw * vh;
+  const int nmt = (ncell + 31) >> 5;
+  const int mvalid = __builtin_amdgcn_readfirstlane(max(0, min(2, (nmt - wave + NW - 1) / NW)));
+  const unsigned vw_magic = 65535u / (unsigned)vw + 1u;   // idx / vw for idx < 256 (k_conv_mfma16)
+  int cl0[2], cofs[2];
+  bool cval[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int idx = 32 * (wave + NW * m) + pos;
+    cval[m] = idx < ncell;
+    const int ic = min(idx, ncell - 1);
+    const int cy = (int)(((unsigned)ic * vw_magic) >> 16), cx = ic - cy * vw;
+    cl0[m] = cy * TW + cx;
+    cofs[m] = (ty0 + cy) * W + tx0 + cx;
+  }
+  const int ntb = ntile0 + ngroup * NT;                  // first n-tile of this workgroup
+  f32x16 acc[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][m][r] = 0.f;
+  const uint16_t* bl = filt + (size_t)ntb * 512 + lane * 8;
+  const size_t bs_split = (size_t)ntl_bank * 512, bs_kstep = 3 * bs_split;
+  const int nkstep = 2 * kh * kw;
+
+  auto k_loop = [&](auto mv_tag) {
+    constexpr int MV = decltype(mv_tag)::value;
+    auto load_b = [&](bf16x8 (&b)[NT][3], int kstep) {
+      const uint16_t* p = bl + (size_t)min(kstep, nkstep - 1) * bs_kstep;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt][s] = *(const bf16x8*)(p + s * bs_split + nt * 512);
+    };
+    auto load_a = [&](bf16x8 (&a)[2][3], int tapofs, int ks) {     // tapofs = ti * TW + tj
+#pragma unroll
+      for (int m = 0; m < MV; ++m) {
+        const int cl = cl0[m] + tapofs;
+        const char* p = smem + cl * 64 + (((2 * ks + kg) ^ ((cl >> 2) & 3)) << 4);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[m][s] = *(const bf16x8*)(p + s * PLANE);
+      }
+    };
+    auto mma = [&](const bf16x8 (&a)[2][3], const bf16x8 (&b)[NT][3]) {
+      // products outermost (consecutive MFMAs go to different accumulators: an accumulator is touched every 2 NT instructions)
+      auto sweep = [&](int sa, int sb) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int m = 0; m < MV; ++m) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nt][sb], a[m][sa], acc[nt][m], 0, 0, 0);
+      };
+      sweep(1, 1); sweep(0, 2); sweep(2, 0); sweep(0, 1); sweep(1, 0); sweep(0, 0);
+    };
+    bf16x8 a0[2][3], a1[2][3], b0[NT][3], b1[NT][3];
+    load_b(b0, 0);
+    load_a(a0, 0, 0);
+    int ti = 0, tj = 0;
+    const int ntap = kh * kw;
+#pragma unroll 1
+    for (int tap = 0; tap < ntap; ++tap) {
+      // operands in explicit ping-pong, the schedule pinned: the next k-step's 15 filter loads + 6 LDS reads are ISSUED before this
+      // k-step's 60 MFMAs (1 920 cycles) and waited for after them.  Left alone, hipcc's scheduler sinks every load to just in front
+      // of its first use to save registers (80 VGPRs) — an L2 round trip in front of every other MFMA, with one wavefront per SIMD
+      const int tapofs = ti * TW + tj;
+      load_b(b1, 2 * tap + 1);
+      load_a(a1, tapofs, 1);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      if (++tj == kw) { tj = 0; ++ti; }
+      const int nextofs = tap + 1 < ntap ? ti * TW + tj : tapofs;   // (past the last tap: this tap again, never used)
+      load_b(b0, 2 * tap + 2);
+      load_a(a0, nextofs, 0);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (mvalid == 2) k_loop(std::integral_constant<int, 2>());
+  else if (mvalid == 1) k_loop(std::integral_constant<int, 1>());
+  if (mvalid == 0) return;
+
+  // D[i = filter 32 nt + (r & 3) + 8 (r >> 2) + 4 kg][j = cell pos of M-tile m]
+  float* Rl = resp + lv.cell_off * nf;
+  const size_t HW = (size_t)H * W;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    if (m < mvalid && cval[m]) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float* pl = Rl + (size_t)(32 * (ntb + nt) + 4 * kg) * HW + cofs[m];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int fo = (r & 3) + 8 * (r >> 2);
+          if (32 * (ntb + nt) + 4 * kg + fo < nf) pl[(size_t)fo * HW] = acc[nt][m][r];
+        }
+      }
+    }
+  }
+}
+
+template <int NT, int NW, bool PIN>
+static void launch_conv_split_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                                float* resp, int nf, int ntl_bank, int ntile0, int ngroups, int kh, int kw, hipStream_t s) {
+  constexpr int ROWS = 4 * NW, NHALVES = 16 / ROWS;
+  const size_t lds = (size_t)(16 + kw - 1) * (ROWS + kh - 1) * 192;
+  static LdsOptIn optin;
+  optin.ensure((const void*)k_conv_split32<NT, NW, PIN>, lds);
+  const int grid = (ntiles + 7) / 8 * 8 * NHALVES * ngroups;
+  hipLaunchKernelGGL((k_conv_split32<NT, NW, PIN>), dim3(grid), dim3(64 * NW), lds, s, tiles, levels, feat_split, wS, resp, nf, ntl_bank,
+                     ntile0, ngroups, ntiles, kh, kw);
+}
+template <int NW, bool PIN>
+static void launch_conv_split_nw(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                                 float* resp, int nf, int kh, int kw, hipStream_t s) {
+  // groups of five n-tiles (160 filters: the person bank's 156 in one pass), then the remainder with its own instantiation
+  const int ntl = conv_split_ntiles(nf), full = ntl / 5, rest = ntl - 5 * full;
+  if (full) launch_conv_split_t<5, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 0, full, kh, kw, s);
+  switch (rest) {
+    case 1: launch_conv_split_t<1, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, kh, kw, s); break;
+    case 2: launch_conv_split_t<2, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, kh, kw, s); break;
+    case 3: launch_conv_split_t<3, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, kh, kw, s); break;
+    case 4: launch_conv_split_t<4, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, kh, kw, s); break;
+    default: break;
+  }
+}
+// variant (tuning builds): bit 0: four wavefronts per workgroup (16 x 16 cell units) instead of two (16 x 8: two workgroups per CU);
+// bit 1: hipcc's own K-loop schedule at two wavefronts per SIMD instead of the pinned one
+void launch_conv_split(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                       float* resp, int nf, int kh, int kw, int variant, hipStream_t s) {
+  if (ntiles <= 0) return;
+  if (variant == 1) launch_conv_split_nw<4, true>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 2) launch_conv_split_nw<2, false>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 3) launch_conv_split_nw<4, false>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else launch_conv_split_nw<2, true>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+}

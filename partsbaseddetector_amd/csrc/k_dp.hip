@@ -573,7 +573,8 @@ void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks
 template <typename T, int FM>
 __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, const ReduceBlock* __restrict__ blocks, double thresh,
                                               int* __restrict__ count, CandRec* __restrict__ rec, int capacity,
-                                              const FoldJob* __restrict__ folds, const float* __restrict__ biasw, int rescan) {
+                                              const FoldJob* __restrict__ folds, const float* __restrict__ biasw, int rescan,
+                                              const uint8_t* __restrict__ nms_mask, const char* __restrict__ rootv_base) {
   const ReduceBlock rb = blocks[blockIdx.x];
   const RootJob& J = jobs[rb.job];
   const unsigned cell = rb.cell0 + threadIdx.x;
@@ -582,9 +583,11 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
   int bi = 0;
   const T bias = J.bias;                             // `T bias = root.bias(0)[0]` (:165)
   if (rescan) {
-    // root tables handed in by the caller (pbd_set_root): only the threshold and the compaction are redone
+    // root tables handed in by the caller (pbd_set_root), or the second pass of the score-map NMS option (nms_mask: the local
+    // maxima of every root plane, same element offsets as the rootv planes): only the threshold and the compaction are redone
     v = ((const T*)J.rootv)[cell];
-    if ((double)v > thresh) {
+    const bool keep = !nms_mask || nms_mask[(size_t)((const char*)J.rootv - rootv_base) / sizeof(T) + cell] != 0;
+    if ((double)v > thresh && keep) {
       const int idx = atomicAdd(count, 1);
       if (idx < capacity) { CandRec r; r.level = J.level; r.comp = J.comp; r.y = cell / J.W; r.x = cell - r.y * J.W; rec[idx] = r; }
     }
@@ -634,19 +637,21 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
 
 template <typename T>
 static void launch_root_t(const RootJob* jobs, const ReduceBlock* blocks, int nblocks, double thresh, int* count, CandRec* rec,
-                          int capacity, const FoldJob* folds, const float* biasw, int rescan, int fm, hipStream_t s) {
+                          int capacity, const FoldJob* folds, const float* biasw, int rescan, int fm, const uint8_t* nms_mask,
+                          const char* rootv_base, hipStream_t s) {
   const dim3 g(nblocks), b(256);
-  if (fm <= 1) hipLaunchKernelGGL((k_root<T, 1>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan);
-  else if (fm <= 4) hipLaunchKernelGGL((k_root<T, 4>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan);
-  else if (fm <= 6) hipLaunchKernelGGL((k_root<T, 6>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan);
-  else hipLaunchKernelGGL((k_root<T, PBD_FOLD_MAXMIX>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan);
+  if (fm <= 1) hipLaunchKernelGGL((k_root<T, 1>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan, nms_mask, rootv_base);
+  else if (fm <= 4) hipLaunchKernelGGL((k_root<T, 4>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan, nms_mask, rootv_base);
+  else if (fm <= 6) hipLaunchKernelGGL((k_root<T, 6>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan, nms_mask, rootv_base);
+  else hipLaunchKernelGGL((k_root<T, PBD_FOLD_MAXMIX>), g, b, 0, s, jobs, blocks, thresh, count, rec, capacity, folds, biasw, rescan, nms_mask, rootv_base);
 }
 // fm: largest mixture count of a part (only the fold reads it); blocks: one entry per 256 cells of a job
 void launch_root(const RootJob* jobs, const ReduceBlock* blocks, int nblocks, double thresh, int* count, CandRec* rec,
-                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, int fm, hipStream_t s) {
+                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, int fm, const uint8_t* nms_mask,
+                 const char* rootv_base, hipStream_t s) {
   if (nblocks <= 0) return;
-  if (ts == 8) launch_root_t<double>(jobs, blocks, nblocks, thresh, count, rec, capacity, folds, biasw, rescan, fm, s);
-  else launch_root_t<float>(jobs, blocks, nblocks, thresh, count, rec, capacity, folds, biasw, rescan, fm, s);
+  if (ts == 8) launch_root_t<double>(jobs, blocks, nblocks, thresh, count, rec, capacity, folds, biasw, rescan, fm, nms_mask, rootv_base, s);
+  else launch_root_t<float>(jobs, blocks, nblocks, thresh, count, rec, capacity, folds, biasw, rescan, fm, nms_mask, rootv_base, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -745,10 +750,9 @@ void launch_backtrack(const int* count, const CandRec* rec, int capacity, const 
 // Neubeck & Van Gool block NMS on a score map (reference src/nms.cpp:84-129; dead
 // code there, offered as an optional pre-filter).  One thread per (sz+1)^2 block.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_nms_map(const float* __restrict__ src, int M, int N, int sz,
-                                                uint8_t* __restrict__ dst) {
+template <typename T>
+__device__ __forceinline__ void nms_block(const T* __restrict__ src, int M, int N, int sz, uint8_t* __restrict__ dst, int b) {
   const int nbx = (N + sz) / (sz + 1), nby = (M + sz) / (sz + 1);
-  const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nbx * nby) return;
   const int m = (b / nbx) * (sz + 1), n = (b % nbx) * (sz + 1);
   const int i1 = min(m + sz + 1, M), j1 = min(n + sz + 1, N);
@@ -775,6 +779,25 @@ __global__ __launch_bounds__(64) void k_nms_map(const float* __restrict__ src, i
     }
   if (!any) vnmax = 0;
   if (vcmax > vnmax) dst[(size_t)ci * N + cj] = 255;
+}
+__global__ __launch_bounds__(64) void k_nms_map(const float* __restrict__ src, int M, int N, int sz,
+                                                uint8_t* __restrict__ dst) {
+  nms_block<float>(src, M, N, sz, dst, blockIdx.x * 64 + threadIdx.x);
+}
+// the same on the resident root-score planes of a frame (or batch): blockIdx.y = root job (level, component); the mask plane of
+// a job sits at the element offset of its rootv plane
+template <typename T>
+__global__ __launch_bounds__(64) void k_nms_roots(const RootJob* __restrict__ jobs, const char* __restrict__ rootv_base, int sz,
+                                                  uint8_t* __restrict__ mask) {
+  const RootJob& J = jobs[blockIdx.y];
+  nms_block<T>((const T*)J.rootv, J.H, J.W, sz, mask + (size_t)((const char*)J.rootv - rootv_base) / sizeof(T), blockIdx.x * 64 + threadIdx.x);
+}
+void launch_nms_roots(const RootJob* jobs, int njobs, unsigned maxcells, const char* rootv_base, int ts, int sz, uint8_t* mask, hipStream_t s) {
+  if (njobs <= 0 || maxcells == 0) return;
+  // blocks of a plane <= cells of it (sz >= 1: fewer); one thread per NMS block, lanes past the job's blocks return
+  const dim3 grid((maxcells + 63) / 64, njobs);
+  if (ts == 8) hipLaunchKernelGGL(k_nms_roots<double>, grid, dim3(64), 0, s, jobs, rootv_base, sz, mask);
+  else hipLaunchKernelGGL(k_nms_roots<float>, grid, dim3(64), 0, s, jobs, rootv_base, sz, mask);
 }
 
 void launch_nms_map(const float* src, int rows, int cols, int sz, uint8_t* dst, hipStream_t s) {

@@ -12,6 +12,7 @@
 #include <map>
 #include <new>
 #include "pbd_internal.hpp"
+#include "dt_core.hpp"   // dt_segments: the planner and the kernels share one definition
 
 #define HIPCHK(h, call)                                                                  \
   do {                                                                                   \
@@ -300,6 +301,12 @@ static int upload_model(pbd_handle* h) {
   } else {
     HIPCHK(h, hipMemcpy(h->d_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  if (h->conv_mode == PBD_CONV_SPLIT) {   // the three exact bfloat16 parts of every weight, in the MFMA operand order of k_conv_split32
+    std::vector<uint16_t> wS;
+    conv_split_filters(h->filters.data(), m.nfilters, m.kh, m.kw, wS);
+    HIPCHK(h, hipMalloc((void**)&h->d_wS, wS.size() * sizeof(uint16_t)));
+    HIPCHK(h, hipMemcpy(h->d_wS, wS.data(), wS.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
   // orientation-snap table of the HOG kernel (k_hog.hip): 511 x 511 bytes, computed on the device by the reference's own
   // comparison chain in T
   HIPCHK(h, hipMalloc(&h->d_hog_lut, hog_binlut_bytes()));
@@ -430,7 +437,7 @@ static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget,
   g.lpb = dt_lpb_for(g.stride, len, fold >= 0 ? nmaps : 1, budget, ts, nt, seg, round_lanes);
   // wave-uniform quotients of the block's index arithmetic, as constants (pbd_internal.hpp)
   g.nsub = nt / g.lpb;
-  g.P = std::max(1, std::min(g.nsub, len / 8));          // dt_segments (dt_core.hpp)
+  g.P = dt_segments(g.nsub, len);
   g.chunk = (len + g.nsub - 1) / g.nsub;
   g.magic_lpb = dt_magic((unsigned)g.lpb);
   g.magic_nlines = dt_magic((unsigned)nlines);
@@ -547,8 +554,10 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
     if ((rc = dev_alloc(h, &h->d_feat, feat_bytes))) return rc;
     if ((rc = dev_alloc(h, &h->d_pk, pk_bytes))) return rc;
   }
+  if (h->conv_mode == PBD_CONV_SPLIT && (rc = dev_alloc(h, &h->d_feat_split, cells * 3 * PBD_FLEN))) return rc;
   if ((rc = dev_alloc(h, &h->d_rootv, cells * m.ncomponents * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_rooti, cells * m.ncomponents))) return rc;
+  if (h->nms_sz > 0 && (rc = dev_alloc(h, &h->d_nms_mask, cells * m.ncomponents))) return rc;
 
   std::vector<LevelDev> ld(n);
   for (int l = 0; l < n; ++l) {
@@ -914,6 +923,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   if ((rc = dev_upload(h, &h->d_redblocks, redblk))) return rc;
   h->n_rootjobs = (int)rj.size();
   h->root_cells = rcells;
+  h->root_maxcells = 0;
+  for (const RootJob& J : rj) h->root_maxcells = std::max(h->root_maxcells, (unsigned)J.H * (unsigned)J.W);
   if ((rc = dev_upload(h, &h->d_rootjobs, rj))) return rc;
   h->n_rootblocks = (int)rootblk.size();
   if ((rc = dev_upload(h, &h->d_rootblocks, rootblk))) return rc;
@@ -940,7 +951,8 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
   }
   LAUNCHCHK(h, "image pyramid");
   h->have_pyr = true;
-  if (h->compact) h->have_dp = false;   // the level images + features share their memory with the Ik planes / the x pass's scratch
+  if (h->compact) h->have_dp = h->min_ran = false;   // the level images + features share their memory with the Ik planes / the x pass's scratch:
+                                                     // the previous min()'s tables are gone (a plane handed in later is then NOT on top of a min())
   return PBD_OK;
 }
 
@@ -949,13 +961,18 @@ static int run_hog(pbd_handle* h) {
   LAUNCHCHK(h, "HOG");
   h->have_feat = true;
   compact_mark_feat(h, true);
-  if (h->compact) h->have_dp = false;
+  if (h->compact) h->have_dp = h->min_ran = false;
   return PBD_OK;
 }
 
 static int run_pdf(pbd_handle* h) {
   const pbd_model_desc& m = h->md;
-  if (h->conv_mode == PBD_CONV_MFMA)
+  if (h->conv_mode == PBD_CONV_SPLIT) {
+    // the features' three exact bfloat16 parts (a pass over 25 MB per frame), then the bank on the bf16 matrix units
+    launch_feat_split((const float*)h->d_feat, h->d_feat_split, h->cells, h->stream);
+    static const int svariant = PBD_PROBE_ENV("PBD_SPLIT_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_SPLIT_VARIANT")) : 0;   // tuning builds
+    launch_conv_split(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat_split, h->d_wS, (float*)h->d_resp, m.nfilters, m.kh, m.kw, svariant, h->stream);
+  } else if (h->conv_mode == PBD_CONV_MFMA)
     if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT,
                                          (const double*)h->d_wT + (size_t)m.kh * m.kw * m.flen * h->nfpad + m.flen, (double*)h->d_resp, m.nfilters, h->nfpad, m.kh, m.kw, h->stream);
     else {
@@ -990,6 +1007,14 @@ static int run_pdf(pbd_handle* h) {
   return PBD_OK;
 }
 
+// pbd_options.reserved[0] = sz > 0: nonMaximaSuppression(rootv, sz) of every (level, component) plane on the device, then the hits
+static void nms_and_rescan(pbd_handle* h) {
+  hipMemsetAsync(h->d_nms_mask, 0, h->cells * (size_t)h->md.ncomponents, h->stream);
+  launch_nms_roots(h->d_rootjobs, h->n_rootjobs, h->root_maxcells, h->d_rootv, h->ts, h->nms_sz, h->d_nms_mask, h->stream);
+  launch_root(h->d_rootjobs, h->d_rootblocks, h->n_rootblocks, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
+              h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 1, h->fold_mix, h->d_nms_mask, h->d_rootv, h->stream);
+}
+
 static int run_dp_min(pbd_handle* h) {
   const bool dpt = h->profiling && h->dp_timer_on;
   if (dpt) hipEventRecord(h->ev_dp0, h->stream);
@@ -1003,8 +1028,16 @@ static int run_dp_min(pbd_handle* h) {
       launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
   }
   hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
+  if (h->nms_sz > 0) {
+    // score-map NMS in front of the back-tracking (src/nms.cpp:84-129; the reference's call site is commented out,
+    // src/PartsBasedDetector.cpp:86): the root tables are written with no hit (threshold +inf), the block NMS runs on the
+    // resident rootv planes, and the hit list is then compacted from (score > thresh) AND (local maximum)
+    launch_root(h->d_rootjobs, h->d_rootblocks, h->n_rootblocks, INFINITY, h->d_cand_count, h->d_cand_rec,
+                h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 0, h->fold_mix, nullptr, nullptr, h->stream);
+    nms_and_rescan(h);
+  } else
   launch_root(h->d_rootjobs, h->d_rootblocks, h->n_rootblocks, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
-              h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 0, h->fold_mix, h->stream);
+              h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 0, h->fold_mix, nullptr, nullptr, h->stream);
   if (dpt) hipEventRecord(h->ev_dp1, h->stream);
   h->dp_timed = dpt;
   LAUNCHCHK(h, "DP min");
@@ -1023,8 +1056,10 @@ static int run_dp_min(pbd_handle* h) {
 static int run_argmin_enqueue(pbd_handle* h) {
   if (h->root_dirty) {   // root tables injected since min(): the hits are those of the tables now on the device
     hipMemsetAsync(h->d_cand_count, 0, sizeof(int), h->stream);
+    if (h->nms_sz > 0) nms_and_rescan(h);
+    else
     launch_root(h->d_rootjobs, h->d_rootblocks, h->n_rootblocks, (double)h->md.thresh, h->d_cand_count, h->d_cand_rec,
-                h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 1, h->fold_mix, h->stream);
+                h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 1, h->fold_mix, nullptr, nullptr, h->stream);
     h->root_dirty = false;
   }
   launch_backtrack(h->d_cand_count, h->d_cand_rec, h->opt.max_candidates, h->d_back, h->md.ncomponents, h->d_parent,
@@ -1205,6 +1240,8 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   h->ts = (o.scalar_type == PBD_SCALAR_F64) ? 8 : 4;
   int rc = ingest_model(h, model);
   if (rc) return rc;
+  if (o.reserved[0] < 0 || o.reserved[0] > 1024) return fail(h, PBD_ERR_ARG, "reserved[0] (nms_sz): 0 = off, or the window of the score-map NMS");
+  h->nms_sz = o.reserved[0];
   h->conv_mode = o.conv_mode;
   if (h->conv_mode == PBD_CONV_AUTO)
     // measured on MI355X for N = 26 .. 312 5x5x32 filters at 640x480 (profiles/archive/r03b_conv_modes.json): the fp32 MFMA
@@ -1212,7 +1249,20 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
     // 312: 0.76 vs 2.89) — the contraction is K = 800 deep whatever N is, so one 16-filter n-tile already pays.
     // The VALU kernel remains the bit-exact parity path (PBD_CONV_EXACT) and what banks of fewer than 16 filters get.
     // Any filter size goes the same way (3x3 .. 9x9: the contraction is kh * kw * 32 >= 288 deep; run-time tap loop of the same kernel).
-    h->conv_mode = model->nfilters >= 16 ? PBD_CONV_MFMA : PBD_CONV_EXACT;
+    // Round 5: float handles take the split-product bank (k_conv_split.hip: the fp32 products as six exact bfloat16 partial
+    // products on the bf16 matrix units, fp32 accumulators — errors of the fp32 MFMA chain's size, 2-3x its speed, and off the
+    // vector ALU's pipe); a weight outside bfloat16's finite range (|w| >= 3e38: no trained model) keeps the fp32 MFMA bank.
+    {
+      bool splittable = h->ts == 4 && model->flen == PBD_FLEN;
+      for (size_t i = 0; splittable && i < h->filters.size(); ++i) splittable = std::fabs(h->filters[i]) < 3.0e38f;
+      h->conv_mode = model->nfilters >= 16 ? (splittable ? PBD_CONV_SPLIT : PBD_CONV_MFMA) : PBD_CONV_EXACT;
+    }
+  if (h->conv_mode == PBD_CONV_SPLIT && (h->ts != 4 || model->flen != PBD_FLEN))
+    return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_SPLIT: float handles (32-channel HOG features)");
+  if (h->conv_mode == PBD_CONV_SPLIT)
+    for (size_t i = 0; i < h->filters.size(); ++i)
+      if (!(std::fabs(h->filters[i]) < 3.0e38f)) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_SPLIT: a filter weight outside bfloat16's finite range");
+  if (h->conv_mode < PBD_CONV_AUTO || h->conv_mode > PBD_CONV_SPLIT) return fail(h, PBD_ERR_ARG, "conv_mode: PBD_CONV_*");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(h, PBD_ERR_HIP, "no HIP device visible");
   if (o.device < 0 || o.device >= ndev) return fail(h, PBD_ERR_ARG, "bad device ordinal");
@@ -1229,7 +1279,7 @@ int pbd_destroy(pbd_handle* h) {
   if (!h) return PBD_ERR_ARG;
   if (h->stream) hipStreamSynchronize(h->stream);
   free_frame(h);
-  hipFree(h->d_wT); hipFree(h->d_biasw); hipFree(h->d_hog_lut); hipFree(h->d_parent); hipFree(h->d_plane0); hipFree(h->d_nparts);
+  hipFree(h->d_wT); hipFree(h->d_wS); hipFree(h->d_biasw); hipFree(h->d_hog_lut); hipFree(h->d_parent); hipFree(h->d_plane0); hipFree(h->d_nparts);
   hipFree(h->d_flat); hipFree(h->d_depth);
   hipFree(h->d_cand_count); hipFree(h->d_cand_rec); hipFree(h->d_cand_out);
   if (h->h_cand_out) hipHostFree(h->h_cand_out);
@@ -1465,7 +1515,7 @@ static int set_level_features_(pbd_handle* h, int level, const void* in, int ts)
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->d_feat + L.cell_off * PBD_FLEN * ts, in, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyHostToDevice));
   if (h->compact) {   // the write went over the Ik planes / the x pass's scratch; the other levels may still be stale
-    h->have_dp = false;
+    h->have_dp = h->min_ran = false;
     if (h->feat_ok.size() != (size_t)h->nvl) compact_mark_feat(h, false);
     h->feat_ok[level] = 1;
     h->have_feat = all_active_set(h, h->feat_ok, 1);
@@ -1672,6 +1722,11 @@ int pbd_set_dp_pointers(pbd_handle* h, int level, int component, int part, int p
   HIPCHK(h, hipMemcpy(h->d_exty + eo, ys.data(), HW * 2, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_pk + eo, ks.data(), HW, hipMemcpyHostToDevice));
   h->ext_ptr = true;
+  if (h->compact) {   // d_pk is the memory of the level images + features (and the first call's d_extx / d_exty allocation moved nothing, but the
+                      // Ik write above went over them): pyramid() -> set_dp_pointers -> pdf() must not run on clobbered features
+    h->have_pyr = h->have_feat = false;
+    compact_mark_feat(h, false);
+  }
   if (h->ext_set.size() != (size_t)h->nvl * std::max(h->nplanes, 1)) h->ext_set.assign((size_t)h->nvl * std::max(h->nplanes, 1), 0);
   h->ext_set[(size_t)level * std::max(h->nplanes, 1) + P.plane0 + parent_mix] = 1;
   // with a min() of this handle behind them the planes not handed in keep its tables; without one, back-tracking may only
@@ -1686,6 +1741,7 @@ int pbd_get_footprint(const pbd_handle* h, size_t* frame_bytes, size_t* model_by
   return PBD_OK;
 }
 int pbd_abi_version(void) { return PBD_ABI_VERSION; }
+int pbd_get_conv_mode(const pbd_handle* h) { return h ? h->conv_mode : PBD_ERR_ARG; }   // what PBD_CONV_AUTO resolved to
 int pbd_get_stage_state(const pbd_handle* h, int32_t state[4]) {
   if (!h || !state) return PBD_ERR_ARG;
   state[0] = h->have_pyr; state[1] = h->have_feat; state[2] = h->have_resp; state[3] = h->have_dp;
@@ -1726,13 +1782,16 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   DtMap maps[2] = {dt_map(d_in, d_tmp, d_ixT, 0.f, 0.f, osx, 1), dt_map(d_tmp, d_sdt, d_iy, 0.f, 0.f, osy, 0)};
   maps[0].a = ax; maps[0].b = bx; maps[0].r2a = 1.0 / (2.0 * ax);   // the caller's quadratics (not the model's -w)
   maps[1].a = ay; maps[1].b = by; maps[1].r2a = 1.0 / (2.0 * ay);
-  h->dt_nt = tsz == 8 ? 64 : PBD_DT_NT_DEFAULT;
-  if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
+  // block size of THIS call's two launches: a local — the handle's dt_nt belongs to the frame plan, whose uploaded tasks carry
+  // the geometry derived from it (nsub, P, chunk); overwriting it here made a detect() after a pbd_dt2d launch 128-lane blocks
+  // over 256-lane tasks
+  int nt = tsz == 8 ? 64 : PBD_DT_NT_DEFAULT;
+  if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) nt = std::max(64, std::min(256, atoi(e) & ~63));
   size_t dt_base = 40 * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
-  const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 4, tsz, h->dt_nt));
+  const size_t budget = std::max<size_t>(dt_base, dt_lds_bytes(dt_stride_for(std::max(rows, cols)), 4, tsz, nt));
   if (budget > 160 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "map too large for the LDS-resident distance transform");
-  DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz, h->dt_nt, h->dt_seg), dt_group(1, 1, cols, rows, budget, tsz, h->dt_nt, h->dt_seg)};
+  DtGroup groups[2] = {dt_group(0, 1, rows, cols, budget, tsz, nt, h->dt_seg), dt_group(1, 1, cols, rows, budget, tsz, nt, h->dt_seg)};
   std::vector<DtTask> tasks;
   dt_add_tasks(groups[0], tasks);
   const int nx = (int)tasks.size();
@@ -1743,9 +1802,9 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
-  launch_dt_pass(d_tasks, nx, d_maps, nullptr, h->d_biasw, budget, tsz, h->dt_nt, 0, h->stream);
+  launch_dt_pass(d_tasks, nx, d_maps, nullptr, h->d_biasw, budget, tsz, nt, 0, h->stream);
   if (PBD_PROBE_ENV("PBD_DEBUG_SKIP_Y")) { hipMemsetAsync(d_sdt, 0, HW * ts, h->stream); hipMemsetAsync(d_iy, 0, HW * 2, h->stream); }   // probe build: leave the x pass as the last DT launch (its stamps are then readable)
-  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_maps, nullptr, h->d_biasw, budget, tsz, h->dt_nt, 0, h->stream);
+  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_maps, nullptr, h->d_biasw, budget, tsz, nt, 0, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_sdt, HW * ts, hipMemcpyDeviceToHost, h->stream));   // the y pass's scores, untouched
   HIPCHK(h, hipMemcpyAsync(hx.data(), d_ixT, HW * 2, hipMemcpyDeviceToHost, h->stream));   // the passes' own pointers

@@ -183,6 +183,8 @@ struct pbd_handle {
   uint8_t* d_img = nullptr; size_t img_cap = 0;
   uint8_t* d_pyr = nullptr;
   char* d_feat = nullptr; char* d_resp = nullptr; char* d_acc = nullptr;   // T data, addressed in bytes (elements * ts)
+  uint16_t* d_feat_split = nullptr;   // PBD_CONV_SPLIT: the features as [cell][3 splits][32 channels] bfloat16 (per frame plan)
+  uint16_t* d_wS = nullptr;           // PBD_CONV_SPLIT: the filters as [tap][2 k-steps][3 splits][n-tile][2 k-groups][32][8] bfloat16 (per model)
   uint8_t* d_pk = nullptr;
   unsigned long long* d_scr_base = nullptr;   // [nlevels][nflat parts] element offset of mixture 0's DT planes (ix / iy / sdt)
   std::vector<unsigned long long> scr_base;   // host copy (pbd_get_dp_pointers)
@@ -211,7 +213,9 @@ struct pbd_handle {
   int dt_seg = 0;                                    // target segment length of the DT scans (0: as many lines per block as fit)
   int xcd_chunk = 16;                                // consecutive k_dt_pass tasks kept on one XCD (0: table order)
   std::vector<RoundLaunch> rl;
-  int n_rootjobs = 0; unsigned root_cells = 0;
+  int n_rootjobs = 0; unsigned root_cells = 0, root_maxcells = 0;
+  int nms_sz = 0;                 // pbd_options.reserved[0]: window of the score-map NMS in front of the back-tracking (0: off, the reference's state)
+  uint8_t* d_nms_mask = nullptr;  // [cells * ncomponents]: local maxima of the root planes (same element offsets as d_rootv)
   ReduceBlock* d_rootblocks = nullptr; int n_rootblocks = 0;   // k_root: one 256-thread block per 256 cells of a root job
   // candidates
   int* d_cand_count = nullptr; CandRec* d_cand_rec = nullptr;
@@ -299,6 +303,11 @@ void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const 
 size_t hog_lds_bytes(int sbin, int tc, int ts);
 size_t hog_binlut_bytes();                                        // orientation-snap table: best_o for every (dx, dy) in [-255, 255]^2
 void launch_hog_binlut(uint8_t* lut, int ts, hipStream_t s);      // evaluated in T (ts = sizeof(T)) with the reference's own chain (k_hog.hip)
+// split-product filter bank (k_conv_split.hip): fp32 features -> three exact bfloat16 parts; kh x kw x 32 filters, float responses
+void launch_feat_split(const float* feat, uint16_t* out, size_t ncells, hipStream_t s);
+void launch_conv_split(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                       float* resp, int nf, int kh, int kw, int variant, hipStream_t s);
+void conv_split_filters(const float* filters, int nf, int kh, int kw, std::vector<uint16_t>& out);   // host: the d_wS layout
 void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const void* feat,
                        const void* wT, void* resp, int ts, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
@@ -316,7 +325,9 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt);
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
                    int ts, hipStream_t s);
 void launch_root(const RootJob* jobs, const ReduceBlock* blocks, int nblocks, double thresh, int* count, CandRec* rec,
-                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, int fm, hipStream_t s);
+                 int capacity, int ts, const FoldJob* folds, const float* biasw, int rescan, int fm, const uint8_t* nms_mask,
+                 const char* rootv_base, hipStream_t s);
+void launch_nms_roots(const RootJob* jobs, int njobs, unsigned maxcells, const char* rootv_base, int ts, int sz, uint8_t* mask, hipStream_t s);
 void launch_backtrack(const int* count, const CandRec* rec, int capacity, const BackLevel* back, int ncomp,
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
                       char* out, size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,

@@ -107,6 +107,53 @@ def test_pdf_mfma_tolerance(gpu_required, orc):
     assert _pdf_case(orc, capi.PBD_CONV_MFMA, 9, 5, 14) < 2e-5  # 45 filters: padded N
 
 
+def test_pdf_split_products_tolerance(gpu_required, orc):
+    """PBD_CONV_SPLIT: the fp32 products through exact three-way bfloat16 splits on the bf16 matrix units (six partial products,
+    fp32 accumulators): the same tolerance as the fp32 MFMA bank against the oracle's tap-ordered sums."""
+    assert _pdf_case(orc, capi.PBD_CONV_SPLIT, 5, 4, 13) < 2e-5
+    assert _pdf_case(orc, capi.PBD_CONV_SPLIT, 9, 5, 14) < 2e-5  # 45 filters: padded N
+
+
+def test_pdf_split_products_all_levels_and_borders(gpu_required, orc):
+    """every level of several pyramids (1x1 cells up, partial tiles on both edges, lower tile halves past the last row, a partial
+    n-tile group: 37 and 97 filters) — borders included: the truncation channel's 1 outside the level is exact in bfloat16."""
+    for nfilt in (37, 97):
+        m = make_tree_model([-1] + [0] * (nfilt - 1), 1, seed=77)
+        h = capi.Handle(m, conv_mode=capi.PBD_CONV_SPLIT)
+        for i, (w, hh) in enumerate([(70, 50), (131, 97), (260, 200), (83, 300)]):
+            h.pyramid(make_image(300 + i, w, hh))
+            g = h._geo
+            h.pdf()
+            for l in range(g["nlevels"]):
+                if g["cell_w"][l] == 0 or g["cell_h"][l] == 0:
+                    continue
+                ref = orc.pdf_level(h.level_features(l), m.filtersw)
+                for n in sorted({0, 15, 16, 31, 32, 36, nfilt - 1}):
+                    assert np.abs(h.level_response(l, n) - ref[n]).max() < 2e-5, (nfilt, w, hh, l, n)
+        h.close()
+
+
+def test_detect_split_products_matches_the_mfma_bank(gpu_required):
+    """end to end on the person model: the same candidates as the fp32 MFMA bank, root scores within 1e-4 (north_star)"""
+    from partsbaseddetector_amd.model import make_person_model
+    m = make_person_model(K=6)
+    im = make_image(5, 320, 240)
+    ha, hb = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA), capi.Handle(m, conv_mode=capi.PBD_CONV_SPLIT)
+    ha.pyramid(im); ha.pdf(); ha.dp_min()
+    g = ha._geo
+    vals = np.concatenate([ha.root(l, 0)[0].ravel() for l in range(g["nlevels"]) if g["cell_w"][l] and g["cell_h"][l]])
+    ha.close(); hb.close()
+    m.thresh = float(np.percentile(vals, 99.5))
+    ha, hb = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA), capi.Handle(m, conv_mode=capi.PBD_CONV_SPLIT)
+    a, b = ha.detect(im, capacity=16384), hb.detect(im, capacity=16384)
+    ka = {(int(r["level"]), int(r["component"]), tuple(int(v) for v in l[0])): float(r["score"]) for r, l in zip(a[0], a[2])}
+    kb = {(int(r["level"]), int(r["component"]), tuple(int(v) for v in l[0])): float(r["score"]) for r, l in zip(b[0], b[2])}
+    common = set(ka) & set(kb)
+    assert len(common) >= 0.98 * max(len(ka), len(kb)) and len(common) > 50          # (threshold straddlers may differ)
+    assert max(abs(ka[k] - kb[k]) for k in common) < 1e-4
+    ha.close(); hb.close()
+
+
 @pytest.mark.parametrize("variant", [3, 5, 10, 18, 21])
 def test_pdf_mfma_tuning_variants(gpu_required, variant):
     """The filter-bank kernels kept behind PBD_MFMA_VARIANT (tuning build only: one n-tile / 4-byte B loads / the persistent and
