@@ -114,7 +114,9 @@ def main_group(args):
     dtype = np.float64 if args.dtype == "f64" else np.float32
     model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).cuda(), W, H, dtype=dtype)
     conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA, "split": capi.PBD_CONV_SPLIT}[args.conv]
-    g = capi.Group(model, [d for _ in range(S) for d in range(N)], gather=capi.PBD_GATHER_HOST, conv_mode=conv, dtype=dtype, graph=args.graph)
+    # every device listed S times (S frames in flight per device: host gather — RCCL wants distinct devices); S = 1: the RCCL all-gather
+    # when librccl loads and N > 1 (PBD_GATHER_AUTO), and the line says which one ran and on how many ranks
+    g = capi.Group(model, [d for _ in range(S) for d in range(N)], gather=capi.PBD_GATHER_HOST if S > 1 else capi.PBD_GATHER_AUTO, conv_mode=conv, dtype=dtype, graph=args.graph)
     pinned = [torch.from_numpy(make_image(i, W, H)).pin_memory() for i in range(8)]
     frames = [t.numpy() for t in pinned]
     t0 = time.perf_counter()
@@ -133,6 +135,7 @@ def main_group(args):
                        "frames_per_step_per_gpu": 1, "inflight": S, "input": "pinned host images (H2D inside the timed region)",
                        "parallelism": f"pbd_group: one process, {N} device(s) x {S} members", "prewarm_frames": nwarm,
                        "group_size": g.size, "gather_mode": {capi.PBD_GATHER_HOST: "host", capi.PBD_GATHER_RCCL: "rccl"}.get(g.gather_mode, g.gather_mode),
+                       "rccl_comm_size": g.comm_size, "frames_total": args.steps * N,
                        "devices": [{"device": d, "name": torch.cuda.get_device_properties(d).name,
                                     "pci_bus_id": getattr(torch.cuda.get_device_properties(d), "pci_bus_id", None),
                                     "uuid": str(getattr(torch.cuda.get_device_properties(d), "uuid", "")) or None} for d in range(N)],
@@ -172,12 +175,13 @@ def main():
     ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU-side smoke runs)")
     ap.add_argument("--legs", default="all",
-                    help="comma-separated subset of timed,h2d,single,seq,batchseq,cpu (default all).  timed = the K steps `value` is quoted "
+                    help="comma-separated subset of timed,h2d,mfma32,single,seq,batchseq,cpu (default all).  timed = the K steps `value` is quoted "
                          "on; h2d = the same with pinned host images; single = the handles fed one frame per call; seq = sequential "
-                         "single frames with stage events; batchseq = batches one at a time with stage events (`roofline`); cpu = the "
+                         "single frames with stage events; batchseq = batches one at a time with stage events (`roofline`); mfma32 = the "
+                         "timed leg once more on handles with the fp32 MFMA filter bank (`value_fp32_mfma`, N = 1, when the timed handles run the split bank); cpu = the "
                          "oracle on the host cores.  Without `timed` the line's value is null (profiling runs)")
     args = ap.parse_args()
-    ALL_LEGS = ("timed", "h2d", "single", "seq", "batchseq", "cpu")
+    ALL_LEGS = ("timed", "h2d", "mfma32", "single", "seq", "batchseq", "cpu")
     legs = set(ALL_LEGS) if args.legs == "all" else set(x for x in args.legs.split(",") if x)
     if legs - set(ALL_LEGS):
         raise SystemExit(f"--legs: unknown leg(s) {sorted(legs - set(ALL_LEGS))}; choose from {ALL_LEGS}")
@@ -217,7 +221,7 @@ def main():
 
     W, H = args.width, args.height
     model = make_person_model(K=args.mixtures)
-    conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA}[args.conv]
+    conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA, "split": capi.PBD_CONV_SPLIT}[args.conv]
     dtype = np.float64 if args.dtype == "f64" else np.float32
     # distinct frames per rank and per step slot (32 seeds as in configs[2]); resident in HBM and, for the
     # H2D-inclusive leg, in pinned host memory
@@ -240,7 +244,9 @@ def main():
     if by_levels:   # SURVEY 8e / configs[3]: one frame, levels spread over the ranks by greedy LPT on the cell counts
         from partsbaseddetector_amd.parallel import shard_levels_lpt
         g = handles[0].geometry(W, H)
-        my_levels = shard_levels_lpt((g["cell_w"].astype(np.int64) * g["cell_h"]).tolist(), world)[rank]
+        level_cells = (g["cell_w"].astype(np.int64) * g["cell_h"]).tolist()
+        level_sets = shard_levels_lpt(level_cells, world)
+        my_levels = level_sets[rank]
         for hd in handles:
             hd.set_levels(my_levels)
 
@@ -347,6 +353,22 @@ def main():
     # ---- the same K steps handing over pinned host images: H2D inside every step ----
     if "h2d" in legs:
         dt_h2d, _, per_frame_ms_h2d = timed(args.steps, host=True)
+    # ---- the timed leg once more with the fp32 MFMA filter bank (rounds 3-4's default) beside the split-product bank: same frames,
+    #      same steps (bounded), fresh handles; N = 1 only ----
+    CONV_NAMES = {capi.PBD_CONV_EXACT: "exact (VALU, reference summation order)", capi.PBD_CONV_MFMA: "mfma (fp32 / fp64 MFMA, k-ordered fma chain)",
+                  capi.PBD_CONV_SPLIT: "split (fp32 products as six exact bfloat16 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulators)"}
+    conv_resolved = handles[0].conv_mode
+    dt_mfma32, steps_mfma32, pf_mfma32 = None, min(args.steps, 100), [0.0]
+    if "mfma32" in legs and world == 1 and conv_resolved == capi.PBD_CONV_SPLIT:
+        split_handles = list(handles)
+        handles[:] = [capi.Handle(model, device=local, conv_mode=capi.PBD_CONV_MFMA, max_candidates=cap * (B if B > 1 else 1), dtype=dtype, graph=args.graph) for _ in range(S)]
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 0.5:
+            run(2 * S)
+        dt_mfma32, _, pf_mfma32 = timed(steps_mfma32, host=False)
+        for hd in handles:
+            hd.close()
+        handles[:] = split_handles
     if world > 1:
         ncand_all = sum(len(g[0]) for g in gathered_last[0]) if (rank == 0 and gathered_last[0]) else 0   # the last step's gather (inside the timed region)
     else:
@@ -437,17 +459,31 @@ def main():
         elif stage["dp_min"] >= stage["pdf"]:
             roof = roof_single
         else:
-            peak = 78.6 if args.dtype == "f64" else 157.3     # dense vector/matrix FMA peak of the dtype (MI355X_MICROARCH.md)
+            peak = 78.6 if args.dtype == "f64" else 157.3     # dense vector/matrix FMA peak of the dtype (MI355X_MICROARCH.md); fp32-equivalent flops for the split bank
             roof = {"kernel": f"pdf filter bank (k_conv_mfma{'_f64, fp64' if args.dtype == 'f64' else ', fp32'} MFMA)" if conv != capi.PBD_CONV_EXACT
                     else f"pdf filter bank (k_conv_exact<{args.dtype}>, VALU, reference summation order)", "bound": "mfma",
                     "achieved": round(pdf_tf, 3),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(pdf_tf / peak, 5), "traffic": None,
                     "launch_ms": round(float(stage["pdf"]), 4), "algorithmic_flops": work["F_pdf"]}
+        # filter bank: fp32-equivalent flops (F_pdf) per second; the split bank executes 6 bf16 MFMA flops per fp32-equivalent one and is
+        # priced against the dense bf16 peak (2.5 PF), the fp32 / fp64 MFMA banks against theirs
+        is_split = conv_resolved == capi.PBD_CONV_SPLIT
+        pdf_peak = 2500.0 if is_split else (78.6 if args.dtype == "f64" else 157.3)
+        pdf_mult = 6.0 if is_split else 1.0
+        pdf_ms_b = stage_batch["pdf"] / B if stage_batch else None
+        pdf_tf_b = work["F_pdf"] / (pdf_ms_b * 1e-3) / 1e12 if pdf_ms_b else None
+        pdf_block = {"TFLOP/s": round(pdf_tf, 3), "what": "fp32-equivalent TFLOP/s (F_pdf = 2 x cells x filters x kh kw 32), a frame on its own",
+                     "ms": round(stage["pdf"], 4), "ms_per_frame_batched": (round(pdf_ms_b, 4) if pdf_ms_b else None),
+                     "TFLOP/s_batched": (round(pdf_tf_b, 3) if pdf_tf_b else None),
+                     "mfma_TFLOP/s_batched": (round(pdf_tf_b * pdf_mult, 2) if pdf_tf_b else None), "mfma_flops_per_fp32_flop": pdf_mult,
+                     "peak": pdf_peak, "frac": round((pdf_tf_b if pdf_tf_b else pdf_tf) * pdf_mult / pdf_peak, 4),
+                     "bank": CONV_NAMES.get(conv_resolved, str(conv_resolved))}
         rnd = lambda v, n=3: None if v is None else round(v, n)
         config = {"workload": f"person 26 parts x {args.mixtures} mixtures ({len(model.filtersw)} {model.filtersw[0].shape[0]}x{model.filtersw[0].shape[1] // 32}x32 filters), "
                               f"{W}x{H} BGR, full pyramid ({hd.geometry(W, H)['nlevels']} levels), "
                               f"threshold = 99.9th pct of root scores",
-                  "frames_per_step_per_gpu": B, "inflight": S, "conv": args.conv, "input": "frames resident in HBM",
+                  "frames_per_step_per_gpu": B, "inflight": S, "conv": CONV_NAMES.get(conv_resolved, str(conv_resolved)), "conv_requested": args.conv,
+                  "frames_total_per_step": B * (1 if by_levels else world), "input": "frames resident in HBM",
                   "distinct_frames_per_rank": nimg, "distinct_step_slots": nslots,
                   "batching": (f"pbd_detect_batch: every handle processes {B} frames per step, one launch per stage for the batch" if B > 1 else "single frames"),
                   "launch": "hipGraph replay (one hipGraphLaunch per step)" if args.graph else "eager (~30 launches per step)",
@@ -456,6 +492,15 @@ def main():
                   "candidates_last_step": int(ncand_all), "candidates_last_step_is": "records of the last timed step, all its frames (and all ranks: the gathered list)", "parallelism": (f"levels (LPT sets) x{world}" if by_levels else f"frames x{world}"),
                   "gather": (f"every step, inside the timed region: torch.distributed gather to rank 0, backend {args.backend}, "
                              f"counts first, then the records padded to the longest list" if world > 1 else "none (one rank)")}
+        if by_levels:
+            # what the LPT partition is: every rank's levels and share of the frame's cells; the makespan (largest share) against
+            # the ideal 1 / N — level 0 alone is a fixed fraction of the cells, which bounds the strong-scaling speed-up
+            tot = float(sum(level_cells))
+            shares = [sum(level_cells[l] for l in ls) / tot for ls in level_sets]
+            config["level_sets"] = [{"rank": r, "levels": [int(l) for l in ls], "cell_share": round(sh, 4)} for r, (ls, sh) in enumerate(zip(level_sets, shares))]
+            config["lpt_makespan_share"] = round(max(shares), 4)
+            config["lpt_speedup_bound"] = round(1.0 / max(shares), 3)
+            config["lpt_ideal_speedup"] = world
         if world > 1:
             config["backend"] = dist.get_backend()
             config["backend_world"] = backend_world
@@ -472,6 +517,10 @@ def main():
                          "what": f"completion-to-completion wall time per step in the timed loop (rank 0): completions of the {S} steps in flight "
                                  f"arrive in bursts — throughput pacing, not latency (latency: `sequential`)"},
             "value_resident": rnd(value), "value_incl_h2d": rnd(value_h2d),
+            "value_fp32_mfma": (round(steps_mfma32 * per_rank / dt_mfma32, 3) if dt_mfma32 else None),
+            "value_fp32_mfma_is": (f"the same workload on handles with PBD_CONV_MFMA (fp32 v_mfma_f32_16x16x4_f32 bank, the default of rounds 3-4), {steps_mfma32} steps" if dt_mfma32 else None),
+            "value_fp32_mfma_frame_ms": ({"median": pct(pf_mfma32, 50), "p10": pct(pf_mfma32, 10), "p90": pct(pf_mfma32, 90), "max": round(float(np.max(pf_mfma32)), 3),
+                                          "first_steps": [round(float(x), 2) for x in pf_mfma32[:12]]} if dt_mfma32 else None),
             "value_single_frame_calls": (round(args.steps * B / dt_single, 3) if dt_single else None),
             "value_is": "frames resident in HBM when the timed region starts (the tier's contract, DESIGN.md 7); value_incl_h2d = the same steps "
                         "from pinned host images; value_single_frame_calls = ONE GPU's handles fed one frame per call",
@@ -485,8 +534,7 @@ def main():
             "roofline_single_frame": roof_single,
             "roofline_dt": {"bound": "hbm", "achieved": round(dp_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(dp_gbs / 8000.0, 5), "ms": round(float(dp_ms), 4)},
-            "pdf": {"TFLOP/s": round(pdf_tf, 3), "peak": 78.6 if args.dtype == "f64" else 157.3,
-                    "frac": round(pdf_tf / (78.6 if args.dtype == "f64" else 157.3), 4), "ms": round(stage["pdf"], 4)},
+            "pdf": pdf_block,
             "stage_ms_sequential": {k: round(v, 4) for k, v in stage.items()},
             "stage_ms_per_frame_batched": ({k: round(v / B, 4) for k, v in stage_batch.items()} if stage_batch else None),
         }

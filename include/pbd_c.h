@@ -136,7 +136,7 @@ typedef struct pbd_options {
 int pbd_abi_version(void);
 /* Version history: 3 = rounds 3-4.  4 (round 5) = PBD_CONV_AUTO resolves to PBD_CONV_SPLIT for float handles (numerics of
  * AUTO change in the last bits: rounds 3-4 resolved to PBD_CONV_MFMA, and before that to EXACT for banks other than 5 x 5),
- * PBD_CONV_SPLIT, pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state.  Struct layouts unchanged.   */
+ * PBD_CONV_SPLIT, pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state, pbd_group_comm_size.  Struct layouts unchanged.   */
 
 /* ---- output record: include/Candidate.hpp:56-111 --------------------------
  * One candidate = head + max_parts boxes (x, y, width, height as cv::Rect)
@@ -236,6 +236,7 @@ int pbd_group_destroy(pbd_group* g);
 const char* pbd_group_last_error(const pbd_group* g);
 int pbd_group_size(const pbd_group* g);
 int pbd_group_gather_mode(const pbd_group* g);          /* PBD_GATHER_HOST or PBD_GATHER_RCCL actually in use   */
+int pbd_group_comm_size(const pbd_group* g);            /* ranks of the RCCL communicator (ncclCommCount); 0 = host gather (ABI 4) */
 pbd_handle* pbd_group_member(pbd_group* g, int i);     /* borrowed: stage entry points, pbd_get_stage_ms, ...   */
 /* BASELINE configs[2]: a batch of same-sized frames, frame f on member f % size, all members busy at once.
  * Frame f's candidates land at heads[f*capacity], boxes[f*capacity*max_parts*4], locs[f*capacity*max_parts*3]

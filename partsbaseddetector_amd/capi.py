@@ -38,7 +38,7 @@ EXPORTS = [
     "pbd_get_work", "pbd_dp_timer", "pbd_debug_dt_stamps", "pbd_debug_hog_stamps", "pbd_debug_conv_stamps",
     "pbd_set_root", "pbd_set_root_f64", "pbd_set_dp_pointers", "pbd_get_footprint", "pbd_abi_version",
     "pbd_detect_batch_u8", "pbd_detect_batch_enqueue_u8", "pbd_detect_batch_enqueue_dev_u8", "pbd_detect_batch_collect",
-    "pbd_get_stage_state", "pbd_get_conv_mode",
+    "pbd_get_stage_state", "pbd_get_conv_mode", "pbd_group_comm_size",
 ]
 PBD_ABI_VERSION = 4
 
@@ -421,6 +421,7 @@ class Group:
             raise PbdError(rc, msg)
         self.size = self.L.pbd_group_size(self.g)
         self.gather_mode = self.L.pbd_group_gather_mode(self.g)
+        self.comm_size = self.L.pbd_group_comm_size(self.g)       # ranks of the RCCL communicator (0: host gather)
         self.max_parts = self.L.pbd_max_parts(C.c_void_p(self.L.pbd_group_member(self.g, 0)))
 
     def close(self):

@@ -90,8 +90,9 @@ void conv_split_filters(const float* filters, int nf, int kh, int kw, std::vecto
 }
 
 // NT: 32-filter n-tiles per workgroup (1..5); NW: wavefronts per workgroup (2: a 16 x 8 half of a ConvTile, 4: the whole 16 x 16 tile)
-// PIN: the K loop's schedule pinned for ONE wavefront per SIMD (see the loop); false: hipcc's own schedule at two wavefronts per SIMD
-template <int NT, int NW, bool PIN>
+// PIN: the K loop's schedule for ONE wavefront per SIMD (see the loop): 1 = the next k-step's loads as a block in front of this k-step's MFMAs,
+// 2 = the same loads dealt out between the MFMAs (sched_group_barrier); 0: hipcc's own schedule at two wavefronts per SIMD
+template <int NT, int NW, int PIN>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN ? 1 : 2))) void k_conv_split32(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
                                                              const uint16_t* __restrict__ feat, const uint16_t* __restrict__ filt,
                                                              float* __restrict__ resp, int nf, int ntl_bank, int ntile0, int ngroups,
@@ -219,17 +220,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
       // k-step's 60 MFMAs (1 920 cycles) and waited for after them.  Left alone, hipcc's scheduler sinks every load to just in front
       // of its first use to save registers (80 VGPRs) — an L2 round trip in front of every other MFMA, with one wavefront per SIMD
       const int tapofs = ti * TW + tj;
+      auto deal = [&]() {   // PIN == 2: one load per three MFMAs, then one LDS read per two (the MFMA pipe never waits for an issue burst)
+        if constexpr (PIN == 2) {
+#pragma unroll
+          for (int i = 0; i < 3 * NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, MV == 2 ? 3 : 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+#pragma unroll
+          for (int i = 0; i < 3 * MV; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        }
+      };
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
       load_b(b1, 2 * tap + 1);
       load_a(a1, tapofs, 1);
-      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      if (PIN == 1) __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
+      deal();
       if (PIN) __builtin_amdgcn_sched_barrier(0);
       if (++tj == kw) { tj = 0; ++ti; }
       const int nextofs = tap + 1 < ntap ? ti * TW + tj : tapofs;   // (past the last tap: this tap again, never used)
       load_b(b0, 2 * tap + 2);
       load_a(a0, nextofs, 0);
-      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      if (PIN == 1) __builtin_amdgcn_sched_barrier(0);
       mma(a1, b1);
+      deal();
       if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
   }
 }
 
-template <int NT, int NW, bool PIN>
+template <int NT, int NW, int PIN>
 static void launch_conv_split_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
                                 float* resp, int nf, int ntl_bank, int ntile0, int ngroups, int kh, int kw, hipStream_t s) {
   constexpr int ROWS = 4 * NW, NHALVES = 16 / ROWS;
@@ -267,7 +279,7 @@ static void launch_conv_split_t(const ConvTile* tiles, int ntiles, const LevelDe
   hipLaunchKernelGGL((k_conv_split32<NT, NW, PIN>), dim3(grid), dim3(64 * NW), lds, s, tiles, levels, feat_split, wS, resp, nf, ntl_bank,
                      ntile0, ngroups, ntiles, kh, kw);
 }
-template <int NW, bool PIN>
+template <int NW, int PIN>
 static void launch_conv_split_nw(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
                                  float* resp, int nf, int kh, int kw, hipStream_t s) {
   // groups of five n-tiles (160 filters: the person bank's 156 in one pass), then the remainder with its own instantiation
@@ -282,12 +294,14 @@ static void launch_conv_split_nw(const ConvTile* tiles, int ntiles, const LevelD
   }
 }
 // variant (tuning builds): bit 0: four wavefronts per workgroup (16 x 16 cell units) instead of two (16 x 8: two workgroups per CU);
-// bit 1: hipcc's own K-loop schedule at two wavefronts per SIMD instead of the pinned one
+// 2 / 3: hipcc's own K-loop schedule at two wavefronts per SIMD instead of the pinned one; 4 / 5: loads dealt out between the MFMAs
 void launch_conv_split(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
                        float* resp, int nf, int kh, int kw, int variant, hipStream_t s) {
   if (ntiles <= 0) return;
-  if (variant == 1) launch_conv_split_nw<4, true>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
-  else if (variant == 2) launch_conv_split_nw<2, false>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
-  else if (variant == 3) launch_conv_split_nw<4, false>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
-  else launch_conv_split_nw<2, true>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  if (variant == 1) launch_conv_split_nw<4, 1>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 2) launch_conv_split_nw<2, 0>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 3) launch_conv_split_nw<4, 0>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 4) launch_conv_split_nw<2, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 5) launch_conv_split_nw<4, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else launch_conv_split_nw<2, 1>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
 }

@@ -387,6 +387,7 @@ static void free_frame(pbd_handle* h) {
   h->fw = h->fh = h->fcn = 0;
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
   h->min_ran = false;
+  h->feat_split_ok = false;
   h->feat_ok.clear(); h->resp_ok.clear(); h->ext_set.clear(); h->root_set.clear();
 }
 
@@ -554,7 +555,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
     if ((rc = dev_alloc(h, &h->d_feat, feat_bytes))) return rc;
     if ((rc = dev_alloc(h, &h->d_pk, pk_bytes))) return rc;
   }
-  if (h->conv_mode == PBD_CONV_SPLIT && (rc = dev_alloc(h, &h->d_feat_split, cells * 3 * PBD_FLEN))) return rc;
+  h->d_feat_split = nullptr;   // (PBD_CONV_SPLIT: placed below, once the DT planes are known — the compact plan shares their memory)
   if ((rc = dev_alloc(h, &h->d_rootv, cells * m.ncomponents * ts))) return rc;
   if ((rc = dev_alloc(h, &h->d_rooti, cells * m.ncomponents))) return rc;
   if (h->nms_sz > 0 && (rc = dev_alloc(h, &h->d_nms_mask, cells * m.ncomponents))) return rc;
@@ -623,6 +624,15 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   if ((rc = dev_alloc(h, &h->d_dt_ixT, h->dt_cap_elems))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_iy, h->dt_cap_elems))) return rc;
   if (!fold && (rc = dev_alloc(h, &h->d_acc, cells * h->nslots * ts))) return rc;
+  if (h->conv_mode == PBD_CONV_SPLIT) {
+    // the features' bfloat16 parts (192 B per cell) live from HOG to the end of the filter bank; the x pass's pointer planes from min()
+    // to argmin(): the compact plan (whose stage buffers already refuse to be read once a later stage has reused them) puts both in
+    // one region where the planes are large enough (person model: 300 B per cell); the default plan keeps them apart (pdf() may be
+    // called again after min() there)
+    const size_t split_elems = cells * 3 * PBD_FLEN;
+    if (h->compact && h->dt_cap_elems >= split_elems) h->d_feat_split = (uint16_t*)h->d_dt_ixT;
+    else if ((rc = dev_alloc(h, &h->d_feat_split, split_elems))) return rc;
+  }
 
   // DT LDS budget per block unless the longest line needs more at the minimum number of lines per block
   int maxlen = 1;
@@ -957,8 +967,10 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
 }
 
 static int run_hog(pbd_handle* h) {
-  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->d_hog_lut, h->stream);
+  uint16_t* split = h->conv_mode == PBD_CONV_SPLIT ? h->d_feat_split : nullptr;
+  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->d_hog_lut, split, h->stream);
   LAUNCHCHK(h, "HOG");
+  h->feat_split_ok = split != nullptr;
   h->have_feat = true;
   compact_mark_feat(h, true);
   if (h->compact) h->have_dp = h->min_ran = false;
@@ -968,8 +980,12 @@ static int run_hog(pbd_handle* h) {
 static int run_pdf(pbd_handle* h) {
   const pbd_model_desc& m = h->md;
   if (h->conv_mode == PBD_CONV_SPLIT) {
-    // the features' three exact bfloat16 parts (a pass over 25 MB per frame), then the bank on the bf16 matrix units
-    launch_feat_split((const float*)h->d_feat, h->d_feat_split, h->cells, h->stream);
+    // the features' three exact bfloat16 parts: written by k_hog's epilogue; features handed in by the caller (pbd_set_level_features)
+    // are split here (a pass over 25 MB per frame).  Then the bank on the bf16 matrix units
+    if (!h->feat_split_ok) {
+      launch_feat_split((const float*)h->d_feat, h->d_feat_split, h->cells, h->stream);
+      h->feat_split_ok = true;
+    }
     static const int svariant = PBD_PROBE_ENV("PBD_SPLIT_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_SPLIT_VARIANT")) : 0;   // tuning builds
     launch_conv_split(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat_split, h->d_wS, (float*)h->d_resp, m.nfilters, m.kh, m.kw, svariant, h->stream);
   } else if (h->conv_mode == PBD_CONV_MFMA)
@@ -1047,6 +1063,7 @@ static int run_dp_min(pbd_handle* h) {
   h->root_dirty = false;
   if (h->compact) {     // their memory now holds the DP's planes: every feature / response plane is stale until produced or handed in again
     h->have_pyr = h->have_feat = h->have_resp = false;
+    h->feat_split_ok = false;   // (the split bank's copy of the features shared the x pass's pointer planes)
     compact_mark_feat(h, false);
     compact_mark_resp(h, false);
   }
@@ -1244,7 +1261,7 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
   h->nms_sz = o.reserved[0];
   h->conv_mode = o.conv_mode;
   if (h->conv_mode == PBD_CONV_AUTO)
-    // measured on MI355X for N = 26 .. 312 5x5x32 filters at 640x480 (profiles/archive/r03b_conv_modes.json): the fp32 MFMA
+    // measured on MI355X for N = 26 .. 312 5x5x32 filters at 640x480 (profiles/history/archive/r03b_conv_modes.json): the fp32 MFMA
     // implicit GEMM beats the direct VALU correlation at every N (26 filters: 0.11 vs 0.38 ms; 156: 0.40 vs 1.62;
     // 312: 0.76 vs 2.89) — the contraction is K = 800 deep whatever N is, so one 16-filter n-tile already pays.
     // The VALU kernel remains the bit-exact parity path (PBD_CONV_EXACT) and what banks of fewer than 16 filters get.
@@ -1514,6 +1531,7 @@ static int set_level_features_(pbd_handle* h, int level, const void* in, int ts)
   ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->d_feat + L.cell_off * PBD_FLEN * ts, in, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyHostToDevice));
+  h->feat_split_ok = false;   // (the split-product bank's copy of the features is re-derived in front of the next pdf())
   if (h->compact) {   // the write went over the Ik planes / the x pass's scratch; the other levels may still be stale
     h->have_dp = h->min_ran = false;
     if (h->feat_ok.size() != (size_t)h->nvl) compact_mark_feat(h, false);
@@ -1853,7 +1871,7 @@ static int hog_u8_(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
   HIPCHK(h, hipMemcpy2D(d_im, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_lv, &L, sizeof(L), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_tiles, tiles.data(), sizeof(HogTile) * tiles.size(), hipMemcpyHostToDevice));
-  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, ts, cn, sbin, tc, h->d_hog_lut, h->stream);
+  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, ts, cn, sbin, tc, h->d_hog_lut, nullptr, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, d_feat, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyDeviceToHost));
   hipFree(d_im); hipFree(d_feat); hipFree(d_lv); hipFree(d_tiles);

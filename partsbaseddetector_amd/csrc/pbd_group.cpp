@@ -21,6 +21,7 @@ typedef int (*fnCommDestroy)(ncclComm_t);
 typedef int (*fnAllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t);
 typedef int (*fnGroup)(void);
 typedef const char* (*fnErrStr)(int);
+typedef int (*fnCommCount)(const ncclComm_t, int*);
 struct Rccl {
   void* so = nullptr;
   fnCommInitAll CommInitAll = nullptr;
@@ -28,6 +29,7 @@ struct Rccl {
   fnAllGather AllGather = nullptr;
   fnGroup GroupStart = nullptr, GroupEnd = nullptr;
   fnErrStr GetErrorString = nullptr;
+  fnCommCount CommCount = nullptr;     // optional (pbd_group_comm_size)
   bool load() {
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
       so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
@@ -40,6 +42,7 @@ struct Rccl {
     GroupStart = (fnGroup)dlsym(so, "ncclGroupStart");
     GroupEnd = (fnGroup)dlsym(so, "ncclGroupEnd");
     GetErrorString = (fnErrStr)dlsym(so, "ncclGetErrorString");
+    CommCount = (fnCommCount)dlsym(so, "ncclCommCount");
     return CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd && GetErrorString;
   }
 };
@@ -231,6 +234,12 @@ int pbd_group_destroy(pbd_group* g) {
 const char* pbd_group_last_error(const pbd_group* g) { return g ? g->err.c_str() : "null group"; }
 int pbd_group_size(const pbd_group* g) { return g ? (int)g->m.size() : 0; }
 int pbd_group_gather_mode(const pbd_group* g) { return g ? g->mode : PBD_GATHER_HOST; }
+// ranks of the RCCL communicator the gather runs on, as RCCL reports it (ncclCommCount of member 0's communicator); 0: host gather
+int pbd_group_comm_size(const pbd_group* g) {
+  if (!g || g->mode != PBD_GATHER_RCCL || g->comms.empty() || !g->comms[0] || !g->rccl.CommCount) return 0;
+  int n = 0;
+  return g->rccl.CommCount(g->comms[0], &n) == 0 ? n : -1;
+}
 pbd_handle* pbd_group_member(pbd_group* g, int i) { return (g && i >= 0 && i < (int)g->m.size()) ? g->m[i] : nullptr; }
 
 static int all_levels(pbd_group* g) {   // undo a level sharding left behind by pbd_group_detect_u8

@@ -184,6 +184,7 @@ struct pbd_handle {
   uint8_t* d_pyr = nullptr;
   char* d_feat = nullptr; char* d_resp = nullptr; char* d_acc = nullptr;   // T data, addressed in bytes (elements * ts)
   uint16_t* d_feat_split = nullptr;   // PBD_CONV_SPLIT: the features as [cell][3 splits][32 channels] bfloat16 (per frame plan)
+  bool feat_split_ok = false;         // ... written by k_hog for the features now in d_feat (false: handed in by the caller -> k_feat_split before the bank)
   uint16_t* d_wS = nullptr;           // PBD_CONV_SPLIT: the filters as [tap][2 k-steps][3 splits][n-tile][2 k-groups][32][8] bfloat16 (per model)
   uint8_t* d_pk = nullptr;
   unsigned long long* d_scr_base = nullptr;   // [nlevels][nflat parts] element offset of mixture 0's DT planes (ix / iy / sdt)
@@ -299,7 +300,7 @@ int pbd_i_emit(pbd_handle* h, const std::vector<const char*>& recs, pbd_candidat
 void launch_resize(const PyrJob* jobs, int njobs, int maxpix, int cn, int sstride, const uint8_t* src, uint8_t* pyr, hipStream_t s);
 void launch_pyrdown(const PyrJob* jobs, int njobs, int maxw, int maxh, int cn, uint8_t* pyr, hipStream_t s);
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
-                int cn, int sbin, int tc, const uint8_t* binlut, hipStream_t s);
+                int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, hipStream_t s);
 size_t hog_lds_bytes(int sbin, int tc, int ts);
 size_t hog_binlut_bytes();                                        // orientation-snap table: best_o for every (dx, dy) in [-255, 255]^2
 void launch_hog_binlut(uint8_t* lut, int ts, hipStream_t s);      // evaluated in T (ts = sizeof(T)) with the reference's own chain (k_hog.hip)
