@@ -358,17 +358,22 @@ def main():
     CONV_NAMES = {capi.PBD_CONV_EXACT: "exact (VALU, reference summation order)", capi.PBD_CONV_MFMA: "mfma (fp32 / fp64 MFMA, k-ordered fma chain)",
                   capi.PBD_CONV_SPLIT: "split (fp32 products as six exact bfloat16 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulators)"}
     conv_resolved = handles[0].conv_mode
-    dt_mfma32, steps_mfma32, pf_mfma32 = None, min(args.steps, 100), [0.0]
+    # (a SEPARATE process: fresh handles created beside the timed ones in this process stalled for tens of ms at a time — r05 session 2 —,
+    #  and a second process repeats the protocol exactly: pre-warm, warm-up, K steps.  This process's handles are idle meanwhile.)
+    value_mfma32, steps_mfma32 = None, min(args.steps, 100)
     if "mfma32" in legs and world == 1 and conv_resolved == capi.PBD_CONV_SPLIT:
-        split_handles = list(handles)
-        handles[:] = [capi.Handle(model, device=local, conv_mode=capi.PBD_CONV_MFMA, max_candidates=cap * (B if B > 1 else 1), dtype=dtype, graph=args.graph) for _ in range(S)]
-        tw = time.perf_counter()
-        while time.perf_counter() - tw < 0.5:
-            run(2 * S)
-        dt_mfma32, _, pf_mfma32 = timed(steps_mfma32, host=False)
-        for hd in handles:
-            hd.close()
-        handles[:] = split_handles
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps_mfma32), "--warmup", str(args.warmup), "--conv", "mfma",
+               "--legs", "timed", "--inflight", str(S), "--batch", str(B), "--width", str(W), "--height", str(H), "--mixtures", str(args.mixtures),
+               "--dtype", args.dtype, "--graph", str(args.graph)]
+        torch.cuda.synchronize()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and sub:
+                value_mfma32 = json.loads(sub[-1])["value"]
+        except (subprocess.TimeoutExpired, ValueError, KeyError):
+            value_mfma32 = None
     if world > 1:
         ncand_all = sum(len(g[0]) for g in gathered_last[0]) if (rank == 0 and gathered_last[0]) else 0   # the last step's gather (inside the timed region)
     else:
@@ -517,10 +522,9 @@ def main():
                          "what": f"completion-to-completion wall time per step in the timed loop (rank 0): completions of the {S} steps in flight "
                                  f"arrive in bursts — throughput pacing, not latency (latency: `sequential`)"},
             "value_resident": rnd(value), "value_incl_h2d": rnd(value_h2d),
-            "value_fp32_mfma": (round(steps_mfma32 * per_rank / dt_mfma32, 3) if dt_mfma32 else None),
-            "value_fp32_mfma_is": (f"the same workload on handles with PBD_CONV_MFMA (fp32 v_mfma_f32_16x16x4_f32 bank, the default of rounds 3-4), {steps_mfma32} steps" if dt_mfma32 else None),
-            "value_fp32_mfma_frame_ms": ({"median": pct(pf_mfma32, 50), "p10": pct(pf_mfma32, 10), "p90": pct(pf_mfma32, 90), "max": round(float(np.max(pf_mfma32)), 3),
-                                          "first_steps": [round(float(x), 2) for x in pf_mfma32[:12]]} if dt_mfma32 else None),
+            "value_fp32_mfma": value_mfma32,
+            "value_fp32_mfma_is": (f"`value` of `bench.py --conv mfma --legs timed --steps {steps_mfma32}` (PBD_CONV_MFMA: the fp32 v_mfma_f32_16x16x4_f32 bank, the default of "
+                                   f"rounds 3-4), run as a child process after this process's timed legs" if value_mfma32 else None),
             "value_single_frame_calls": (round(args.steps * B / dt_single, 3) if dt_single else None),
             "value_is": "frames resident in HBM when the timed region starts (the tier's contract, DESIGN.md 7); value_incl_h2d = the same steps "
                         "from pinned host images; value_single_frame_calls = ONE GPU's handles fed one frame per call",

@@ -14,11 +14,10 @@
 //   * features: [cell][split][32 channels] bfloat16 in HBM (192 B per cell: k_feat_split, or k_hog's epilogue);
 //   * filters:  [tap][k-step (16 channels)][split][32-filter n-tile][k-group (8 channels)][32 filters][8] bfloat16 — ONE
 //     16-byte load per lane, k-step, split and n-tile, 1 KB contiguous per wavefront (host, once per model; L2-resident);
-//   * a workgroup = NW wavefronts = a 16 x 4 NW cell unit of a ConvTile; every wavefront owns two 32-cell M-tiles x NT
-//     (<= 5) 32-filter n-tiles = up to 160 accumulator registers, ONE wavefront per SIMD (the register file is the
-//     occupancy bound, two workgroups of two wavefronts per CU): per k-step 15 filter loads + 6 LDS reads feed 60 MFMAs of 32
-//     cycles — the operand traffic of a 64 x 160 register block is half the L1's rate where a 32 x 80 block saturates it
-//     (tests/tools/conv_split_probe.hip, round 4: 45 % of the bf16 peak);
+//   * a workgroup = NW wavefronts = a 16 x 4 NW cell unit of a ConvTile (default NW = 4: the whole tile); every wavefront owns two
+//     32-cell M-tiles x NT (<= 5) 32-filter n-tiles = up to 160 accumulator registers, ONE wavefront per SIMD (the register file
+//     is the occupancy bound): per k-step 15 filter loads + 6 LDS reads feed 60 MFMAs of 32 cycles — the operand traffic of a
+//     64 x 160 register block is half the L1's rate where a 32 x 80 block saturates it (tests/tools/conv_split_probe.hip, round 4);
 //   * the unit's halo tile sits in LDS as [split][cell][64 B], the four 16-byte channel groups of a cell XOR-swizzled with
 //     bits 2-3 of the cell index: the 16 lanes of a ds_read_b128 lane group read 16 consecutive cells -> 16 different
 //     16-byte bank slots (MI355X_MICROARCH.md, LDS: the lane groups are {0-3, 12-15, 20-27}, ...: the lane -> cell map of an
@@ -207,6 +206,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
 #pragma unroll
           for (int m = 0; m < MV; ++m) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nt][sb], a[m][sa], acc[nt][m], 0, 0, 0);
       };
+      // feature part x filter part, the small products of a k-step before its large one: m m, h l, l h (2^-16), h m, m h (2^-8), h h
       sweep(1, 1); sweep(0, 2); sweep(2, 0); sweep(0, 1); sweep(1, 0); sweep(0, 0);
     };
     bf16x8 a0[2][3], a1[2][3], b0[NT][3], b1[NT][3];
@@ -293,15 +293,22 @@ static void launch_conv_split_nw(const ConvTile* tiles, int ntiles, const LevelD
     default: break;
   }
 }
-// variant (tuning builds): bit 0: four wavefronts per workgroup (16 x 16 cell units) instead of two (16 x 8: two workgroups per CU);
-// 2 / 3: hipcc's own K-loop schedule at two wavefronts per SIMD instead of the pinned one; 4 / 5: loads dealt out between the MFMAs
+// Default (variant 0): four wavefronts per workgroup = one 16 x 16 cell ConvTile, ONE workgroup per CU (298 registers per
+// wavefront), the next k-step's loads dealt out between this k-step's MFMAs.  Measured on the MI355X (profiles/r05*: pdf per frame
+// in batches of 8 / whole-pipeline frames per second with three batches in flight): 0.168 ms / 2 090-2 116; the same with the loads
+// issued as a block in front of the MFMAs 0.180 / 1 900; two-wavefront workgroups (16 x 8 cell units, two per CU) 0.174 / 1 830
+// and 0.186 / 1 830; hipcc's own schedule (loads sunk to their uses, 240 registers, two wavefronts per SIMD) 0.187 / 1 960 with
+// four wavefronts per workgroup, 0.225 / 1 685 with two.  One workgroup per CU leaves the CU's other LDS half and a quarter of its
+// registers to a distance-transform block of another batch in flight, whose integer / fp64 vector work issues beside bf16 MFMAs
+// (tests/tools/mfma_valu_overlap_probe.hip: 0.5-0.75 of the shorter one hidden; fp32 FMAs: none).
+// variant (tuning builds, PBD_SPLIT_VARIANT): 1 = loads as a block, 2 / 3 = the two-wavefront forms of 0 / 1, 4 / 5 = hipcc's schedule (4 / 2 wavefronts)
 void launch_conv_split(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
                        float* resp, int nf, int kh, int kw, int variant, hipStream_t s) {
   if (ntiles <= 0) return;
   if (variant == 1) launch_conv_split_nw<4, 1>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
-  else if (variant == 2) launch_conv_split_nw<2, 0>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
-  else if (variant == 3) launch_conv_split_nw<4, 0>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
-  else if (variant == 4) launch_conv_split_nw<2, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
-  else if (variant == 5) launch_conv_split_nw<4, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
-  else launch_conv_split_nw<2, 1>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 2) launch_conv_split_nw<2, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 3) launch_conv_split_nw<2, 1>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 4) launch_conv_split_nw<4, 0>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 5) launch_conv_split_nw<2, 0>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else launch_conv_split_nw<4, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
 }

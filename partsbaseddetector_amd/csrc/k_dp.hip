@@ -429,8 +429,11 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   DT_STAMP(5);
 }
 
+#ifndef PBD_DT_WPE
+#define PBD_DT_WPE 3     // wavefronts per SIMD the register allocation must allow (experiment builds: 5 -> 96 registers, see the Makefile)
+#endif
 template <typename T, int FM>
-__global__ __launch_bounds__(256, 3) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
+__global__ __launch_bounds__(256, PBD_DT_WPE) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
                                                     const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   DT_STAMP(0);
