@@ -308,7 +308,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         outs, stamps = [], [t0]
-        run(nsteps, outs, stamps, host=host, B=B, solo=solo)
+        run(nsteps * S, outs, stamps, host=host, B=B, solo=solo)      # a step = one batch on EACH of the S handles (see `config.step`)
         torch.cuda.synchronize()
         if coll:
             dist.barrier()
@@ -341,7 +341,7 @@ def main():
         while time.perf_counter() - tw < PREWARM_S or prewarm_frames < 4 * S:
             run(2 * S, host=(prewarm_frames // (2 * S)) % 2 == 1)
             prewarm_frames += 2 * S
-    run(args.warmup)
+    run(args.warmup * S)
     for hd in handles:
         hd.dp_timer(reset=True)
 
@@ -425,7 +425,7 @@ def main():
         work = hd.work()
         stage = stage_acc or {k: 0.0 for k in ("image_pyramid", "hog", "pdf", "dp_min", "argmin", "total")}
         dp_ms = dp_ms_seq
-        per_rank = (1 if by_levels else world) * B
+        per_rank = (1 if by_levels else world) * B * S     # frames per step: every rank's S handles take one batch of B frames each
         ms_per_step = dt / args.steps * 1e3 if dt else None
         value = args.steps * per_rank / dt if dt else None
         value_h2d = args.steps * per_rank / dt_h2d if dt_h2d else None
@@ -487,8 +487,11 @@ def main():
         config = {"workload": f"person 26 parts x {args.mixtures} mixtures ({len(model.filtersw)} {model.filtersw[0].shape[0]}x{model.filtersw[0].shape[1] // 32}x32 filters), "
                               f"{W}x{H} BGR, full pyramid ({hd.geometry(W, H)['nlevels']} levels), "
                               f"threshold = 99.9th pct of root scores",
-                  "frames_per_step_per_gpu": B, "inflight": S, "conv": CONV_NAMES.get(conv_resolved, str(conv_resolved)), "conv_requested": args.conv,
-                  "frames_total_per_step": B * (1 if by_levels else world), "input": "frames resident in HBM",
+                  "frames_per_step_per_gpu": B * S, "frames_per_batch": B, "inflight": S,
+                  "step": (f"one batch of {B} frames on each of the {S} handles in flight = {B * S} frames per GPU (rounds 1-4 counted every batch as a step: with the "
+                           f"driver's 20 steps the timed window was 0.08-0.10 s and the pipeline's fill and drain — one batch running alone at either end — weighed 4-5 %; "
+                           f"a step of {S} batches times {S}x the frames between the same two synchronisations)"), "conv": CONV_NAMES.get(conv_resolved, str(conv_resolved)), "conv_requested": args.conv,
+                  "frames_total_per_step": B * S * (1 if by_levels else world), "input": "frames resident in HBM",
                   "distinct_frames_per_rank": nimg, "distinct_step_slots": nslots,
                   "batching": (f"pbd_detect_batch: every handle processes {B} frames per step, one launch per stage for the batch" if B > 1 else "single frames"),
                   "launch": "hipGraph replay (one hipGraphLaunch per step)" if args.graph else "eager (~30 launches per step)",
@@ -519,13 +522,13 @@ def main():
             "scaling": "strong" if by_levels else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": config,
             "frame_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),
-                         "what": f"completion-to-completion wall time per step in the timed loop (rank 0): completions of the {S} steps in flight "
+                         "what": f"completion-to-completion wall time per BATCH in the timed loop (rank 0): completions of the {S} batches in flight "
                                  f"arrive in bursts — throughput pacing, not latency (latency: `sequential`)"},
             "value_resident": rnd(value), "value_incl_h2d": rnd(value_h2d),
             "value_fp32_mfma": value_mfma32,
             "value_fp32_mfma_is": (f"`value` of `bench.py --conv mfma --legs timed --steps {steps_mfma32}` (PBD_CONV_MFMA: the fp32 v_mfma_f32_16x16x4_f32 bank, the default of "
                                    f"rounds 3-4), run as a child process after this process's timed legs" if value_mfma32 else None),
-            "value_single_frame_calls": (round(args.steps * B / dt_single, 3) if dt_single else None),
+            "value_single_frame_calls": (round(args.steps * B * S / dt_single, 3) if dt_single else None),
             "value_is": "frames resident in HBM when the timed region starts (the tier's contract, DESIGN.md 7); value_incl_h2d = the same steps "
                         "from pinned host images; value_single_frame_calls = ONE GPU's handles fed one frame per call",
             "incl_h2d": {"value": rnd(value_h2d), "unit": "frames/s", "ms_per_step": rnd(dt_h2d / args.steps * 1e3 if dt_h2d else None, 4),

@@ -268,6 +268,269 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv_split32p — the 5 x 5 bank as a PERSISTENT workgroup with the tile staging hidden under the MFMAs.  In k_conv_split32
+// the matrix pipe is busy 58-64 % of the kernel's time (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, profiles/r05*): with one
+// wavefront per SIMD nothing runs while a workgroup stages its tile (global -> registers -> LDS, a memory round trip per batch of
+// loads) or stores its 160 x 256 results.  Here a workgroup (4 wavefronts, one per CU by registers) walks a list of units (tile,
+// n-group); the K loop runs over the two 16-channel halves of the tile one after the other — (half 0: taps 0..24), (half 1: taps
+// 0..24) — and while one half (38 KB: [split][cell][32 B]) feeds the MFMAs, the next half — of this unit, or half 0 of the next
+// unit — is fetched piece by piece between the MFMAs into the other buffer: the same 77 KB of LDS as the one-shot kernel (a
+// distance-transform block of another batch still fits beside it), two barriers per unit, no staging phase.  The filter loads run
+// on across the halves and units (the last k-step of a half prefetches the first of the next).
+// Units: tile positions x, x + 8, ... of the plan's list belong to XCD x = blockIdx.x % 8 (k_conv_split32's convention); workgroup
+// j of the XCD takes its units j, j + nwx, ...
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void conv_split32p_body(char* smem, const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
+                                                   const uint16_t* __restrict__ feat, const uint16_t* __restrict__ filt,
+                                                   float* __restrict__ resp, int nf, int ntl_bank, int ntile0, int ngroups,
+                                                   int ntiles_total) {
+  constexpr int NW = 4, KW = 5, TW = 20, NC = 400, HPLANE = NC * 32, HBUF = 3 * HPLANE, NTAP = 25, NHP = NC * 6;   // NHP: 16-byte pieces of a half tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, nwx = gridDim.x >> 3;
+  const int ntx = ntiles_total > xcd ? (ntiles_total - xcd + 7) >> 3 : 0;
+  const int nunits = ntx * ngroups;
+  if (j0 >= nunits) return;
+  const int c = lane & 31, kg = lane >> 5;
+  const int mid = ((c & 15) >= 4 && (c & 15) < 12) ? 1 : 0;
+  const int pos = (c & 15) + 16 * (mid ^ (c >> 4));          // (k_conv_split32: each ds_read_b128 lane group = 16 consecutive cells)
+  const size_t bs_split = (size_t)ntl_bank * 512, bs_kstep = 3 * bs_split;
+
+  struct Unit { int y0, x0, W, H, ng; size_t cell_off; };
+  auto unit_of = [&](int v) {
+    const int ti = xcd + 8 * (v / ngroups);
+    const ConvTile t = tiles[ti];
+    const LevelDev lv = levels[t.level];
+    return Unit{t.y0, t.x0, lv.cw, lv.ch, v - (v / ngroups) * ngroups, (size_t)lv.cell_off};
+  };
+  // piece jj of this thread of half `half` of unit U's tile: the global address (clamped) ...
+  auto piece_src = [&](const Unit& U, int half, int jj) {
+    const int i = min(jj * 256 + tid, NHP - 1);
+    const int cell = (int)(((unsigned)i * 43691u) >> 18), p6 = i - cell * 6;          // i / 6 (exact for i < 2^16)
+    const int cy = (int)(((unsigned)cell * 52429u) >> 20), cx = cell - cy * TW;        // cell / 20
+    const int y = min(max(U.y0 - 2 + cy, 0), U.H - 1), x = min(max(U.x0 - 2 + cx, 0), U.W - 1);
+    const int gp = (p6 >> 1) * 4 + 2 * half + (p6 & 1);                                // piece of the cell's 192 bytes: 4 split + channel group
+    return (const u32x4*)(feat + (U.cell_off + (size_t)(y * U.W + x)) * (3 * PBD_FLEN) + gp * 8);
+  };
+  // ... and where it goes: border value (0, and 1.0 = 0x3F80 in the truncation channel: half 1, part h, second group, element 7) if the cell
+  // lies outside the level; [split][cell][32 B] with the two 16-byte groups of a cell swapped in every other run of 8 cells (16 consecutive
+  // cells x 16 bytes then cover all 16 bank slots)
+  auto piece_put = [&](const Unit& U, int half, int jj, char* buf, u32x4 v) {
+    const int i = min(jj * 256 + tid, NHP - 1);
+    const int cell = (int)(((unsigned)i * 43691u) >> 18), p6 = i - cell * 6;
+    const int cy = (int)(((unsigned)cell * 52429u) >> 20), cx = cell - cy * TW;
+    const int y = U.y0 - 2 + cy, x = U.x0 - 2 + cx;
+    // (a mask, not a select: hipcc turns `inside ? v : border` into a conditional LOAD at the point of use — the fetch issued a k-step early
+    //  is then gone, and the branch cuts the k-step's scheduling region in two)
+    const unsigned m = 0u - (unsigned)((int)(y >= 0) & (int)(y < U.H) & (int)(x >= 0) & (int)(x < U.W));
+    const unsigned b3 = (half == 1 && p6 == 1) ? 0x3F800000u : 0u;
+    const u32x4 w = u32x4{v[0] & m, v[1] & m, v[2] & m, (v[3] & m) | (b3 & ~m)};
+    *(u32x4*)(buf + (p6 >> 1) * HPLANE + cell * 32 + (((p6 & 1) ^ ((cell >> 3) & 1)) << 4)) = w;
+  };
+  constexpr int NPT = (NHP + 255) / 256;                     // pieces per thread and half tile (10)
+  static_assert(2 * NPT <= NTAP - 1, "a half tile is staged under the 25 k-steps of the previous half");
+
+  int v = j0;
+  Unit U = unit_of(v);
+  {  // the first unit's first half: nothing to hide it under
+    u32x4 r[NPT];
+#pragma unroll
+    for (int jj = 0; jj < NPT; ++jj) r[jj] = *piece_src(U, 0, jj);
+#pragma unroll
+    for (int jj = 0; jj < NPT; ++jj) piece_put(U, 0, jj, smem, r[jj]);
+  }
+  const uint16_t* bl = filt + (size_t)(ntile0 + U.ng * NT) * 512 + lane * 8;
+  bf16x8 a0[2][3], a1[2][3], b0[NT][3], b1[NT][3];
+  auto load_b = [&](bf16x8 (&b)[NT][3], const uint16_t* p) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt][s] = *(const bf16x8*)(p + s * bs_split + nt * 512);
+  };
+  load_b(b0, bl);                                            // k-step (tap 0, half 0) of the first unit
+  f32x16 acc[NT][2];
+
+  while (true) {
+    const int vn = v + nwx;
+    const bool has_next = vn < nunits;
+    const Unit Un = unit_of(has_next ? vn : v);              // (after the last unit: this unit again — its half 0 is staged once more, unused)
+    const uint16_t* bln = filt + (size_t)(ntile0 + Un.ng * NT) * 512 + lane * 8;
+    // packed M-tiles of the unit's valid cells (k_conv_split32)
+    const int vw = min(16, U.W - U.x0), vh = min(16, U.H - U.y0), ncell = vw * vh;
+    const int nmt = (ncell + 31) >> 5;
+    const int mvalid = __builtin_amdgcn_readfirstlane(max(0, min(2, (nmt - wave + NW - 1) / NW)));
+    const unsigned vw_magic = 65535u / (unsigned)vw + 1u;
+    int cl0[2], cofs[2];
+    bool cval[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int idx = 32 * (wave + NW * m) + pos;
+      cval[m] = idx < ncell;
+      const int ic = min(idx, ncell - 1);
+      const int cy = (int)(((unsigned)ic * vw_magic) >> 16), cx = ic - cy * vw;
+      cl0[m] = cy * TW + cx;
+      cofs[m] = (U.y0 + cy) * U.W + U.x0 + cx;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][m][r] = 0.f;
+
+    // one half of the unit: 25 k-steps (one per tap) on buffer `bufc`, operands in ping-pong (ac / bc hold the k-step being multiplied,
+    // an / bn receive the next one's), one staging action per k-step: even k-steps fetch a piece of the half staged next (unit Us, half hs),
+    // odd ones write it to `bufn`.  bnext: the filters of the k-step after this half's last.
+    auto run_half = [&](auto mv_tag, int half, const char* bufc, char* bufn, const Unit& Us, int hs, const uint16_t* bnext,
+                        bf16x8 (&ac)[2][3], bf16x8 (&bc)[NT][3], bf16x8 (&an)[2][3], bf16x8 (&bn)[NT][3]) __attribute__((always_inline)) {
+      constexpr int MV = decltype(mv_tag)::value;
+      auto load_a = [&](bf16x8 (&a)[2][3], int tapofs) {
+#pragma unroll
+        for (int m = 0; m < (MV ? MV : 1); ++m) {
+          if (MV == 0) break;
+          const int cl = cl0[m] + tapofs;
+          const char* p = bufc + cl * 32 + ((kg ^ ((cl >> 3) & 1)) << 4);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) a[m][s] = *(const bf16x8*)(p + s * HPLANE);
+        }
+      };
+      auto mma = [&](const bf16x8 (&a)[2][3], const bf16x8 (&b)[NT][3]) {
+        auto sweep = [&](int sa, int sb) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int m = 0; m < MV; ++m) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nt][sb], a[m][sa], acc[nt][m], 0, 0, 0);
+        };
+        sweep(1, 1); sweep(0, 2); sweep(2, 0); sweep(0, 1); sweep(1, 0); sweep(0, 0);
+      };
+      // the next k-step's loads dealt out between this k-step's MFMAs (k_conv_split32, PIN == 2); extra: the block's staging action
+      auto deal = [&](int extra_vmem, int extra_dsw) {
+        if constexpr (MV > 0) {
+#pragma unroll
+          for (int i = 0; i < 3 * NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, MV == 2 ? 3 : 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+          if (extra_vmem) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+          if (extra_dsw) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+#pragma unroll
+          for (int i = 0; i < 3 * MV; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, MV == 2 ? 2 : 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        }
+      };
+      const uint16_t* bh = bl + (size_t)half * bs_kstep;       // k-step (tap, half) = filters' k-step 2 tap + half
+      __syncthreads();                                          // `bufc` is complete (its pieces were written under the previous half); nobody reads `bufn` any more
+      load_a(ac, 0);
+      u32x4 pv = u32x4{0u, 0u, 0u, 0u};
+      int ti = 0, tj = 0;
+#pragma unroll 1
+      for (int tp = 0; tp < NTAP / 2; ++tp) {                   // taps 2 tp, 2 tp + 1
+        __builtin_amdgcn_sched_barrier(0);
+        pv = *piece_src(Us, hs, min(tp, NPT - 1));
+        if (MV) load_b(bn, bh + (size_t)(2 * (2 * tp + 1)) * bs_kstep);
+        if (++tj == KW) { tj = 0; ++ti; }
+        load_a(an, ti * TW + tj);
+        mma(ac, bc);
+        deal(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        piece_put(Us, hs, min(tp, NPT - 1), bufn, pv);           // (taps past the half's last piece write that piece once more)
+        if (MV) load_b(bc, bh + (size_t)(2 * (2 * tp + 2)) * bs_kstep);
+        if (++tj == KW) { tj = 0; ++ti; }
+        load_a(ac, ti * TW + tj);
+        mma(an, bn);
+        deal(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // tap 24: the operands are in (ac, bc); the first k-step of the next half goes to bn (its A operands are read after the barrier)
+      __builtin_amdgcn_sched_barrier(0);
+      if (MV) load_b(bn, bnext);
+      mma(ac, bc);
+      deal(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto run_unit = [&](auto mv_tag) __attribute__((always_inline)) {
+      // half 0 on buffer 0 (staging this unit's half 1 into buffer 1), then half 1 on buffer 1 (staging the next unit's half 0 into buffer 0);
+      // 25 k-steps per half: the ping-pong roles swap from half to half and are back after the unit
+      run_half(mv_tag, 0, smem, smem + HBUF, U, 1, bl + bs_kstep, a0, b0, a1, b1);
+      run_half(mv_tag, 1, smem + HBUF, smem, Un, 0, bln, a1, b1, a0, b0);
+    };
+    // (every wavefront runs both of its M-tiles, valid or not — a tile past the unit's last cell repeats that cell and is never stored: the
+    //  workgroup meets at a barrier per half anyway, so a wavefront that skipped MFMAs would only wait there, and ONE instantiation of the
+    //  K loop keeps the kernel at 406 registers instead of 478: a distance-transform wavefront of another batch still fits on the SIMD)
+    run_unit(std::integral_constant<int, 2>());
+
+    // D[i = filter 32 nt + (r & 3) + 8 (r >> 2) + 4 kg][j = cell pos of M-tile m]
+    {
+      float* Rl = resp + U.cell_off * nf;
+      const size_t HW = (size_t)U.H * U.W;
+      const int ntb = ntile0 + U.ng * NT;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (m < mvalid && cval[m]) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float* pl = Rl + (size_t)(32 * (ntb + nt) + 4 * kg) * HW + cofs[m];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int fo = (r & 3) + 8 * (r >> 2);
+              if (32 * (ntb + nt) + 4 * kg + fo < nf) pl[(size_t)fo * HW] = acc[nt][m][r];
+            }
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    v = vn; U = Un; bl = bln;
+  }
+}
+
+// CAP: register budget of the allocation: 200 + 200 (a 112-register distance-transform wavefront of another batch fits on the SIMD beside it; the
+// compiler takes 406 when left alone) or the whole file.  (amdgpu_num_vgpr wants a literal: two kernels around one body.)
+template <int NT, bool CAP> struct ConvSplit32p;
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(200))) void k_conv_split32p_cap(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
+    const uint16_t* __restrict__ feat, const uint16_t* __restrict__ filt, float* __restrict__ resp, int nf, int ntl_bank, int ntile0, int ngroups, int ntiles_total) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv_split32p_body<NT>(smem, tiles, levels, feat, filt, resp, nf, ntl_bank, ntile0, ngroups, ntiles_total);
+}
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv_split32p_all(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
+    const uint16_t* __restrict__ feat, const uint16_t* __restrict__ filt, float* __restrict__ resp, int nf, int ntl_bank, int ntile0, int ngroups, int ntiles_total) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv_split32p_body<NT>(smem, tiles, levels, feat, filt, resp, nf, ntl_bank, ntile0, ngroups, ntiles_total);
+}
+template <int NT, bool CAP>
+static void launch_conv_split_p(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                                float* resp, int nf, int ntl_bank, int ntile0, int ngroups, int ncu, hipStream_t s) {
+  const size_t lds = 2 * 3 * 400 * 32;
+  static LdsOptIn optin;
+  const int grid = 8 * std::max(1, (ncu + 7) / 8);          // one workgroup per CU (by registers), the same number on every XCD
+  if constexpr (CAP) {
+    optin.ensure((const void*)k_conv_split32p_cap<NT>, lds);
+    hipLaunchKernelGGL((k_conv_split32p_cap<NT>), dim3(grid), dim3(256), lds, s, tiles, levels, feat_split, wS, resp, nf, ntl_bank, ntile0, ngroups, ntiles);
+  } else {
+    optin.ensure((const void*)k_conv_split32p_all<NT>, lds);
+    hipLaunchKernelGGL((k_conv_split32p_all<NT>), dim3(grid), dim3(256), lds, s, tiles, levels, feat_split, wS, resp, nf, ntl_bank, ntile0, ngroups, ntiles);
+  }
+}
+template <bool CAP>
+static void launch_conv_split_persistent_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                                           float* resp, int nf, int ncu, hipStream_t s) {
+  const int ntl = conv_split_ntiles(nf), full = ntl / 5, rest = ntl - 5 * full;
+  if (full) launch_conv_split_p<5, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 0, full, ncu, s);
+  switch (rest) {
+    case 1: launch_conv_split_p<1, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
+    case 2: launch_conv_split_p<2, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
+    case 3: launch_conv_split_p<3, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
+    case 4: launch_conv_split_p<4, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
+    default: break;
+  }
+}
+// 5 x 5 banks only (two half tiles of 20 x 20 cells in LDS)
+void launch_conv_split_persistent(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                                  float* resp, int nf, int ncu, bool cap, hipStream_t s) {
+  if (ntiles <= 0) return;
+  if (cap) launch_conv_split_persistent_t<true>(tiles, ntiles, levels, feat_split, wS, resp, nf, ncu, s);
+  else launch_conv_split_persistent_t<false>(tiles, ntiles, levels, feat_split, wS, resp, nf, ncu, s);
+}
+
 template <int NT, int NW, int PIN>
 static void launch_conv_split_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
                                 float* resp, int nf, int ntl_bank, int ntile0, int ngroups, int kh, int kw, hipStream_t s) {

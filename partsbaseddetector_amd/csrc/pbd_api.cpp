@@ -645,12 +645,14 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   // the two-wavefront / 25 KB blocks by 2-8 % of dp_min in batches (640x480: 0.328 -> 0.314 ms per frame, 0.600 -> 0.581 alone);
   // with 16-bit links (10 B per element: 1280x720, 1920x1080) they lose 9-12 %, and there the geometry above stays.
   const bool byte_links = dt_stride_for(maxlen) <= 256;
-  h->dt_nt = h->ts == 8 ? 64 : (byte_links ? 256 : PBD_DT_NT_DEFAULT);
+  // double (17 B per line element): two wavefronts and 40 KB per block — round 4, session 34: 0.473 / 0.721 ms per frame (batches / alone)
+  // against 0.485 / 0.770 with one wavefront and 20 KB; round 5, session 3: 0.477 against 0.497 in batches, 893 against 879 frames/s
+  h->dt_nt = h->ts == 8 ? 128 : (byte_links ? 256 : PBD_DT_NT_DEFAULT);
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
   h->dt_nt_x = h->dt_nt;      // lanes of a fold x-pass block
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT_X")) h->dt_nt_x = std::max(64, std::min(256, atoi(e) & ~63));
   if (const char* e = PBD_PROBE_ENV("PBD_DT_SEG")) h->dt_seg = atoi(e);
-  size_t dt_base = (h->ts == 8 ? 20 : (byte_links ? 40 : 25)) * 1024;
+  size_t dt_base = (h->ts == 8 ? 40 : (byte_links ? 40 : 25)) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_B")) dt_base = (size_t)atoi(e);
   int max_mix = 4;
@@ -987,6 +989,9 @@ static int run_pdf(pbd_handle* h) {
       h->feat_split_ok = true;
     }
     static const int svariant = PBD_PROBE_ENV("PBD_SPLIT_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_SPLIT_VARIANT")) : 0;   // tuning builds
+    if ((svariant == 6 || svariant == 7) && m.kh == 5 && m.kw == 5)
+      launch_conv_split_persistent(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat_split, h->d_wS, (float*)h->d_resp, m.nfilters, h->ncu, svariant == 7, h->stream);
+    else
     launch_conv_split(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat_split, h->d_wS, (float*)h->d_resp, m.nfilters, m.kh, m.kw, svariant, h->stream);
   } else if (h->conv_mode == PBD_CONV_MFMA)
     if (h->ts == 8) launch_conv_mfma_f64(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, (const double*)h->d_feat, (const double*)h->d_wT,

@@ -308,6 +308,8 @@ void launch_hog_binlut(uint8_t* lut, int ts, hipStream_t s);      // evaluated i
 void launch_feat_split(const float* feat, uint16_t* out, size_t ncells, hipStream_t s);
 void launch_conv_split(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
                        float* resp, int nf, int kh, int kw, int variant, hipStream_t s);
+void launch_conv_split_persistent(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                                  float* resp, int nf, int ncu, bool cap, hipStream_t s);   // 5 x 5 banks: persistent workgroups, staging hidden under the MFMAs
 void conv_split_filters(const float* filters, int nf, int kh, int kw, std::vector<uint16_t>& out);   // host: the d_wS layout
 void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const void* feat,
                        const void* wT, void* resp, int ts, int nf, int nfpad, int kh, int kw, hipStream_t s);

@@ -277,6 +277,42 @@ def test_pdf_mfma_tuning_variants(gpu_required, variant):
     assert worst < 2e-5, worst
 
 
+@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7])
+def test_pdf_split_tuning_variants(gpu_required, variant):
+    """The split-product bank's kernels kept behind PBD_SPLIT_VARIANT (tuning build only: loads as a block / two-wavefront workgroups /
+    hipcc's own schedule / the persistent double-buffered kernel with and without the register cap) against the oracle: ragged levels,
+    45 filters (two n-tiles), 36 (padded), and 170 (a full group of five n-tiles + one more).  Subprocess: the library is chosen at import."""
+    import subprocess
+    tune = os.path.join(ROOT, "partsbaseddetector_amd", "libpbd_hip_tune.so")
+    if not os.path.exists(tune):
+        pytest.skip("tuning build absent (make -C partsbaseddetector_amd/csrc tune)")
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from partsbaseddetector_amd import capi\n"
+        "from partsbaseddetector_amd.model import make_image, make_tree_model\n"
+        "from oracle import orc\n"
+        "worst = 0.0\n"
+        "for (parts, K, seed, w, h) in [(9, 5, 14, 120, 90), (6, 6, 15, 333, 207), (34, 5, 16, 200, 150)]:\n"
+        "    m = make_tree_model([-1] + [0] * (parts - 1), K, seed=seed)\n"
+        "    hd = capi.Handle(m, conv_mode=capi.PBD_CONV_SPLIT)\n"
+        "    for rep in range(2):\n"
+        "        hd.pyramid(make_image(seed + rep, w, h)); hd.pdf()\n"
+        "        g = hd._geo\n"
+        "        for l in (0, 1, 5, g['nlevels'] - 1):\n"
+        "            ref = orc.pdf_level(hd.level_features(l), m.filtersw)\n"
+        "            for n in range(0, len(m.filtersw), 3 if len(m.filtersw) > 100 else 1):\n"
+        "                worst = max(worst, float(np.abs(hd.level_response(l, n) - ref[n]).max()))\n"
+        "    hd.close()\n"
+        "print('WORST', worst)\n"
+    )
+    env = dict(os.environ, PBD_LIBRARY=tune, PBD_SPLIT_VARIANT=str(variant))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float(r.stdout.strip().split("WORST")[-1])
+    assert worst < 2e-5, worst
+
+
 def test_pdf_zero_taps_and_border_channel(gpu_required, orc):
     m = make_tree_model([-1, 0], 2, seed=21)
     for f in m.filtersw:  # zero taps are skipped by the reference (filter.cpp:3808-3857): same result
