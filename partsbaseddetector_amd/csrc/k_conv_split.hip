@@ -481,54 +481,38 @@ __device__ __forceinline__ void conv_split32p_body(char* smem, const ConvTile* _
   }
 }
 
-// CAP: register budget of the allocation: 200 + 200 (a 112-register distance-transform wavefront of another batch fits on the SIMD beside it; the
-// compiler takes 406 when left alone) or the whole file.  (amdgpu_num_vgpr wants a literal: two kernels around one body.)
-template <int NT, bool CAP> struct ConvSplit32p;
 template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(200))) void k_conv_split32p_cap(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv_split32p(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
     const uint16_t* __restrict__ feat, const uint16_t* __restrict__ filt, float* __restrict__ resp, int nf, int ntl_bank, int ntile0, int ngroups, int ntiles_total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   conv_split32p_body<NT>(smem, tiles, levels, feat, filt, resp, nf, ntl_bank, ntile0, ngroups, ntiles_total);
 }
 template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv_split32p_all(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
-    const uint16_t* __restrict__ feat, const uint16_t* __restrict__ filt, float* __restrict__ resp, int nf, int ntl_bank, int ntile0, int ngroups, int ntiles_total) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  conv_split32p_body<NT>(smem, tiles, levels, feat, filt, resp, nf, ntl_bank, ntile0, ngroups, ntiles_total);
-}
-template <int NT, bool CAP>
 static void launch_conv_split_p(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
                                 float* resp, int nf, int ntl_bank, int ntile0, int ngroups, int ncu, hipStream_t s) {
   const size_t lds = 2 * 3 * 400 * 32;
   static LdsOptIn optin;
+  optin.ensure((const void*)k_conv_split32p<NT>, lds);
   const int grid = 8 * std::max(1, (ncu + 7) / 8);          // one workgroup per CU (by registers), the same number on every XCD
-  if constexpr (CAP) {
-    optin.ensure((const void*)k_conv_split32p_cap<NT>, lds);
-    hipLaunchKernelGGL((k_conv_split32p_cap<NT>), dim3(grid), dim3(256), lds, s, tiles, levels, feat_split, wS, resp, nf, ntl_bank, ntile0, ngroups, ntiles);
-  } else {
-    optin.ensure((const void*)k_conv_split32p_all<NT>, lds);
-    hipLaunchKernelGGL((k_conv_split32p_all<NT>), dim3(grid), dim3(256), lds, s, tiles, levels, feat_split, wS, resp, nf, ntl_bank, ntile0, ngroups, ntiles);
-  }
+  hipLaunchKernelGGL((k_conv_split32p<NT>), dim3(grid), dim3(256), lds, s, tiles, levels, feat_split, wS, resp, nf, ntl_bank, ntile0, ngroups, ntiles);
 }
-template <bool CAP>
-static void launch_conv_split_persistent_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
-                                           float* resp, int nf, int ncu, hipStream_t s) {
+// 5 x 5 banks only (two half tiles of 20 x 20 cells in LDS).  TUNING BUILDS ONLY (PBD_SPLIT_VARIANT=6), measured and not adopted (r05 session 4,
+// alternating runs): pdf 0.172-0.177 ms per frame in batches of 8 against 0.169 for k_conv_split32's default, 1 815-1 853 against 2 034-2 043 frames/s
+// with three batches in flight (406 registers: no distance-transform wavefront fits beside it; capped at 400 with amdgpu_num_vgpr the K loop
+// spills: 0.316 ms).  The one-shot kernel's staging phase is NOT what holds its matrix pipe at 58-64 %: at ~1.2 PF of bf16 products on random
+// data the chip runs at its power limit (effective clock ~2.0 GHz; the guides' best HIP GEMM sustains 1.3 PF on random operands).
+void launch_conv_split_persistent(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                                  float* resp, int nf, int ncu, hipStream_t s) {
+  if (ntiles <= 0) return;
   const int ntl = conv_split_ntiles(nf), full = ntl / 5, rest = ntl - 5 * full;
-  if (full) launch_conv_split_p<5, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 0, full, ncu, s);
+  if (full) launch_conv_split_p<5>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 0, full, ncu, s);
   switch (rest) {
-    case 1: launch_conv_split_p<1, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
-    case 2: launch_conv_split_p<2, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
-    case 3: launch_conv_split_p<3, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
-    case 4: launch_conv_split_p<4, CAP>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
+    case 1: launch_conv_split_p<1>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
+    case 2: launch_conv_split_p<2>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
+    case 3: launch_conv_split_p<3>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
+    case 4: launch_conv_split_p<4>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, ncu, s); break;
     default: break;
   }
-}
-// 5 x 5 banks only (two half tiles of 20 x 20 cells in LDS)
-void launch_conv_split_persistent(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
-                                  float* resp, int nf, int ncu, bool cap, hipStream_t s) {
-  if (ntiles <= 0) return;
-  if (cap) launch_conv_split_persistent_t<true>(tiles, ntiles, levels, feat_split, wS, resp, nf, ncu, s);
-  else launch_conv_split_persistent_t<false>(tiles, ntiles, levels, feat_split, wS, resp, nf, ncu, s);
 }
 
 template <int NT, int NW, int PIN>

@@ -102,6 +102,20 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
 #pragma unroll
   for (int u = 0; u < U; ++u) ob[u] = off[u] * (unsigned)sizeof(T);
   int c = 0;
+#ifdef PBD_FOLD_PREFETCH
+  // experiment (r05): the NEXT child's plane values are fetched before this child's arithmetic and Ik stores — the children's memory
+  // round trips overlap instead of following each other (a fold block's loader is 3-4 dependent round trips for the person tree)
+  T sdn[U][M];
+  {
+    const FoldChild& C0 = J->ch[0];
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      GP(char) pl = (GP(char))C0.sdt[k];
+#pragma unroll
+      for (int u = 0; u < U; ++u) sdn[u][k] = *(GP(T))(pl + ob[u]);
+    }
+  }
+#endif
   do {                                                   // (a fold job has at least one child: a loop that may run zero times made the
                                                          // compiler wait, after it, for the children's Ik STORES before the LDS stores)
     const FoldChild& C = J->ch[c];
@@ -119,12 +133,28 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
       asm volatile("" : "+v"(obc[u]), "+v"(offc[u]));
 #endif
     }
+#ifdef PBD_FOLD_PREFETCH
+    {
+      const FoldChild& Cn = J->ch[min(c + 1, nch - 1)];  // (after the last child: that child again, unused)
+#pragma unroll
+      for (int k = 0; k < M; ++k)
+#pragma unroll
+        for (int u = 0; u < U; ++u) sd[u][k] = sdn[u][k];
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        GP(char) pl = (GP(char))Cn.sdt[k];
+#pragma unroll
+        for (int u = 0; u < U; ++u) sdn[u][k] = *(GP(T))(pl + obc[u]);
+      }
+    }
+#else
 #pragma unroll
     for (int k = 0; k < M; ++k) {
       GP(char) pl = (GP(char))C.sdt[k];                  // entries beyond K repeat plane K - 1 (plan): never predicated
 #pragma unroll
       for (int u = 0; u < U; ++u) sd[u][k] = *(GP(T))(pl + obc[u]);
     }
+#endif
     float bias[M][M];
     // (wave-uniform: scalar loads.  Fetching the block with vector loads instead — it overflows the scalar register file and
     // part of it is spilled to vector-register lanes — was measured 9 % slower per fold launch: twelve more vector-memory

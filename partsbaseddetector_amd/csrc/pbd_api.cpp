@@ -989,8 +989,8 @@ static int run_pdf(pbd_handle* h) {
       h->feat_split_ok = true;
     }
     static const int svariant = PBD_PROBE_ENV("PBD_SPLIT_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_SPLIT_VARIANT")) : 0;   // tuning builds
-    if ((svariant == 6 || svariant == 7) && m.kh == 5 && m.kw == 5)
-      launch_conv_split_persistent(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat_split, h->d_wS, (float*)h->d_resp, m.nfilters, h->ncu, svariant == 7, h->stream);
+    if (svariant == 6 && m.kh == 5 && m.kw == 5)
+      launch_conv_split_persistent(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat_split, h->d_wS, (float*)h->d_resp, m.nfilters, h->ncu, h->stream);
     else
     launch_conv_split(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat_split, h->d_wS, (float*)h->d_resp, m.nfilters, m.kh, m.kw, svariant, h->stream);
   } else if (h->conv_mode == PBD_CONV_MFMA)

@@ -309,7 +309,7 @@ void launch_feat_split(const float* feat, uint16_t* out, size_t ncells, hipStrea
 void launch_conv_split(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
                        float* resp, int nf, int kh, int kw, int variant, hipStream_t s);
 void launch_conv_split_persistent(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
-                                  float* resp, int nf, int ncu, bool cap, hipStream_t s);   // 5 x 5 banks: persistent workgroups, staging hidden under the MFMAs
+                                  float* resp, int nf, int ncu, hipStream_t s);   // 5 x 5 banks: persistent workgroups, staging hidden under the MFMAs (tuning variant, not adopted)
 void conv_split_filters(const float* filters, int nf, int kh, int kw, std::vector<uint16_t>& out);   // host: the d_wS layout
 void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const void* feat,
                        const void* wT, void* resp, int ts, int nf, int nfpad, int kh, int kw, hipStream_t s);

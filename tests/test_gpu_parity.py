@@ -277,10 +277,10 @@ def test_pdf_mfma_tuning_variants(gpu_required, variant):
     assert worst < 2e-5, worst
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 4, 6])
 def test_pdf_split_tuning_variants(gpu_required, variant):
     """The split-product bank's kernels kept behind PBD_SPLIT_VARIANT (tuning build only: loads as a block / two-wavefront workgroups /
-    hipcc's own schedule / the persistent double-buffered kernel with and without the register cap) against the oracle: ragged levels,
+    hipcc's own schedule / the persistent double-buffered kernel) against the oracle: ragged levels,
     45 filters (two n-tiles), 36 (padded), and 170 (a full group of five n-tiles + one more).  Subprocess: the library is chosen at import."""
     import subprocess
     tune = os.path.join(ROOT, "partsbaseddetector_amd", "libpbd_hip_tune.so")
