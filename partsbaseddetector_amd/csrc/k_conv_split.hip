@@ -528,17 +528,22 @@ static void launch_conv_split_t(const ConvTile* tiles, int ntiles, const LevelDe
 }
 template <int NW, int PIN>
 static void launch_conv_split_nw(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
-                                 float* resp, int nf, int kh, int kw, hipStream_t s) {
-  // groups of five n-tiles (160 filters: the person bank's 156 in one pass), then the remainder with its own instantiation
-  const int ntl = conv_split_ntiles(nf), full = ntl / 5, rest = ntl - 5 * full;
-  if (full) launch_conv_split_t<5, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 0, full, kh, kw, s);
-  switch (rest) {
-    case 1: launch_conv_split_t<1, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, kh, kw, s); break;
-    case 2: launch_conv_split_t<2, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, kh, kw, s); break;
-    case 3: launch_conv_split_t<3, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, kh, kw, s); break;
-    case 4: launch_conv_split_t<4, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, 5 * full, 1, kh, kw, s); break;
-    default: break;
-  }
+                                 float* resp, int nf, int kh, int kw, hipStream_t s, int G = 5) {
+  // groups of G = five n-tiles (160 filters: the person bank's 156 in one pass), then the remainder with its own instantiation
+  // (G = 4 / 3: tuning variants — fewer accumulators per wavefront, two wavefronts per SIMD, every tile staged once per group)
+  const int ntl = conv_split_ntiles(nf), full = ntl / G, rest = ntl - G * full;
+  auto go = [&](int nt, int ntile0, int ngroups) {
+    switch (nt) {
+      case 1: launch_conv_split_t<1, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s); break;
+      case 2: launch_conv_split_t<2, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s); break;
+      case 3: launch_conv_split_t<3, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s); break;
+      case 4: launch_conv_split_t<4, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s); break;
+      case 5: launch_conv_split_t<5, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s); break;
+      default: break;
+    }
+  };
+  if (full) go(G, 0, full);
+  if (rest) go(rest, G * full, 1);
 }
 // Default (variant 0): four wavefronts per workgroup = one 16 x 16 cell ConvTile, ONE workgroup per CU (298 registers per
 // wavefront), the next k-step's loads dealt out between this k-step's MFMAs.  Measured on the MI355X (profiles/r05*: pdf per frame
@@ -557,5 +562,7 @@ void launch_conv_split(const ConvTile* tiles, int ntiles, const LevelDev* levels
   else if (variant == 3) launch_conv_split_nw<2, 1>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
   else if (variant == 4) launch_conv_split_nw<4, 0>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
   else if (variant == 5) launch_conv_split_nw<2, 0>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
+  else if (variant == 7) launch_conv_split_nw<4, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s, 4);   // groups of four n-tiles (+ remainder)
+  else if (variant == 8) launch_conv_split_nw<4, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s, 3);   // groups of three
   else launch_conv_split_nw<4, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, s);
 }

@@ -102,20 +102,6 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
 #pragma unroll
   for (int u = 0; u < U; ++u) ob[u] = off[u] * (unsigned)sizeof(T);
   int c = 0;
-#ifdef PBD_FOLD_PREFETCH
-  // experiment (r05): the NEXT child's plane values are fetched before this child's arithmetic and Ik stores — the children's memory
-  // round trips overlap instead of following each other (a fold block's loader is 3-4 dependent round trips for the person tree)
-  T sdn[U][M];
-  {
-    const FoldChild& C0 = J->ch[0];
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-      GP(char) pl = (GP(char))C0.sdt[k];
-#pragma unroll
-      for (int u = 0; u < U; ++u) sdn[u][k] = *(GP(T))(pl + ob[u]);
-    }
-  }
-#endif
   do {                                                   // (a fold job has at least one child: a loop that may run zero times made the
                                                          // compiler wait, after it, for the children's Ik STORES before the LDS stores)
     const FoldChild& C = J->ch[c];
@@ -133,28 +119,12 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
       asm volatile("" : "+v"(obc[u]), "+v"(offc[u]));
 #endif
     }
-#ifdef PBD_FOLD_PREFETCH
-    {
-      const FoldChild& Cn = J->ch[min(c + 1, nch - 1)];  // (after the last child: that child again, unused)
-#pragma unroll
-      for (int k = 0; k < M; ++k)
-#pragma unroll
-        for (int u = 0; u < U; ++u) sd[u][k] = sdn[u][k];
-#pragma unroll
-      for (int k = 0; k < M; ++k) {
-        GP(char) pl = (GP(char))Cn.sdt[k];
-#pragma unroll
-        for (int u = 0; u < U; ++u) sdn[u][k] = *(GP(T))(pl + obc[u]);
-      }
-    }
-#else
 #pragma unroll
     for (int k = 0; k < M; ++k) {
       GP(char) pl = (GP(char))C.sdt[k];                  // entries beyond K repeat plane K - 1 (plan): never predicated
 #pragma unroll
       for (int u = 0; u < U; ++u) sd[u][k] = *(GP(T))(pl + obc[u]);
     }
-#endif
     float bias[M][M];
     // (wave-uniform: scalar loads.  Fetching the block with vector loads instead — it overflows the scalar register file and
     // part of it is spilled to vector-register lanes — was measured 9 % slower per fold launch: twelve more vector-memory
@@ -459,11 +429,11 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   DT_STAMP(5);
 }
 
-#ifndef PBD_DT_WPE
-#define PBD_DT_WPE 3     // wavefronts per SIMD the register allocation must allow (experiment builds: 5 -> 96 registers, see the Makefile)
-#endif
+// (round 5, measured and rejected: the register allocation forced to 96 — launch bound 5 — so that two DT wavefronts fit on a SIMD beside a
+//  304-register wavefront of the split-product bank: dp_min 0.339-0.344 ms per frame against 0.330-0.337, 2 029-2 056 against 2 089-2 118 frames/s;
+//  the fold loader fetching the next child's planes under this child's arithmetic: 0.333-0.344 against 0.337-0.342, 0.585-0.588 against 0.581 alone)
 template <typename T, int FM>
-__global__ __launch_bounds__(256, PBD_DT_WPE) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
+__global__ __launch_bounds__(256, 3) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
                                                     const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   DT_STAMP(0);

@@ -277,7 +277,7 @@ def test_pdf_mfma_tuning_variants(gpu_required, variant):
     assert worst < 2e-5, worst
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 6])
+@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7, 8])
 def test_pdf_split_tuning_variants(gpu_required, variant):
     """The split-product bank's kernels kept behind PBD_SPLIT_VARIANT (tuning build only: loads as a block / two-wavefront workgroups /
     hipcc's own schedule / the persistent double-buffered kernel) against the oracle: ragged levels,
