@@ -301,9 +301,11 @@ static int upload_model(pbd_handle* h) {
   } else {
     HIPCHK(h, hipMemcpy(h->d_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  size_t split_bytes = 0;
   if (h->conv_mode == PBD_CONV_SPLIT) {   // the three exact bfloat16 parts of every weight, in the MFMA operand order of k_conv_split32
     std::vector<uint16_t> wS;
     conv_split_filters(h->filters.data(), m.nfilters, m.kh, m.kw, wS);
+    split_bytes = wS.size() * sizeof(uint16_t);
     HIPCHK(h, hipMalloc((void**)&h->d_wS, wS.size() * sizeof(uint16_t)));
     HIPCHK(h, hipMemcpy(h->d_wS, wS.data(), wS.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
@@ -351,7 +353,7 @@ static int upload_model(pbd_handle* h) {
   HIPCHK(h, hipHostMalloc((void**)&h->h_cand_out, h->cand_stride * cap));
   HIPCHK(h, hipHostMalloc((void**)&h->h_cand_count, sizeof(int) * 4));
   h->model_bytes = wT.size() * h->ts + hog_binlut_bytes() + bw.size() * sizeof(float) + (par.size() * 4 + npv.size()) * sizeof(int) + sizeof(int) +
-                   sizeof(CandRec) * cap + h->cand_stride * cap;
+                   sizeof(CandRec) * cap + h->cand_stride * cap + split_bytes;
   return PBD_OK;
 }
 
@@ -1764,7 +1766,7 @@ int pbd_get_footprint(const pbd_handle* h, size_t* frame_bytes, size_t* model_by
   return PBD_OK;
 }
 int pbd_abi_version(void) { return PBD_ABI_VERSION; }
-int pbd_get_conv_mode(const pbd_handle* h) { return h ? h->conv_mode : PBD_ERR_ARG; }   // what PBD_CONV_AUTO resolved to
+int pbd_get_conv_mode(const pbd_handle* h) { return h ? h->conv_mode : -PBD_ERR_ARG; }   // what PBD_CONV_AUTO resolved to (negative: error)
 int pbd_get_stage_state(const pbd_handle* h, int32_t state[4]) {
   if (!h || !state) return PBD_ERR_ARG;
   state[0] = h->have_pyr; state[1] = h->have_feat; state[2] = h->have_resp; state[3] = h->have_dp;

@@ -1717,3 +1717,12 @@ def test_fuzz_detect_one_seed(gpu_required):
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]     # (the tool asserts on the first difference)
     print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "")
+
+
+def test_fuzz_split_bank_one_seed(gpu_required):
+    """One bounded seed of tests/tools_fuzz_split.py: random banks (16 .. 340 filters, 3x3 .. 9x9, rectangular, cell sizes 4 / 8, ragged levels)
+    through the split-product filter bank against the oracle on every level."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools_fuzz_split.py"), "20", "3"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "")
