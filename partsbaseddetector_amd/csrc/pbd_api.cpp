@@ -571,6 +571,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
 
   // HOG tiles: TC x TC cells; shrink the tile until its LDS footprint fits
   h->hog_tc = 16;
+  if (const char* e = PBD_PROBE_ENV("PBD_HOG_TC")) h->hog_tc = std::max(2, std::min(16, atoi(e)));   // tuning builds
   while (h->hog_tc > 2 && hog_lds_bytes(m.sbin, h->hog_tc, h->ts) > 150 * 1024) h->hog_tc /= 2;
   if (hog_lds_bytes(m.sbin, h->hog_tc, h->ts) > 150 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "sbin too large");
   std::vector<HogTile> ht;
