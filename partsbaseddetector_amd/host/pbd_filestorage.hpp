@@ -17,10 +17,11 @@
 // .gitmodules:1-3) and OpenCV is not available here, so the reader is pinned only against this
 // writer and against hand-written samples in OpenCV's layout (tests/test_model_io.py).
 //
-// One deliberate difference: deserialize (:148-152) keeps `defid` only when the node is a scalar
+// One deliberate difference BY DEFAULT: deserialize (:148-152) keeps `defid` only when the node is a scalar
 // int and otherwise stores {0} — which silently breaks every part with more than one mixture
 // (defid is then a K-element sequence).  Here sequences are read as sequences (the evident
 // intent); a scalar still yields a 1-element vector and an empty node yields {0} like the reference.
+// setLiteralDefid(true) (pbd_modelconv --literal-defid) reads the field exactly as the reference does.
 #ifndef PBD_FILESTORAGE_HPP_
 #define PBD_FILESTORAGE_HPP_
 
@@ -227,6 +228,7 @@ class FsYaml {
 
 // ---- include/FileStorageModel.hpp:46-55 ----------------------------------------------------------------
 class FileStorageModel : public Model {
+  bool literal_defid_ = false;
   static bool mat_from(const FsNode& n, Mat& m) {
     const FsNode *r = n.get("rows"), *c = n.get("cols"), *d = n.get("data");
     if (!r || !c || !d) return false;
@@ -238,6 +240,10 @@ class FileStorageModel : public Model {
     return true;
   }
  public:
+  // false (default): `defid` sequences are read as sequences — the evident intent; true: src/FileStorageModel.cpp:148-152 literally
+  // (`if (defid.isInt()) defid >> defid_[c][p]; else defid_[c][p].push_back(0);` — every part with more than one mixture, and in YAML
+  // every part, ends up with the single deformation index 0): for a caller who wants the reference's behaviour on such a file bug for bug
+  void setLiteralDefid(bool on) { literal_defid_ = on; }
   bool deserialize(const std::string& filename) override {   // src/FileStorageModel.cpp:96-159
     std::ifstream f(filename.c_str(), std::ios::binary);
     if (!f) return false;
@@ -286,6 +292,8 @@ class FileStorageModel : public Model {
         const FsNode* d = part->get("defid");
         std::vector<int> dv = d ? d->numbers<int>() : std::vector<int>();
         if (dv.empty()) dv.push_back(0);                 // :151 (empty / missing node)
+        if (literal_defid_)                              // :148-152 to the letter: a scalar int is kept, anything else (a K-element sequence!) becomes {0}
+          dv = (d && d->isInt()) ? std::vector<int>(1, (int)d->real()) : std::vector<int>(1, 0);
         defid_[c][p] = dv;
       }
     }

@@ -65,3 +65,26 @@ def test_reader_rejects_garbage(tmp_path):
     (tmp_path / "bad.xml").write_text("<opencv_storage><name>x</name></opencv_storage>")
     out = subprocess.run([CONV, str(tmp_path / "bad.xml"), str(tmp_path / "o.bin")], capture_output=True, text=True)
     assert out.returncode != 0 and "Error deserializing" in out.stdout   # deserialize() returns false (demo.cpp:79-82)
+
+
+def test_filestorage_reader_literal_defid(tmp_path):
+    """--literal-defid: `defid` read exactly as src/FileStorageModel.cpp:148-152 reads it — a scalar int is kept, any other node (the K-element
+    sequence of a part with several mixtures; in YAML every flow sequence) becomes {0}; the default reader keeps the sequences."""
+    assert os.path.exists(CONV), "build() did not produce pbd_modelconv"
+    m3 = make_tree_model([-1, 0, 1], 3, seed=5)           # K = 3: defid sequences of three
+    m1 = make_tree_model([-1, 0, 1], 1, seed=5)           # K = 1: one index per part
+    for m, ext, want in ((m3, ".xml", "zero"), (m1, ".xml", "kept"), (m1, ".yaml", "zero")):
+        src = tmp_path / ("m" + ext)
+        m.name = "Synthetic"
+        m.save_filestorage(str(src))
+        out = subprocess.run([CONV, "--literal-defid", str(src), str(tmp_path / "lit.bin")], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lit = Model.load(str(tmp_path / "lit.bin"))
+        _conv(src, tmp_path / "dflt.bin")
+        dflt = Model.load(str(tmp_path / "dflt.bin"))
+        for p in range(1, m.nparts(0)):
+            assert list(dflt.defid[0][p]) == list(m.defid[0][p])
+            if want == "zero":      # (the flat dump repeats the single index for every mixture of the part)
+                assert set(lit.defid[0][p]) == {0} and any(v != 0 for v in m.defid[0][p]) or p == 1 and list(m.defid[0][p])[0] == 0, (ext, p, lit.defid[0][p])
+            else:
+                assert list(lit.defid[0][p]) == list(m.defid[0][p]), (ext, p, lit.defid[0][p])
