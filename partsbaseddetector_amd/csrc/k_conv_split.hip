@@ -531,7 +531,10 @@ static void launch_conv_split_nw(const ConvTile* tiles, int ntiles, const LevelD
                                  float* resp, int nf, int kh, int kw, hipStream_t s, int G = 5) {
   // groups of G = five n-tiles (160 filters: the person bank's 156 in one pass), then the remainder with its own instantiation
   // (G = 4 / 3: tuning variants — fewer accumulators per wavefront, two wavefronts per SIMD, every tile staged once per group)
-  const int ntl = conv_split_ntiles(nf), full = ntl / G, rest = ntl - G * full;
+  // (banks of more than 160 filters: balanced groups — 208 filters as 4 + 3 n-tiles instead of 5 + 2 — measured the same, 0.300 vs 0.302 ms per frame: what a
+  //  second group costs is staging every tile again and a second launch tail, not the smaller register block; session 11)
+  const int ntl = conv_split_ntiles(nf);
+  const int full = ntl / G, rest = ntl - G * full;
   auto go = [&](int nt, int ntile0, int ngroups) {
     switch (nt) {
       case 1: launch_conv_split_t<1, NW, PIN>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s); break;
