@@ -113,7 +113,8 @@ def main_group(args):
     model = make_person_model(K=args.mixtures)
     dtype = np.float64 if args.dtype == "f64" else np.float32
     model.thresh = pick_threshold(capi, model, torch.from_numpy(make_image(0, W, H)).cuda(), W, H, dtype=dtype)
-    conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA, "split": capi.PBD_CONV_SPLIT}[args.conv]
+    conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA, "split": capi.PBD_CONV_SPLIT,
+            "split16": capi.PBD_CONV_SPLIT_F16}[args.conv]
     # every device listed S times (S frames in flight per device: host gather — RCCL wants distinct devices); S = 1: the RCCL all-gather
     # when librccl loads and N > 1 (PBD_GATHER_AUTO), and the line says which one ran and on how many ranks
     g = capi.Group(model, [d for _ in range(S) for d in range(N)], gather=capi.PBD_GATHER_HOST if S > 1 else capi.PBD_GATHER_AUTO, conv_mode=conv, dtype=dtype, graph=args.graph)
@@ -149,7 +150,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--conv", choices=["auto", "exact", "mfma", "split"], default="auto")
+    ap.add_argument("--conv", choices=["auto", "exact", "mfma", "split", "split16"], default="auto")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("PBD_INFLIGHT", "3")),
                     help="steps in flight per GPU on independent handles/streams (default 3 handles x batches of 8 frames: "
                          "best measured throughput); 1 = strictly sequential calls (latency mode)")
@@ -175,13 +176,13 @@ def main():
     ap.add_argument("--no-prewarm", action="store_true", help="skip the fixed pre-warm (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for CPU-side smoke runs)")
     ap.add_argument("--legs", default="all",
-                    help="comma-separated subset of timed,h2d,mfma32,single,seq,batchseq,cpu (default all).  timed = the K steps `value` is quoted "
+                    help="comma-separated subset of timed,h2d,mfma32,split16,single,seq,batchseq,cpu (default all).  timed = the K steps `value` is quoted "
                          "on; h2d = the same with pinned host images; single = the handles fed one frame per call; seq = sequential "
                          "single frames with stage events; batchseq = batches one at a time with stage events (`roofline`); mfma32 = the "
                          "timed leg once more on handles with the fp32 MFMA filter bank (`value_fp32_mfma`, N = 1, when the timed handles run the split bank); cpu = the "
                          "oracle on the host cores.  Without `timed` the line's value is null (profiling runs)")
     args = ap.parse_args()
-    ALL_LEGS = ("timed", "h2d", "mfma32", "single", "seq", "batchseq", "cpu")
+    ALL_LEGS = ("timed", "h2d", "mfma32", "split16", "single", "seq", "batchseq", "cpu")
     legs = set(ALL_LEGS) if args.legs == "all" else set(x for x in args.legs.split(",") if x)
     if legs - set(ALL_LEGS):
         raise SystemExit(f"--legs: unknown leg(s) {sorted(legs - set(ALL_LEGS))}; choose from {ALL_LEGS}")
@@ -221,7 +222,8 @@ def main():
 
     W, H = args.width, args.height
     model = make_person_model(K=args.mixtures)
-    conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA, "split": capi.PBD_CONV_SPLIT}[args.conv]
+    conv = {"auto": capi.PBD_CONV_AUTO, "exact": capi.PBD_CONV_EXACT, "mfma": capi.PBD_CONV_MFMA, "split": capi.PBD_CONV_SPLIT,
+            "split16": capi.PBD_CONV_SPLIT_F16}[args.conv]
     dtype = np.float64 if args.dtype == "f64" else np.float32
     # distinct frames per rank and per step slot (32 seeds as in configs[2]); resident in HBM and, for the
     # H2D-inclusive leg, in pinned host memory
@@ -356,7 +358,9 @@ def main():
     # ---- the timed leg once more with the fp32 MFMA filter bank (rounds 3-4's default) beside the split-product bank: same frames,
     #      same steps (bounded), fresh handles; N = 1 only ----
     CONV_NAMES = {capi.PBD_CONV_EXACT: "exact (VALU, reference summation order)", capi.PBD_CONV_MFMA: "mfma (fp32 / fp64 MFMA, k-ordered fma chain)",
-                  capi.PBD_CONV_SPLIT: "split (fp32 products as six exact bfloat16 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulators)"}
+                  capi.PBD_CONV_SPLIT: "split (fp32 products as six exact bfloat16 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulators)",
+                  capi.PBD_CONV_SPLIT_F16: "split16 (OPT-IN: two scaled binary16 parts per operand, three products on v_mfma_f32_32x32x16_f16, fp32 accumulators; "
+                                           "operands carried to 23 of 24 bits)"}
     conv_resolved = handles[0].conv_mode
     # (a SEPARATE process: fresh handles created beside the timed ones in this process stalled for tens of ms at a time — r05 session 2 —,
     #  and a second process repeats the protocol exactly: pre-warm, warm-up, K steps.  This process's handles are idle meanwhile.)
@@ -374,6 +378,26 @@ def main():
                 value_mfma32 = json.loads(sub[-1])["value"]
         except (subprocess.TimeoutExpired, ValueError, KeyError):
             value_mfma32 = None
+    # ---- and with the opt-in binary16 bank (PBD_CONV_SPLIT_F16: half the matrix instructions; NOT the benched path) ----
+    split16 = None
+    if "split16" in legs and world == 1 and conv_resolved == capi.PBD_CONV_SPLIT:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps_mfma32), "--warmup", str(args.warmup), "--conv", "split16",
+               "--legs", "timed,batchseq", "--inflight", str(S), "--batch", str(B), "--width", str(W), "--height", str(H), "--mixtures", str(args.mixtures),
+               "--dtype", args.dtype, "--graph", str(args.graph)]
+        torch.cuda.synchronize()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and sub:
+                j = json.loads(sub[-1])
+                split16 = {"value": j["value"], "unit": "frames/s", "steps": steps_mfma32, "pdf_ms_per_frame_batched": j.get("pdf", {}).get("ms_per_frame_batched"),
+                           "pdf_fp32_equivalent_TFLOP/s": j.get("pdf", {}).get("TFLOP/s_batched"), "dp_min_ms_per_batch": j.get("roofline", {}).get("launch_ms"),
+                           "what": "`bench.py --conv split16 --legs timed,batchseq` as a child process: PBD_CONV_SPLIT_F16, the OPT-IN bank of two scaled binary16 "
+                                   "parts per operand and three products (include/pbd_c.h; errors against fp64 measured equal to the benched bank's, operands carried "
+                                   "to 23 of their 24 bits) — reported beside `value`, never as it"}
+        except (subprocess.TimeoutExpired, ValueError, KeyError):
+            split16 = None
     if world > 1:
         ncand_all = sum(len(g[0]) for g in gathered_last[0]) if (rank == 0 and gathered_last[0]) else 0   # the last step's gather (inside the timed region)
     else:
@@ -485,9 +509,9 @@ def main():
                     "launch_ms": round(float(stage["pdf"]), 4), "algorithmic_flops": work["F_pdf"]}
         # filter bank: fp32-equivalent flops (F_pdf) per second; the split bank executes 6 bf16 MFMA flops per fp32-equivalent one and is
         # priced against the dense bf16 peak (2.5 PF), the fp32 / fp64 MFMA banks against theirs
-        is_split = conv_resolved == capi.PBD_CONV_SPLIT
-        pdf_peak = 2500.0 if is_split else (78.6 if args.dtype == "f64" else 157.3)
-        pdf_mult = 6.0 if is_split else 1.0
+        is_split = conv_resolved in (capi.PBD_CONV_SPLIT, capi.PBD_CONV_SPLIT_F16)
+        pdf_peak = 2500.0 if is_split else (78.6 if args.dtype == "f64" else 157.3)       # (bf16 and f16 dense MFMA peaks are the same)
+        pdf_mult = 6.0 if conv_resolved == capi.PBD_CONV_SPLIT else 3.0 if is_split else 1.0
         pdf_ms_b = stage_batch["pdf"] / B if stage_batch else None
         pdf_tf_b = work["F_pdf"] / (pdf_ms_b * 1e-3) / 1e12 if pdf_ms_b else None
         pdf_block = {"TFLOP/s": round(pdf_tf, 3), "what": "fp32-equivalent TFLOP/s (F_pdf = 2 x cells x filters x kh kw 32), a frame on its own",
@@ -541,6 +565,7 @@ def main():
             "value_fp32_mfma": value_mfma32,
             "value_fp32_mfma_is": (f"`value` of `bench.py --conv mfma --legs timed --steps {steps_mfma32}` (PBD_CONV_MFMA: the fp32 v_mfma_f32_16x16x4_f32 bank, the default of "
                                    f"rounds 3-4), run as a child process after this process's timed legs" if value_mfma32 else None),
+            "opt_in_split_f16": split16,
             "value_single_frame_calls": (round(args.steps * B * S / dt_single, 3) if dt_single else None),
             "value_is": "frames resident in HBM when the timed region starts (the tier's contract, DESIGN.md 7); value_incl_h2d = the same steps "
                         "from pinned host images; value_single_frame_calls = ONE GPU's handles fed one frame per call",

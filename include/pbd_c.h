@@ -87,11 +87,19 @@ enum {
   PBD_CONV_MFMA = 2,  /* MFMA implicit GEMM (k-ordered fma chain) for any kh x kw: fp32
                          v_mfma_f32_16x16x4_f32 for float handles, fp64
                          v_mfma_f64_16x16x4_f64 for double handles             */
-  PBD_CONV_SPLIT = 3  /* float handles, any kh x kw (x 32 channels): the fp32 products on the bf16 matrix units through EXACT
+  PBD_CONV_SPLIT = 3, /* float handles, any kh x kw (x 32 channels): the fp32 products on the bf16 matrix units through EXACT
                          three-way splits (x = h + m + l, three bfloat16 of 8 significant bits; the six partial products above
                          2^-24 relative on v_mfma_f32_32x32x16_bf16, fp32 accumulators): fp32 in, fp32 out, errors of the size of
                          PBD_CONV_MFMA's, on hardware the vector ALU does not share.  Weights must be finite
                          and below 3e38 in magnitude (bfloat16's range)                                          */
+  PBD_CONV_SPLIT_F16 = 4 /* opt-in, never what AUTO resolves to.  float handles: TWO binary16 parts per operand (11 significant
+                         bits each, operands scaled by powers of two into binary16's range: features by 2^12, a bank's weights to
+                         max |w| 2^e in [2^13, 2^14)) and the THREE products above 2^-22 relative on v_mfma_f32_32x32x16_f16, fp32
+                         accumulators, responses scaled back exactly — half the matrix instructions of PBD_CONV_SPLIT.  Operands
+                         are carried to 23 of their 24 bits; measured errors against fp64 on HOG features: those of
+                         PBD_CONV_SPLIT.  Domain: |feature| < 16 (HOG features are <= 1; features handed in
+                         through pbd_set_level_features must respect it), weights finite; a feature below 2^-26 or a
+                         weight below 2^-27 max |w| loses relative (not absolute) precision.                      */
 };
 /* Scalar type T of the instantiation (src/PartsBasedDetector.cpp:132-133):
  * PartsBasedDetector<float> (src/demo.cpp:85) or PartsBasedDetector<double>
@@ -136,7 +144,7 @@ typedef struct pbd_options {
 int pbd_abi_version(void);
 /* Version history: 3 = rounds 3-4.  4 (round 5) = PBD_CONV_AUTO resolves to PBD_CONV_SPLIT for float handles (numerics of
  * AUTO change in the last bits: rounds 3-4 resolved to PBD_CONV_MFMA, and before that to EXACT for banks other than 5 x 5),
- * PBD_CONV_SPLIT, pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state, pbd_group_comm_size.  Struct layouts unchanged.   */
+ * PBD_CONV_SPLIT, PBD_CONV_SPLIT_F16, pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state, pbd_group_comm_size.  Struct layouts unchanged.   */
 
 /* ---- output record: include/Candidate.hpp:56-111 --------------------------
  * One candidate = head + max_parts boxes (x, y, width, height as cv::Rect)

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("PBD_LIBRARY") or os.path.join(_HERE, "libpbd_hip.so")
 
 PBD_OK, PBD_ERR_ARG, PBD_ERR_UNSUPPORTED, PBD_ERR_CAPACITY, PBD_ERR_HIP, PBD_ERR_STATE, PBD_ERR_RCCL = range(7)
 PBD_GATHER_AUTO, PBD_GATHER_HOST, PBD_GATHER_RCCL = 0, 1, 2
-PBD_CONV_AUTO, PBD_CONV_EXACT, PBD_CONV_MFMA, PBD_CONV_SPLIT = 0, 1, 2, 3
+PBD_CONV_AUTO, PBD_CONV_EXACT, PBD_CONV_MFMA, PBD_CONV_SPLIT, PBD_CONV_SPLIT_F16 = 0, 1, 2, 3, 4
 PBD_SCALAR_F32, PBD_SCALAR_F64 = 0, 1
 
 EXPORTS = [

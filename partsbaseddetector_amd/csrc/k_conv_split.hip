@@ -24,11 +24,14 @@
 //     M-tile is permuted so that each group IS one row of 16 cells);
 //   * the valid cells of a ragged unit are packed into M-tiles (level edges issue no MFMAs for cells that do not exist).
 #include <algorithm>
+#include <cmath>
+#include <type_traits>
 #include <vector>
 #include <cstring>
 #include "pbd_internal.hpp"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -91,13 +94,77 @@ void conv_split_filters(const float* filters, int nf, int kh, int kw, std::vecto
 // NT: 32-filter n-tiles per workgroup (1..5); NW: wavefronts per workgroup (2: a 16 x 8 half of a ConvTile, 4: the whole 16 x 16 tile)
 // PIN: the K loop's schedule for ONE wavefront per SIMD (see the loop): 1 = the next k-step's loads as a block in front of this k-step's MFMAs,
 // 2 = the same loads dealt out between the MFMAs (sched_group_barrier); 0: hipcc's own schedule at two wavefronts per SIMD
-template <int NT, int NW, int PIN>
+// ---------------------------------------------------------------------------------------------------------------------
+// PBD_CONV_SPLIT_F16 (opt-in): TWO binary16 parts per operand and THREE products.  binary16 carries 11 significant bits: with
+// x 2^e = h + m (h = RN16(x 2^e), m = RN16(x 2^e - h), the subtraction exact) two parts hold 22-23 of an fp32 number's 24 bits,
+// every product of two parts is exact in an fp32 accumulator, and h h + h m + m h leaves out terms of 2^-22 relative — against
+// 2^-24 for the six bfloat16 products, but far under what the fp32 ACCUMULATION of 800 terms loses either way: measured against
+// fp64 on the person bank (tests/tools_split_products_study.py) max 3.2e-7 / rms 4.1e-8, the six-product bank 3.1e-7 / 3.2e-8,
+// the fp32 MFMA chain 9.1e-7 / 8.2e-8.  Half the matrix instructions of the six-product bank.
+// binary16's range is the price: operands are scaled by powers of two (exact) to sit high in it — features by 2^12 (HOG features
+// are <= 1: the truncation channel; |feature| must stay below 16), every filter's weights by its own 2^e with max |w| 2^e in
+// [2^13, 2^14) — and a part below 2^-14 (scaled) is a binary16 subnormal of absolute precision 2^-25: an absolute error of 2^-37
+// per feature, 2^-38 of the filter's max |w| per weight.  A filter's responses are multiplied by 2^-(12 + e) on the way out (exact).  Not the default and not what
+// PBD_CONV_AUTO resolves to: the operands are represented to 23 bits, not 24 — bench.py reports it beside the benched bank.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SPLIT16_FEXP = 12;
+__global__ __launch_bounds__(256) void k_feat_split16(const float* __restrict__ feat, uint16_t* __restrict__ out, size_t ngroups) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;    // (cell, channel group g = i & 3)
+  if (i >= ngroups) return;
+  const f32x4 a = *(const f32x4*)(feat + i * 8), b = *(const f32x4*)(feat + i * 8 + 4);
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  f16x8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = v[e] * (float)(1 << SPLIT16_FEXP);
+    hi[e] = (_Float16)x;                                        // round to nearest even
+    lo[e] = (_Float16)(x - (float)hi[e]);                       // (the subtraction is exact)
+  }
+  const size_t cell = i >> 2, g = i & 3;
+  *(f16x8*)(out + (cell * 2 + 0) * PBD_FLEN + g * 8) = hi;
+  *(f16x8*)(out + (cell * 2 + 1) * PBD_FLEN + g * 8) = lo;
+}
+void launch_feat_split16(const float* feat, uint16_t* out, size_t ncells, hipStream_t s) {
+  const size_t ngroups = ncells * 4;
+  if (!ngroups) return;
+  hipLaunchKernelGGL(k_feat_split16, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, feat, out, ngroups);
+}
+// filters -> [tap][k-step][part (2)][n-tile][k-group][32][8] binary16 of w 2^e(filter); oscale[filter] = the response scale 2^-(12 + e)
+void conv_split16_filters(const float* filters, int nf, int kh, int kw, std::vector<uint16_t>& out, std::vector<float>& oscale) {
+  const int ntap = kh * kw, NTL = conv_split_ntiles(nf);
+  out.assign((size_t)ntap * 2 * 2 * NTL * 512, 0);
+  oscale.assign((size_t)NTL * 32, 1.f);
+  for (int fn = 0; fn < nf; ++fn) {
+    const float* wf = filters + (size_t)fn * ntap * PBD_FLEN;
+    float wmax = 0.f;
+    for (int i = 0; i < ntap * PBD_FLEN; ++i) wmax = std::max(wmax, std::fabs(wf[i]));
+    int x = 0;
+    if (wmax > 0.f) std::frexp(wmax, &x);                     // wmax = f 2^x, f in [0.5, 1)
+    const int e = wmax > 0.f ? std::min(100, std::max(-110, 14 - x)) : 0;
+    oscale[fn] = std::ldexp(1.0f, -(SPLIT16_FEXP + e));
+    for (int tap = 0; tap < ntap; ++tap)
+      for (int c = 0; c < PBD_FLEN; ++c) {
+        float r = std::ldexp(filters[((size_t)fn * ntap + tap) * PBD_FLEN + c], e);
+        const int ks = c >> 4, kg = (c >> 3) & 1, el = c & 7;
+        for (int s = 0; s < 2; ++s) {
+          const _Float16 hv = (_Float16)r;
+          uint16_t bits; memcpy(&bits, &hv, 2);
+          out[((((size_t)(tap * 2 + ks) * 2 + s) * NTL + fn / 32) * 2 + kg) * 256 + (size_t)(fn % 32) * 8 + el] = bits;
+          r -= (float)hv;                                       // exact
+        }
+      }
+  }
+}
+
+// NS: parts per operand — 3: bfloat16 parts, six products (PBD_CONV_SPLIT); 2: scaled binary16 parts, three products (PBD_CONV_SPLIT_F16, below)
+template <int NT, int NW, int PIN, int NS = 3>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN ? 1 : 2))) void k_conv_split32(const ConvTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
                                                              const uint16_t* __restrict__ feat, const uint16_t* __restrict__ filt,
                                                              float* __restrict__ resp, int nf, int ntl_bank, int ntile0, int ngroups,
-                                                             int ntiles_total, int kh, int kw) {
+                                                             int ntiles_total, int kh, int kw, const float* __restrict__ oscale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ROWS = 4 * NW, NHALVES = 16 / ROWS, NTHR = 64 * NW;
+  using opnd = std::conditional_t<NS == 3, bf16x8, f16x8>;
+  constexpr int ROWS = 4 * NW, NHALVES = 16 / ROWS, NTHR = 64 * NW, PPC = 4 * NS;   // PPC: 16-byte pieces per cell
   const int TW = 16 + kw - 1, TH = ROWS + kh - 1, NC = TW * TH, PLANE = NC * 64;
   // workgroup -> (tile, role = (half, n-group)): tile position 8 g + x runs on XCD x (the plan pairs horizontal neighbours on that
   // convention); the roles of a tile share lin % 8 (one XCD: the halves' common halo rows and the n-groups' common tile come from
@@ -114,10 +181,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
   const int ty0 = t.y0 + ROWS * half, tx0 = t.x0;
   if (ty0 >= H) return;                                  // the lower half of a tile on the level's last rows
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint16_t* F = feat + lv.cell_off * (3 * PBD_FLEN);
-  {  // stage the halo tile: 12 16-byte pieces per cell (piece = 4 split + channel group), batches of independent loads; outside the
-     // level: zeros, and 1.0 (0x3F80, exact in bfloat16: part h) in the truncation channel = element 7 of piece 3 (:147-155)
-    const int NPC = NC * 12, oy = ty0 - kh / 2, ox = tx0 - kw / 2;
+  const uint16_t* F = feat + lv.cell_off * (NS * PBD_FLEN);
+  {  // stage the halo tile: 4 NS 16-byte pieces per cell (piece = 4 split + channel group), batches of independent loads; outside the
+     // level: zeros, and 1.0 (0x3F80, exact in bfloat16: part h; binary16 parts: 2^12 = 0x6C00) in the truncation channel = element 7 of piece 3 (:147-155)
+    const int NPC = NC * PPC, oy = ty0 - kh / 2, ox = tx0 - kw / 2;
+    constexpr unsigned ONE = NS == 3 ? 0x3F800000u : 0x6C000000u;
+    auto cell_of = [](int i) { return NS == 3 ? (int)(((unsigned)i * 43691u) >> 19) : i >> 3; };     // i / 12 (exact for i < 2^17), i / 8
     const unsigned magic_tw = 0xFFFFFFFFu / (unsigned)TW + 1u;     // cell / TW = umulhi(cell, magic) (cell * TW < 2^32)
     constexpr int BATCH = 12;
     for (int i0 = 0; i0 < NPC; i0 += NTHR * BATCH) {
@@ -125,20 +194,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         const int i = min(i0 + j * NTHR + tid, NPC - 1);
-        const int cell = (int)(((unsigned)i * 43691u) >> 19), piece = i - cell * 12;     // i / 12, exact for i < 2^17
+        const int cell = cell_of(i), piece = i - cell * PPC;
         const int cy = (int)__umulhi((unsigned)cell, magic_tw), cx = cell - cy * TW;
         const int y = min(max(oy + cy, 0), H - 1), x = min(max(ox + cx, 0), W - 1);
-        v[j] = *(const u32x4*)(F + ((size_t)(y * W + x) * (3 * PBD_FLEN) + piece * 8));
+        v[j] = *(const u32x4*)(F + ((size_t)(y * W + x) * (NS * PBD_FLEN) + piece * 8));
       }
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         const int i = i0 + j * NTHR + tid;
         if (i < NPC) {
-          const int cell = (int)(((unsigned)i * 43691u) >> 19), piece = i - cell * 12;
+          const int cell = cell_of(i), piece = i - cell * PPC;
           const int cy = (int)__umulhi((unsigned)cell, magic_tw), cx = cell - cy * TW;
           const int y = oy + cy, x = ox + cx;
           const bool inside = y >= 0 && y < H && x >= 0 && x < W;
-          const u32x4 border = u32x4{0u, 0u, 0u, piece == 3 ? 0x3F800000u : 0u};
+          const u32x4 border = u32x4{0u, 0u, 0u, piece == 3 ? ONE : 0u};
           const int q = piece & 3;
           *(u32x4*)(smem + (piece >> 2) * PLANE + cell * 64 + ((q ^ ((cell >> 2) & 3)) << 4)) = inside ? v[j] : border;
         }
@@ -177,43 +246,51 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][m][r] = 0.f;
   const uint16_t* bl = filt + (size_t)ntb * 512 + lane * 8;
-  const size_t bs_split = (size_t)ntl_bank * 512, bs_kstep = 3 * bs_split;
+  const size_t bs_split = (size_t)ntl_bank * 512, bs_kstep = NS * bs_split;
   const int nkstep = 2 * kh * kw;
 
-  auto k_loop = [&](auto mv_tag) {
+  auto k_loop = [&](auto mv_tag) __attribute__((always_inline)) {
     constexpr int MV = decltype(mv_tag)::value;
-    auto load_b = [&](bf16x8 (&b)[NT][3], int kstep) {
+    auto load_b = [&](opnd (&b)[NT][NS], int kstep) __attribute__((always_inline)) {
       const uint16_t* p = bl + (size_t)min(kstep, nkstep - 1) * bs_kstep;
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt][s] = *(const bf16x8*)(p + s * bs_split + nt * 512);
+        for (int nt = 0; nt < NT; ++nt) b[nt][s] = *(const opnd*)(p + s * bs_split + nt * 512);
     };
-    auto load_a = [&](bf16x8 (&a)[2][3], int tapofs, int ks) {     // tapofs = ti * TW + tj
+    auto load_a = [&](opnd (&a)[2][NS], int tapofs, int ks) __attribute__((always_inline)) {     // tapofs = ti * TW + tj
 #pragma unroll
       for (int m = 0; m < MV; ++m) {
         const int cl = cl0[m] + tapofs;
         const char* p = smem + cl * 64 + (((2 * ks + kg) ^ ((cl >> 2) & 3)) << 4);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) a[m][s] = *(const bf16x8*)(p + s * PLANE);
+        for (int s = 0; s < NS; ++s) a[m][s] = *(const opnd*)(p + s * PLANE);
       }
     };
-    auto mma = [&](const bf16x8 (&a)[2][3], const bf16x8 (&b)[NT][3]) {
+    auto mma = [&](const opnd (&a)[2][NS], const opnd (&b)[NT][NS]) __attribute__((always_inline)) {
       // products outermost (consecutive MFMAs go to different accumulators: an accumulator is touched every 2 NT instructions)
-      auto sweep = [&](int sa, int sb) {
+      auto sweep = [&](int sa, int sb) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int m = 0; m < MV; ++m) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nt][sb], a[m][sa], acc[nt][m], 0, 0, 0);
+          for (int m = 0; m < MV; ++m) {
+            if constexpr (NS == 3) acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nt][sb], a[m][sa], acc[nt][m], 0, 0, 0);
+            else acc[nt][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[nt][sb], a[m][sa], acc[nt][m], 0, 0, 0);
+          }
       };
       // feature part x filter part, the small products of a k-step before its large one: m m, h l, l h (2^-16), h m, m h (2^-8), h h
-      sweep(1, 1); sweep(0, 2); sweep(2, 0); sweep(0, 1); sweep(1, 0); sweep(0, 0);
+      // (binary16 parts: h m, m h (2^-11), h h)
+      if constexpr (NS == 3) { sweep(1, 1); sweep(0, 2); sweep(2, 0); }
+      sweep(0, 1); sweep(1, 0); sweep(0, 0);
     };
-    bf16x8 a0[2][3], a1[2][3], b0[NT][3], b1[NT][3];
-    load_b(b0, 0);
-    load_a(a0, 0, 0);
     int ti = 0, tj = 0;
     const int ntap = kh * kw;
+    // (binary16 parts: a k-step is 30 MFMAs = 960 cycles, and SQ_WAIT_INST_ANY reads 32 % of the wavefronts' cycles.  The filters TWO k-steps
+    //  ahead — three register sets in rotation, a body of three taps — measured the same pdf time, 0.141 vs 0.139-0.141 ms per frame, at 430
+    //  registers: no distance-transform wavefront beside it, 2 150 vs 2 225-2 277 frames/s; r05 session 15.  Not latency: the operand traffic.)
+    opnd a0[2][NS], a1[2][NS], b0[NT][NS], b1[NT][NS];
+    load_b(b0, 0);
+    load_a(a0, 0, 0);
 #pragma unroll 1
     for (int tap = 0; tap < ntap; ++tap) {
       // operands in explicit ping-pong, the schedule pinned: the next k-step's 15 filter loads + 6 LDS reads are ISSUED before this
@@ -223,9 +300,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
       auto deal = [&]() {   // PIN == 2: one load per three MFMAs, then one LDS read per two (the MFMA pipe never waits for an issue burst)
         if constexpr (PIN == 2) {
 #pragma unroll
-          for (int i = 0; i < 3 * NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, MV == 2 ? 3 : 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+          for (int i = 0; i < NS * NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, NS == 3 ? (MV == 2 ? 3 : 1) : MV, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
 #pragma unroll
-          for (int i = 0; i < 3 * MV; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+          for (int i = 0; i < NS * MV; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
         }
       };
       if (PIN) __builtin_amdgcn_sched_barrier(0);
@@ -261,7 +338,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int fo = (r & 3) + 8 * (r >> 2);
-          if (32 * (ntb + nt) + 4 * kg + fo < nf) pl[(size_t)fo * HW] = acc[nt][m][r];
+          if (32 * (ntb + nt) + 4 * kg + fo < nf) pl[(size_t)fo * HW] = NS == 3 ? acc[nt][m][r] : acc[nt][m][r] * oscale[32 * (ntb + nt) + 4 * kg + fo];   // (a power of two: exact)
         }
       }
     }
@@ -515,16 +592,41 @@ void launch_conv_split_persistent(const ConvTile* tiles, int ntiles, const Level
   }
 }
 
-template <int NT, int NW, int PIN>
+template <int NT, int NW, int PIN, int NS = 3>
 static void launch_conv_split_t(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
-                                float* resp, int nf, int ntl_bank, int ntile0, int ngroups, int kh, int kw, hipStream_t s) {
+                                float* resp, int nf, int ntl_bank, int ntile0, int ngroups, int kh, int kw, hipStream_t s, const float* oscale = nullptr) {
   constexpr int ROWS = 4 * NW, NHALVES = 16 / ROWS;
-  const size_t lds = (size_t)(16 + kw - 1) * (ROWS + kh - 1) * 192;
+  const size_t lds = (size_t)(16 + kw - 1) * (ROWS + kh - 1) * 64 * NS;
   static LdsOptIn optin;
-  optin.ensure((const void*)k_conv_split32<NT, NW, PIN>, lds);
+  optin.ensure((const void*)k_conv_split32<NT, NW, PIN, NS>, lds);
   const int grid = (ntiles + 7) / 8 * 8 * NHALVES * ngroups;
-  hipLaunchKernelGGL((k_conv_split32<NT, NW, PIN>), dim3(grid), dim3(64 * NW), lds, s, tiles, levels, feat_split, wS, resp, nf, ntl_bank,
-                     ntile0, ngroups, ntiles, kh, kw);
+  hipLaunchKernelGGL((k_conv_split32<NT, NW, PIN, NS>), dim3(grid), dim3(64 * NW), lds, s, tiles, levels, feat_split, wS, resp, nf, ntl_bank,
+                     ntile0, ngroups, ntiles, kh, kw, oscale);
+}
+// PBD_CONV_SPLIT_F16: the default form of the six-product bank (4 wavefronts per workgroup, dealt loads, groups of five n-tiles) over two parts
+// variant (tuning builds, PBD_SPLIT_VARIANT): 4 = hipcc's own schedule at two wavefronts per SIMD, 7 / 8 = groups of four / three n-tiles
+template <int PIN>
+static void launch_conv_split16_g(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                                  float* resp, int nf, int kh, int kw, const float* oscale, int G, hipStream_t s) {
+  const int ntl = conv_split_ntiles(nf), full = ntl / G, rest = ntl - G * full;
+  auto go = [&](int nt, int ntile0, int ngroups) {
+    switch (nt) {
+      case 1: launch_conv_split_t<1, 4, PIN, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s, oscale); break;
+      case 2: launch_conv_split_t<2, 4, PIN, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s, oscale); break;
+      case 3: launch_conv_split_t<3, 4, PIN, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s, oscale); break;
+      case 4: launch_conv_split_t<4, 4, PIN, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s, oscale); break;
+      case 5: launch_conv_split_t<5, 4, PIN, 2>(tiles, ntiles, levels, feat_split, wS, resp, nf, ntl, ntile0, ngroups, kh, kw, s, oscale); break;
+      default: break;
+    }
+  };
+  if (full) go(G, 0, full);
+  if (rest) go(rest, G * full, 1);
+}
+void launch_conv_split16(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                         float* resp, int nf, int kh, int kw, const float* oscale, int variant, hipStream_t s) {
+  if (ntiles <= 0) return;
+  if (variant == 4) launch_conv_split16_g<0>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, oscale, 5, s);
+  else launch_conv_split16_g<2>(tiles, ntiles, levels, feat_split, wS, resp, nf, kh, kw, oscale, variant == 7 ? 4 : variant == 8 ? 3 : 5, s);
 }
 template <int NW, int PIN>
 static void launch_conv_split_nw(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,

@@ -115,7 +115,7 @@ size_t hog_lds_bytes(int sbin, int tc, int ts) { return hog_lds_layout(sbin, tc,
 template <typename T, int SBIN_T, int TC_T>
 __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
                                                 const uint8_t* __restrict__ pyr, T* __restrict__ feat, int cn,
-                                                int sbin_rt, int tc_rt, const uint8_t* __restrict__ binlut, uint16_t* __restrict__ split) {
+                                                int sbin_rt, int tc_rt, const uint8_t* __restrict__ binlut, uint16_t* __restrict__ split, int split_parts) {
   const int sbin = SBIN_T > 0 ? SBIN_T : sbin_rt;
   const int tc = TC_T > 0 ? TC_T : tc_rt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
         if constexpr (sizeof(T) == 4) {
           // PBD_CONV_SPLIT: the feature's three exact bfloat16 parts for the split-product filter bank, [cell][split][32] (k_conv_split.hip:
           // v = h + m + l, every subtraction exact) — written here instead of by a separate pass over the features
-          if (split) {
+          if (split && split_parts == 3) {
             uint16_t* sp = split + (lv.cell_off + gc) * (3 * PBD_FLEN) + k;
             float r = v;
 #pragma unroll
@@ -374,6 +374,12 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
               sp[q * PBD_FLEN] = (uint16_t)hb;
               r = r - __uint_as_float(hb << 16);
             }
+          } else if (split) {   // PBD_CONV_SPLIT_F16: two binary16 parts of v 2^12 (k_feat_split16)
+            _Float16* sp = (_Float16*)split + (lv.cell_off + gc) * (2 * PBD_FLEN) + k;
+            const float x = v * 4096.f;
+            const _Float16 hv = (_Float16)x;
+            sp[0] = hv;
+            sp[PBD_FLEN] = (_Float16)(x - (float)hv);
           }
         }
       }
@@ -385,12 +391,12 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
 
 template <typename T>
 static void launch_hog_t(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, T* feat,
-                         int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, hipStream_t s) {
+                         int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, hipStream_t s) {
   const size_t lds = hog_lds_bytes(sbin, tc, (int)sizeof(T));
   auto go = [&](auto kern) {
     static LdsOptIn optin;  // one per instantiation (the lambda is instantiated per kernel), per-device state inside
     optin.ensure((const void*)kern, lds);
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(HOG_NT), lds, s, tiles, levels, pyr, feat, cn, sbin, tc, binlut, split);
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(HOG_NT), lds, s, tiles, levels, pyr, feat, cn, sbin, tc, binlut, split, split_parts);
   };
   if (sbin == 4 && tc == 16) go(k_hog<T, 4, 16>);
   else if (sbin == 4 && tc == 8) go(k_hog<T, 4, 8>);
@@ -400,10 +406,10 @@ static void launch_hog_t(const HogTile* tiles, int ntiles, const LevelDev* level
 
 // ts = sizeof(T) of the handle's instantiation (HOGFeatures<float> / HOGFeatures<double>, src/HOGFeatures.cpp:51-52);
 // binlut: the orientation-snap table of the same T (launch_hog_binlut)
-// split != nullptr (float handles with the split-product filter bank): the features' bfloat16 parts are written too
+// split != nullptr (float handles with a split-product filter bank): the features' parts are written too — split_parts 3: bfloat16, 2: binary16
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
-                int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, hipStream_t s) {
+                int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, hipStream_t s) {
   if (ntiles <= 0) return;
-  if (ts == 8) launch_hog_t<double>(tiles, ntiles, levels, pyr, (double*)feat, cn, sbin, tc, binlut, nullptr, s);
-  else launch_hog_t<float>(tiles, ntiles, levels, pyr, (float*)feat, cn, sbin, tc, binlut, split, s);
+  if (ts == 8) launch_hog_t<double>(tiles, ntiles, levels, pyr, (double*)feat, cn, sbin, tc, binlut, nullptr, 0, s);
+  else launch_hog_t<float>(tiles, ntiles, levels, pyr, (float*)feat, cn, sbin, tc, binlut, split, split_parts, s);
 }

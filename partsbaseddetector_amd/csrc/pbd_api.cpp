@@ -302,10 +302,18 @@ static int upload_model(pbd_handle* h) {
     HIPCHK(h, hipMemcpy(h->d_wT, wT.data(), wT.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   size_t split_bytes = 0;
-  if (h->conv_mode == PBD_CONV_SPLIT) {   // the three exact bfloat16 parts of every weight, in the MFMA operand order of k_conv_split32
+  h->split_parts = h->conv_mode == PBD_CONV_SPLIT ? 3 : h->conv_mode == PBD_CONV_SPLIT_F16 ? 2 : 0;
+  if (h->split_parts) {   // the three exact bfloat16 parts of every weight (or two binary16 parts of the scaled weight), in the MFMA operand order of k_conv_split32
     std::vector<uint16_t> wS;
-    conv_split_filters(h->filters.data(), m.nfilters, m.kh, m.kw, wS);
-    split_bytes = wS.size() * sizeof(uint16_t);
+    if (h->split_parts == 3) conv_split_filters(h->filters.data(), m.nfilters, m.kh, m.kw, wS);
+    else {
+      std::vector<float> osc;
+      conv_split16_filters(h->filters.data(), m.nfilters, m.kh, m.kw, wS, osc);
+      HIPCHK(h, hipMalloc((void**)&h->d_split_oscale, osc.size() * sizeof(float)));
+      HIPCHK(h, hipMemcpy(h->d_split_oscale, osc.data(), osc.size() * sizeof(float), hipMemcpyHostToDevice));
+      split_bytes += osc.size() * sizeof(float);
+    }
+    split_bytes += wS.size() * sizeof(uint16_t);
     HIPCHK(h, hipMalloc((void**)&h->d_wS, wS.size() * sizeof(uint16_t)));
     HIPCHK(h, hipMemcpy(h->d_wS, wS.data(), wS.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
@@ -627,12 +635,12 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
   if ((rc = dev_alloc(h, &h->d_dt_ixT, h->dt_cap_elems))) return rc;
   if ((rc = dev_alloc(h, &h->d_dt_iy, h->dt_cap_elems))) return rc;
   if (!fold && (rc = dev_alloc(h, &h->d_acc, cells * h->nslots * ts))) return rc;
-  if (h->conv_mode == PBD_CONV_SPLIT) {
-    // the features' bfloat16 parts (192 B per cell) live from HOG to the end of the filter bank; the x pass's pointer planes from min()
+  if (h->split_parts) {
+    // the features' bfloat16 parts (192 B per cell; binary16: 128 B) live from HOG to the end of the filter bank; the x pass's pointer planes from min()
     // to argmin(): the compact plan (whose stage buffers already refuse to be read once a later stage has reused them) puts both in
     // one region where the planes are large enough (person model: 300 B per cell); the default plan keeps them apart (pdf() may be
     // called again after min() there)
-    const size_t split_elems = cells * 3 * PBD_FLEN;
+    const size_t split_elems = cells * h->split_parts * PBD_FLEN;
     if (h->compact && h->dt_cap_elems >= split_elems) h->d_feat_split = (uint16_t*)h->d_dt_ixT;
     else if ((rc = dev_alloc(h, &h->d_feat_split, split_elems))) return rc;
   }
@@ -972,8 +980,8 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
 }
 
 static int run_hog(pbd_handle* h) {
-  uint16_t* split = h->conv_mode == PBD_CONV_SPLIT ? h->d_feat_split : nullptr;
-  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->d_hog_lut, split, h->stream);
+  uint16_t* split = h->split_parts ? h->d_feat_split : nullptr;
+  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->d_hog_lut, split, h->split_parts, h->stream);
   LAUNCHCHK(h, "HOG");
   h->feat_split_ok = split != nullptr;
   h->have_feat = true;
@@ -984,7 +992,14 @@ static int run_hog(pbd_handle* h) {
 
 static int run_pdf(pbd_handle* h) {
   const pbd_model_desc& m = h->md;
-  if (h->conv_mode == PBD_CONV_SPLIT) {
+  if (h->conv_mode == PBD_CONV_SPLIT_F16) {
+    if (!h->feat_split_ok) {
+      launch_feat_split16((const float*)h->d_feat, h->d_feat_split, h->cells, h->stream);
+      h->feat_split_ok = true;
+    }
+    static const int svariant16 = PBD_PROBE_ENV("PBD_SPLIT_VARIANT") ? atoi(PBD_PROBE_ENV("PBD_SPLIT_VARIANT")) : 0;   // tuning builds
+    launch_conv_split16(h->d_conv_tiles, h->n_conv_tiles, h->d_levels, h->d_feat_split, h->d_wS, (float*)h->d_resp, m.nfilters, m.kh, m.kw, h->d_split_oscale, svariant16, h->stream);
+  } else if (h->conv_mode == PBD_CONV_SPLIT) {
     // the features' three exact bfloat16 parts: written by k_hog's epilogue; features handed in by the caller (pbd_set_level_features)
     // are split here (a pass over 25 MB per frame).  Then the bank on the bf16 matrix units
     if (!h->feat_split_ok) {
@@ -1282,12 +1297,12 @@ int pbd_create(const pbd_model_desc* model, const pbd_options* opt, pbd_handle**
       for (size_t i = 0; splittable && i < h->filters.size(); ++i) splittable = std::fabs(h->filters[i]) < 3.0e38f;
       h->conv_mode = model->nfilters >= 16 ? (splittable ? PBD_CONV_SPLIT : PBD_CONV_MFMA) : PBD_CONV_EXACT;
     }
-  if (h->conv_mode == PBD_CONV_SPLIT && (h->ts != 4 || model->flen != PBD_FLEN))
-    return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_SPLIT: float handles (32-channel HOG features)");
-  if (h->conv_mode == PBD_CONV_SPLIT)
+  if ((h->conv_mode == PBD_CONV_SPLIT || h->conv_mode == PBD_CONV_SPLIT_F16) && (h->ts != 4 || model->flen != PBD_FLEN))
+    return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_SPLIT / PBD_CONV_SPLIT_F16: float handles (32-channel HOG features)");
+  if (h->conv_mode == PBD_CONV_SPLIT || h->conv_mode == PBD_CONV_SPLIT_F16)
     for (size_t i = 0; i < h->filters.size(); ++i)
       if (!(std::fabs(h->filters[i]) < 3.0e38f)) return fail(h, PBD_ERR_UNSUPPORTED, "PBD_CONV_SPLIT: a filter weight outside bfloat16's finite range");
-  if (h->conv_mode < PBD_CONV_AUTO || h->conv_mode > PBD_CONV_SPLIT) return fail(h, PBD_ERR_ARG, "conv_mode: PBD_CONV_*");
+  if (h->conv_mode < PBD_CONV_AUTO || h->conv_mode > PBD_CONV_SPLIT_F16) return fail(h, PBD_ERR_ARG, "conv_mode: PBD_CONV_*");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(h, PBD_ERR_HIP, "no HIP device visible");
   if (o.device < 0 || o.device >= ndev) return fail(h, PBD_ERR_ARG, "bad device ordinal");
@@ -1304,7 +1319,7 @@ int pbd_destroy(pbd_handle* h) {
   if (!h) return PBD_ERR_ARG;
   if (h->stream) hipStreamSynchronize(h->stream);
   free_frame(h);
-  hipFree(h->d_wT); hipFree(h->d_wS); hipFree(h->d_biasw); hipFree(h->d_hog_lut); hipFree(h->d_parent); hipFree(h->d_plane0); hipFree(h->d_nparts);
+  hipFree(h->d_wT); hipFree(h->d_wS); hipFree(h->d_split_oscale); hipFree(h->d_biasw); hipFree(h->d_hog_lut); hipFree(h->d_parent); hipFree(h->d_plane0); hipFree(h->d_nparts);
   hipFree(h->d_flat); hipFree(h->d_depth);
   hipFree(h->d_cand_count); hipFree(h->d_cand_rec); hipFree(h->d_cand_out);
   if (h->h_cand_out) hipHostFree(h->h_cand_out);
@@ -1879,7 +1894,7 @@ static int hog_u8_(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
   HIPCHK(h, hipMemcpy2D(d_im, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_lv, &L, sizeof(L), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_tiles, tiles.data(), sizeof(HogTile) * tiles.size(), hipMemcpyHostToDevice));
-  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, ts, cn, sbin, tc, h->d_hog_lut, nullptr, h->stream);
+  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, ts, cn, sbin, tc, h->d_hog_lut, nullptr, 0, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, d_feat, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyDeviceToHost));
   hipFree(d_im); hipFree(d_feat); hipFree(d_lv); hipFree(d_tiles);

@@ -185,6 +185,8 @@ struct pbd_handle {
   char* d_feat = nullptr; char* d_resp = nullptr; char* d_acc = nullptr;   // T data, addressed in bytes (elements * ts)
   uint16_t* d_feat_split = nullptr;   // PBD_CONV_SPLIT: the features as [cell][3 splits][32 channels] bfloat16 (per frame plan)
   bool feat_split_ok = false;         // ... written by k_hog for the features now in d_feat (false: handed in by the caller -> k_feat_split before the bank)
+  float* d_split_oscale = nullptr;    // PBD_CONV_SPLIT_F16: [filter] 2^-(12 + e), the responses' scale (e: the filter's weight exponent)
+  int split_parts = 0;                // 3: PBD_CONV_SPLIT (bfloat16 parts), 2: PBD_CONV_SPLIT_F16 (binary16 parts), 0: no split bank
   uint16_t* d_wS = nullptr;           // PBD_CONV_SPLIT: the filters as [tap][2 k-steps][3 splits][n-tile][2 k-groups][32][8] bfloat16 (per model)
   uint8_t* d_pk = nullptr;
   unsigned long long* d_scr_base = nullptr;   // [nlevels][nflat parts] element offset of mixture 0's DT planes (ix / iy / sdt)
@@ -300,7 +302,7 @@ int pbd_i_emit(pbd_handle* h, const std::vector<const char*>& recs, pbd_candidat
 void launch_resize(const PyrJob* jobs, int njobs, int maxpix, int cn, int sstride, const uint8_t* src, uint8_t* pyr, hipStream_t s);
 void launch_pyrdown(const PyrJob* jobs, int njobs, int maxw, int maxh, int cn, uint8_t* pyr, hipStream_t s);
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
-                int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, hipStream_t s);
+                int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, hipStream_t s);
 size_t hog_lds_bytes(int sbin, int tc, int ts);
 size_t hog_binlut_bytes();                                        // orientation-snap table: best_o for every (dx, dy) in [-255, 255]^2
 void launch_hog_binlut(uint8_t* lut, int ts, hipStream_t s);      // evaluated in T (ts = sizeof(T)) with the reference's own chain (k_hog.hip)
@@ -311,6 +313,11 @@ void launch_conv_split(const ConvTile* tiles, int ntiles, const LevelDev* levels
 void launch_conv_split_persistent(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
                                   float* resp, int nf, int ncu, hipStream_t s);   // 5 x 5 banks: persistent workgroups, staging hidden under the MFMAs (tuning variant, not adopted)
 void conv_split_filters(const float* filters, int nf, int kh, int kw, std::vector<uint16_t>& out);   // host: the d_wS layout
+// PBD_CONV_SPLIT_F16: two scaled binary16 parts per operand, three products (k_conv_split.hip)
+void launch_feat_split16(const float* feat, uint16_t* out, size_t ncells, hipStream_t s);
+void conv_split16_filters(const float* filters, int nf, int kh, int kw, std::vector<uint16_t>& out, std::vector<float>& oscale);   // oscale[filter]: the response scale
+void launch_conv_split16(const ConvTile* tiles, int ntiles, const LevelDev* levels, const uint16_t* feat_split, const uint16_t* wS,
+                         float* resp, int nf, int kh, int kw, const float* oscale, int variant, hipStream_t s);
 void launch_conv_exact(const ConvTile* tiles, int ntiles, const LevelDev* levels, const void* feat,
                        const void* wT, void* resp, int ts, int nf, int nfpad, int kh, int kw, hipStream_t s);
 void launch_conv_mfma(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,

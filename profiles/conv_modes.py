@@ -21,7 +21,8 @@ for K in (1, 2, 6, 8, 12):
     m = make_person_model(K=K)
     m.thresh = 3e38
     row = {"mixtures": K, "filters": 26 * K, "contraction_NxK": 26 * K * 800}
-    for name, mode in (("exact_valu", capi.PBD_CONV_EXACT), ("mfma_f32", capi.PBD_CONV_MFMA), ("split_bf16x6", capi.PBD_CONV_SPLIT)):
+    for name, mode in (("exact_valu", capi.PBD_CONV_EXACT), ("mfma_f32", capi.PBD_CONV_MFMA), ("split_bf16x6", capi.PBD_CONV_SPLIT),
+                       ("split_f16x3_opt_in", capi.PBD_CONV_SPLIT_F16)):
         h = capi.Handle(m, conv_mode=mode)
         h.set_profiling(True)
         ms = []

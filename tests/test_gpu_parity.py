@@ -107,19 +107,26 @@ def test_pdf_mfma_tolerance(gpu_required, orc):
     assert _pdf_case(orc, capi.PBD_CONV_MFMA, 9, 5, 14) < 2e-5  # 45 filters: padded N
 
 
-def test_pdf_split_products_tolerance(gpu_required, orc):
+SPLIT_MODES = [pytest.param(capi.PBD_CONV_SPLIT, id="bf16x6"), pytest.param(capi.PBD_CONV_SPLIT_F16, id="f16x3")]
+
+
+@pytest.mark.parametrize("mode", SPLIT_MODES)
+def test_pdf_split_products_tolerance(gpu_required, orc, mode):
     """PBD_CONV_SPLIT: the fp32 products through exact three-way bfloat16 splits on the bf16 matrix units (six partial products,
-    fp32 accumulators): the same tolerance as the fp32 MFMA bank against the oracle's tap-ordered sums."""
-    assert _pdf_case(orc, capi.PBD_CONV_SPLIT, 5, 4, 13) < 2e-5
-    assert _pdf_case(orc, capi.PBD_CONV_SPLIT, 9, 5, 14) < 2e-5  # 45 filters: padded N
+    fp32 accumulators): the same tolerance as the fp32 MFMA bank against the oracle's tap-ordered sums.  PBD_CONV_SPLIT_F16 (opt-in):
+    two scaled binary16 parts, three products."""
+    assert _pdf_case(orc, mode, 5, 4, 13) < 2e-5
+    assert _pdf_case(orc, mode, 9, 5, 14) < 2e-5  # 45 filters: padded N
 
 
-def test_pdf_split_products_all_levels_and_borders(gpu_required, orc):
+@pytest.mark.parametrize("mode", SPLIT_MODES)
+def test_pdf_split_products_all_levels_and_borders(gpu_required, orc, mode):
     """every level of several pyramids (1x1 cells up, partial tiles on both edges, lower tile halves past the last row, a partial
-    n-tile group: 37 and 97 filters) — borders included: the truncation channel's 1 outside the level is exact in bfloat16."""
+    n-tile group: 37 and 97 filters) — borders included: the truncation channel's 1 outside the level is exact in bfloat16
+    (and 2^12 in binary16)."""
     for nfilt in (37, 97):
         m = make_tree_model([-1] + [0] * (nfilt - 1), 1, seed=77)
-        h = capi.Handle(m, conv_mode=capi.PBD_CONV_SPLIT)
+        h = capi.Handle(m, conv_mode=mode)
         for i, (w, hh) in enumerate([(70, 50), (131, 97), (260, 200), (83, 300)]):
             h.pyramid(make_image(300 + i, w, hh))
             g = h._geo
@@ -133,18 +140,19 @@ def test_pdf_split_products_all_levels_and_borders(gpu_required, orc):
         h.close()
 
 
-def test_detect_split_products_matches_the_mfma_bank(gpu_required):
+@pytest.mark.parametrize("mode", SPLIT_MODES)
+def test_detect_split_products_matches_the_mfma_bank(gpu_required, mode):
     """end to end on the person model: the same candidates as the fp32 MFMA bank, root scores within 1e-4 (north_star)"""
     from partsbaseddetector_amd.model import make_person_model
     m = make_person_model(K=6)
     im = make_image(5, 320, 240)
-    ha, hb = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA), capi.Handle(m, conv_mode=capi.PBD_CONV_SPLIT)
+    ha, hb = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA), capi.Handle(m, conv_mode=mode)
     ha.pyramid(im); ha.pdf(); ha.dp_min()
     g = ha._geo
     vals = np.concatenate([ha.root(l, 0)[0].ravel() for l in range(g["nlevels"]) if g["cell_w"][l] and g["cell_h"][l]])
     ha.close(); hb.close()
     m.thresh = float(np.percentile(vals, 99.5))
-    ha, hb = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA), capi.Handle(m, conv_mode=capi.PBD_CONV_SPLIT)
+    ha, hb = capi.Handle(m, conv_mode=capi.PBD_CONV_MFMA), capi.Handle(m, conv_mode=mode)
     a, b = ha.detect(im, capacity=16384), hb.detect(im, capacity=16384)
     ka = {(int(r["level"]), int(r["component"]), tuple(int(v) for v in l[0])): float(r["score"]) for r, l in zip(a[0], a[2])}
     kb = {(int(r["level"]), int(r["component"]), tuple(int(v) for v in l[0])): float(r["score"]) for r, l in zip(b[0], b[2])}
@@ -154,14 +162,15 @@ def test_detect_split_products_matches_the_mfma_bank(gpu_required):
     ha.close(); hb.close()
 
 
+@pytest.mark.parametrize("mode", SPLIT_MODES)
 @pytest.mark.parametrize("kh,kw,tol", [(3, 3, 2e-5), (7, 7, 4e-5), (9, 9, 6e-5), (3, 7, 3e-5), (6, 4, 3e-5)])
-def test_pdf_split_products_any_filter_size(gpu_required, orc, kh, kw, tol):
+def test_pdf_split_products_any_filter_size(gpu_required, orc, kh, kw, tol, mode):
     """k_conv_split32 takes any kh x kw (run-time tap loop, SpatialConvolutionEngine::setFilters src/SpatialConvolutionEngine.cpp:133-159):
     every level of two pyramids, odd / even / rectangular sizes (anchor kh / 2, kw / 2), borders wider than a unit on the small
     levels, a partial n-tile (21 filters); same tolerances as the fp32 MFMA bank's test."""
     m = make_tree_model([-1] + [0] * 20, 1, seed=31, kh=kh, kw=kw)
-    h = capi.Handle(m, conv_mode=capi.PBD_CONV_SPLIT)
-    assert h.conv_mode == capi.PBD_CONV_SPLIT
+    h = capi.Handle(m, conv_mode=mode)
+    assert h.conv_mode == mode
     for i, (w, hh) in enumerate([(97, 70), (210, 163)]):
         h.pyramid(make_image(400 + i, w, hh))
         g = h._geo
@@ -223,6 +232,87 @@ def test_pdf_split_products_adversarial_ranges_vs_fp64(gpu_required, orc):
             assert es <= 1.5 * em + mag * 2.0 ** -23, (scale_lo, l, es, em, mag)
     hs.close(); hm.close()
     print("split vs fp32-MFMA max |err| against fp64 (scale, level, split, mfma, |resp| max):", worst)
+
+
+def test_pdf_split_f16_ranges_vs_fp64(gpu_required, orc):
+    """PBD_CONV_SPLIT_F16 against an fp64 correlation, next to the six-product bank and the fp32 MFMA chain on the same operands.
+    (a) HOG-range operands (weights 2^-12 .. 2^0 of the bank's maximum with zeros, cancelling tap pairs and mantissas next to binary16
+        rounding boundaries; features 2^-12 .. 2^-1): the error stays within the fp32 MFMA chain's (1.5x allowance for the summation tree +
+        2^-23 of the response magnitude: what the six-product bank is held to) PLUS the mode's own term 3 x 2^-24 x sum |f| |w| — the product
+        h_f h_w + h_f m_w + m_f h_w misses m_f m_w (<= 2^-24 |f w|) and the two operands' 24th bits.  On operands built against binary16's
+        rounding boundaries that term shows (measured: up to 1.9x the chain's error); on HOG features it does not (tools_split_products_study).
+    (b) banks scaled by 2^40 and 2^-40, a bank with one filter holding a weight 2^20 above everything else (every filter carries its own
+        weight exponent: the other filters keep their precision).
+    (c) the mode's documented limit: operands far below the scaled binary16 range (features 2^-40 .. 2^-20) lose RELATIVE precision;
+        the ABSOLUTE error stays under taps x 32 x (2^-36 max |w|) — the subnormal spacing of the scaled parts."""
+    rng = np.random.default_rng(77)
+    nf = 40
+    def spread(shape, lo, hi):
+        v = (np.exp2(rng.uniform(lo, hi, shape)) * rng.choice([-1.0, 1.0], shape)).astype(np.float32)
+        v[rng.random(shape) < 0.1] = 0.0
+        return v
+    def near_boundary(v):          # low mantissa bits next to a binary16 rounding boundary (13 bits below the 11 kept)
+        u = v.view(np.uint32).copy()
+        pick = rng.random(v.shape) < 0.3
+        u[pick] = (u[pick] & np.uint32(0xFFFFE000)) | rng.choice(np.array([0x0FFF, 0x1000, 0x1001, 0x0FFE, 0x1FFF, 0x1002], np.uint32), int(pick.sum()))
+        return u.view(np.float32)
+    im = make_image(9, 150, 110)
+    report = []
+    for case, wscale, wlo, flo, fhi in (("hog", 0, -12, -12, -1), ("big bank", 40, -12, -12, -1), ("small bank", -40, -12, -12, -1),
+                                         ("one large weight", 0, -12, -12, -1), ("tiny features", 0, -12, -40, -20)):
+        m = make_tree_model([-1] + [0] * (nf - 1), 1, seed=3)
+        for i in range(nf):
+            w = near_boundary(spread(m.filtersw[i].shape, wlo, 0))
+            if i % 4 == 1:
+                w[:, 32:64] = -w[:, 0:32]
+            m.filtersw[i][...] = np.ldexp(w, wscale).astype(np.float32)
+        if case == "one large weight":
+            m.filtersw[7][2, 5] = np.float32(2.0 ** 20)
+        h16, h6, hm = (capi.Handle(m, conv_mode=c) for c in (capi.PBD_CONV_SPLIT_F16, capi.PBD_CONV_SPLIT, capi.PBD_CONV_MFMA))
+        for h in (h16, h6, hm):
+            h.pyramid(im)
+        g = h16._geo
+        for l in (0, 4, 9):
+            H, W = int(g["cell_h"][l]), int(g["cell_w"][l])
+            f = near_boundary(np.abs(spread((H, W, 32), flo, fhi)))
+            f[..., 31] = 0.0
+            for h in (h16, h6, hm):
+                h.set_level_features(l, f)
+        for h in (h16, h6, hm):
+            h.pdf()
+        for l in (0, 4, 9):
+            ref = orc.pdf_level(h16.level_features(l), m.filtersw, dtype=np.float64)
+            sabs = orc.pdf_level(np.abs(h16.level_features(l)), [np.abs(w) for w in m.filtersw], dtype=np.float64)     # sum |f| |w| per cell
+            worst = (0.0, 0.0, 0.0, 0.0)
+            for n in range(nf):           # per filter: every filter carries its own weight exponent
+                mag = float(np.abs(ref[n]).max())
+                r16 = h16.level_response(l, n).astype(np.float64)
+                e16, e6, em = (float(np.abs(r - ref[n]).max()) for r in (r16, h6.level_response(l, n).astype(np.float64), hm.level_response(l, n).astype(np.float64)))
+                floor = 25 * 32 * 2.0 ** -36 * float(np.abs(m.filtersw[n]).max())
+                own = 3 * 2.0 ** -24 * float(np.abs(sabs[n]).max())
+                assert e16 <= 1.5 * em + mag * 2.0 ** -23 + own + floor, (case, l, n, e16, e6, em, mag, own)
+                if case == "tiny features" and r16.shape[0] > 4 and r16.shape[1] > 4:
+                    # interior cells (no truncation-channel 1 of the border under the window): every product is tiny, the absolute bound alone holds
+                    ei = float(np.abs(r16 - ref[n])[2:-2, 2:-2].max())
+                    assert ei <= floor, (case, l, n, ei, floor)
+                worst = max(worst, (e16, e6, em, mag))
+            report.append((case, l) + worst)
+        for h in (h16, h6, hm):
+            h.close()
+    print("f16x3 / bf16x6 / fp32-MFMA max |err| against fp64 (case, level, e16, e6, emfma, |resp| max of the worst filter):", report)
+
+
+def test_split_f16_is_opt_in_and_float_only(gpu_required):
+    big = make_tree_model([-1] + [0] * 19, 1, seed=1)
+    h = capi.Handle(big)
+    assert h.conv_mode == capi.PBD_CONV_SPLIT           # AUTO never resolves to the binary16 bank
+    h.close()
+    with pytest.raises(capi.PbdError) as e:
+        capi.Handle(big, conv_mode=capi.PBD_CONV_SPLIT_F16, dtype=np.float64)
+    assert e.value.code == capi.PBD_ERR_UNSUPPORTED
+    with pytest.raises(capi.PbdError) as e:
+        capi.Handle(big, conv_mode=5)
+    assert e.value.code == capi.PBD_ERR_ARG
 
 
 def test_auto_selects_the_split_bank_for_float_handles(gpu_required):

@@ -81,3 +81,54 @@ def test_six_partial_products_match_an_fp32_chain():
     assert dropped < 2.0 ** -22 * np.abs(ref).max() + 1e-9                          # the three products left out are below fp32's resolution of the result
     assert e_split <= 1.5 * e_chain + 1e-7, (e_split, e_chain)
     assert e_split < 2e-6
+
+
+# ---- PBD_CONV_SPLIT_F16: two scaled binary16 parts, three products ----
+def split2_f16(x, e):
+    """x (float32), e (exponent) -> two float32 arrays holding binary16 values with x 2^e ~= h + m (k_feat_split16 / conv_split16_filters)"""
+    s = np.ldexp(x.astype(np.float32), e).astype(np.float32)
+    h = s.astype(np.float16).astype(np.float32)                                     # round to nearest even, subnormals kept
+    m = (s - h).astype(np.float32).astype(np.float16).astype(np.float32)            # (the subtraction is exact)
+    return h, m, (s - h - m).astype(np.float32)
+
+
+def test_two_binary16_parts_hold_23_bits():
+    rng = np.random.default_rng(3)
+    x = np.exp2(rng.uniform(-12, 0, 200000)).astype(np.float32) * rng.choice([-1.0, 1.0], 200000).astype(np.float32)
+    u = x.view(np.uint32).copy()
+    pick = rng.random(len(x)) < 0.3                  # mantissas next to the binary16 rounding boundaries
+    u[pick] = (u[pick] & np.uint32(0xFFFFE000)) | rng.choice(np.array([0x0FFF, 0x1000, 0x1001, 0x1FFF], np.uint32), int(pick.sum()))
+    x = u.view(np.float32)
+    h, m, rest = split2_f16(x, 12)                   # features: scaled by 2^12
+    s = np.ldexp(x, 12)
+    assert np.all(np.abs(rest) <= np.abs(s) * 2.0 ** -23 + 2.0 ** -25)              # 23 bits, or the subnormal spacing's half below 2^-14
+    assert np.all(np.abs(m) <= np.abs(h) * 2.0 ** -11 + 2.0 ** -25)
+    b, bm, _ = split2_f16(x[::-1].copy(), 14)
+    for p, q in ((h, b), (h, bm), (m, b)):                                          # 11 x 11 significant bits: exact in fp32
+        assert np.array_equal((p * q).astype(np.float64), p.astype(np.float64) * q.astype(np.float64))
+    tiny = np.float32(2.0 ** -30) * x                                               # far below the scaled range: absolute, not relative, precision
+    _, _, rest = split2_f16(tiny, 12)
+    assert np.all(np.abs(rest) <= 2.0 ** -25)
+
+
+def test_three_binary16_products_match_an_fp32_chain():
+    rng = np.random.default_rng(4)
+    K, N = 800, 400
+    f = np.abs(rng.normal(0.08, 0.06, (N, K))).astype(np.float32)
+    w = rng.normal(0.0, 0.02, (N, K)).astype(np.float32)
+    ref = (f.astype(np.float64) * w.astype(np.float64)).sum(1)
+    chain = np.zeros(N, np.float32)
+    for k in range(K):
+        chain = (chain + f[:, k] * w[:, k]).astype(np.float32)
+    we = 14 - (np.frexp(np.abs(w).max(1))[1])                                       # per filter (row): max |w| 2^e in [2^13, 2^14)
+    fh, fm, _ = split2_f16(f, 12)
+    wh, wm, _ = split2_f16(w, we[:, None])
+    acc = np.zeros(N, np.float32)
+    for k0 in range(0, K, 16):
+        for a, b in ((fh, wm), (fm, wh), (fh, wh)):                                 # the kernel's order: the small products of a k-step first
+            part = (a[:, k0:k0 + 16].astype(np.float64) * b[:, k0:k0 + 16].astype(np.float64)).sum(1)
+            acc = (acc.astype(np.float64) + part).astype(np.float32)
+    got = np.ldexp(acc, -(12 + we)).astype(np.float32)                              # exact
+    e_split, e_chain = np.abs(got - ref).max(), np.abs(chain - ref).max()
+    assert e_split <= 1.5 * e_chain + 1e-7, (e_split, e_chain)
+    assert e_split < 2e-6

@@ -1,9 +1,9 @@
 """Ad-hoc stress run (not a test): the split-product filter bank (PBD_CONV_SPLIT, k_conv_split32) on random banks — 16 .. 340 filters (every
 n-tile remainder, one to three n-tile groups), 3x3 .. 9x9 and rectangular sizes, cell sizes 4 / 8, random image sizes (ragged tiles on every level,
 levels smaller than a tile), gray / colour, single frames and batches — against the oracle's tap-ordered fp32 sums on every level, and against an
-fp64 correlation on a sample; PBD_CONV_AUTO must have resolved to the split bank.
+fp64 correlation on a sample; PBD_CONV_AUTO must have resolved to the split bank.  `f16`: the same run on the opt-in PBD_CONV_SPLIT_F16 bank.
 
-    python tests/tools_fuzz_split.py [seconds] [seed]
+    python tests/tools_fuzz_split.py [seconds] [seed] [f16]
 """
 import os
 import sys
@@ -20,6 +20,7 @@ from partsbaseddetector_amd.model import make_image, make_tree_model  # noqa: E4
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    f16 = len(sys.argv) > 3 and sys.argv[3] == "f16"
     rng = np.random.default_rng(seed)
     t0 = time.time()
     ncase = nplanes = 0
@@ -33,11 +34,11 @@ def main():
         cn = 1 if rng.random() < 0.2 else 3
         im = make_image(int(rng.integers(1 << 30)), w, h, cn)
         try:
-            hd = capi.Handle(m)                                    # PBD_CONV_AUTO
+            hd = capi.Handle(m, conv_mode=capi.PBD_CONV_SPLIT_F16 if f16 else capi.PBD_CONV_AUTO)
             hd.pyramid(im)
         except capi.PbdError:                                      # (image too small for the pyramid)
             continue
-        assert hd.conv_mode == capi.PBD_CONV_SPLIT
+        assert hd.conv_mode == (capi.PBD_CONV_SPLIT_F16 if f16 else capi.PBD_CONV_SPLIT)
         hd.pdf()
         g = hd._geo
         tol = 2e-5 * max(1.0, kh * kw / 25.0)                      # the contraction is kh kw 32 deep: the bound of the fp32 MFMA bank's tests
@@ -59,7 +60,7 @@ def main():
                     worst64 = max(worst64, float(np.abs(hd.level_response(l, n) - ref64[i]).max()))
         hd.close()
         ncase += 1
-    print(f"split fuzz ok: {ncase} random banks, {nplanes} response planes within the tolerance of the oracle's fp32 sums (worst {worst:.2e}); "
+    print(f"split fuzz ok ({'binary16 x3' if f16 else 'bfloat16 x6'}): {ncase} random banks, {nplanes} response planes within the tolerance of the oracle's fp32 sums (worst {worst:.2e}); "
           f"against fp64 on the sampled planes: worst {worst64:.2e}; {time.time() - t0:.0f} s, seed {seed}")
 
 

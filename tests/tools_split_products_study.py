@@ -55,6 +55,16 @@ for seed in (0, 1, 2):
         for (i, j) in sorted(keep, key=lambda t: -(t[0] + t[1])):
             acc = (acc + mm32(As[i], Bs[j], 32)).astype(np.float32)
         out[f'bf16 {ns}-way split, {len(keep)} products'] = acc
+    # PBD_CONV_SPLIT_F16: two binary16 parts of the operands scaled into binary16's range (features 2^12, every filter to max |w| 2^e in [2^13, 2^14)), three products
+    f16 = lambda x: np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+    def split16(x):
+        h = f16(x); return [h, f16((x - h).astype(np.float32))]
+    we = (14 - np.frexp(np.abs(B).max(0))[1]).astype(np.int32)
+    As, Bs = split16(np.ldexp(A, 12).astype(np.float32)), split16(np.ldexp(B, we[None, :]).astype(np.float32))
+    acc = np.zeros_like(ref, dtype=np.float32)
+    for (i, j) in ((0, 1), (1, 0), (0, 0)):
+        acc = (acc + mm32(As[i], Bs[j], 32)).astype(np.float32)
+    out['binary16 2-way split (scaled), 3 products'] = np.ldexp(acc, -(12 + we)[None, :]).astype(np.float32)
     print(f'seed {seed}: {A.shape[0]} cells x {nf} filters, |response| max {np.abs(ref).max():.3f} rms {np.sqrt((ref**2).mean()):.3f}')
     for k, v in out.items():
         d = np.abs(v.astype(np.float64) - ref)
