@@ -108,6 +108,10 @@ enum {
  * float and are widened where the reference widens them; candidates carry
  * float scores for both (include/Candidate.hpp:72).                          */
 enum { PBD_SCALAR_F32 = 0, PBD_SCALAR_F64 = 1 };
+/* Depth of an input image: the values of cv::Mat::depth() the reference dispatches on (src/HOGFeatures.cpp:136-146:
+ * CV_8U = 0, CV_16U = 2, CV_32F = 5, CV_64F = 6; anything else: CV_Error(StsUnsupportedFormat) -> PBD_ERR_UNSUPPORTED).
+ * The *_u8 entry points are the 8-bit case; pbd_detect_image / pbd_pyramid_image take any of the four.             */
+enum { PBD_DEPTH_8U = 0, PBD_DEPTH_16U = 2, PBD_DEPTH_32F = 5, PBD_DEPTH_64F = 6 };
 typedef struct pbd_options {
   int32_t device;        /* HIP device ordinal                                 */
   int32_t conv_mode;     /* PBD_CONV_*                                         */

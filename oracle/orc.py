@@ -72,32 +72,44 @@ def _cn(im):
     return 1 if im.ndim == 2 else im.shape[2]
 
 
+# image depths the reference dispatches on (src/HOGFeatures.cpp:136-146): numpy dtype -> (cv::Mat::depth() code, oracle suffix)
+DEPTHS = {np.dtype(np.uint8): (0, "8u"), np.dtype(np.uint16): (2, "16u"), np.dtype(np.float32): (5, "32f"), np.dtype(np.float64): (6, "64f")}
+
+
+def _img(im):
+    """an image as the reference would receive it: uint8 unless it already has one of the other accepted depths"""
+    im = np.asarray(im)
+    if im.dtype not in DEPTHS:
+        im = im.astype(np.uint8)
+    return np.ascontiguousarray(im)
+
+
 def resize(im, ow, oh):
-    im = np.ascontiguousarray(im, np.uint8)
+    im = _img(im)
     h, w = im.shape[:2]
     cn = _cn(im)
-    out = np.zeros((oh, ow) + ((cn,) if cn > 1 else ()), np.uint8)
-    lib().orc_resize_linear_8u(_p(im), w, h, cn, w * cn, _p(out), ow, oh)
+    out = np.zeros((oh, ow) + ((cn,) if cn > 1 else ()), im.dtype)
+    getattr(lib(), "orc_resize_linear_" + DEPTHS[im.dtype][1])(_p(im), w, h, cn, w * cn, _p(out), ow, oh)   # (strides in elements)
     return out
 
 
 def pyrdown(im):
-    im = np.ascontiguousarray(im, np.uint8)
+    im = _img(im)
     h, w = im.shape[:2]
     cn = _cn(im)
-    out = np.zeros(((h + 1) // 2, (w + 1) // 2) + ((cn,) if cn > 1 else ()), np.uint8)
-    lib().orc_pyrdown_8u(_p(im), w, h, cn, w * cn, _p(out))
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2) + ((cn,) if cn > 1 else ()), im.dtype)
+    getattr(lib(), "orc_pyrdown_" + DEPTHS[im.dtype][1])(_p(im), w, h, cn, w * cn, _p(out))
     return out
 
 
 def hog(im, sbin, dtype=np.float32):
-    im = np.ascontiguousarray(im, np.uint8)
+    im = _img(im)
     h, w = im.shape[:2]
     cn = _cn(im)
     cw, ch = C.c_int(0), C.c_int(0)
     lib().orc_cells_of(w, h, sbin, C.byref(cw), C.byref(ch))
     out = np.zeros((ch.value, cw.value, 32), dtype)
-    rc = _fn("orc_hog_u8", dtype)(_p(im), w, h, cn, w * cn, sbin, _p(out))
+    rc = _fn("orc_hog_image", dtype)(_p(im), DEPTHS[im.dtype][0], w, h, cn, w * cn * im.itemsize, sbin, _p(out))
     assert rc == 0
     return out
 
@@ -184,9 +196,9 @@ class Frame:
         buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(p)
         return np.frombuffer(buf, dtype=dtype).reshape(shape).copy()
 
-    def image(self, l, cn):
+    def image(self, l, cn, dtype=np.uint8):
         iw, ih = self.dims[l][0], self.dims[l][1]
-        return self._arr("orc_frame_image", l, (ih, iw) + ((cn,) if cn > 1 else ()), np.uint8)
+        return self._arr("orc_frame_image", l, (ih, iw) + ((cn,) if cn > 1 else ()), dtype)
 
     def feat(self, l):
         return self._arr("orc_frame_feat", l, (self.dims[l][3], self.dims[l][2], 32), self.dtype)
@@ -212,8 +224,9 @@ class Frame:
 
 
 def detect(model, im, capacity=8192, keep=False, correct_ptr=0, desc=None, dtype=np.float32):
-    """orc_detect_u8[_f64] -> (heads, boxes, locs, stage_ms[, Frame])."""
-    im = np.ascontiguousarray(im, np.uint8)
+    """orc_detect_image[_f64] -> (heads, boxes, locs, stage_ms[, Frame]).  The image's own dtype is its depth (uint8, uint16, float32,
+    float64: src/HOGFeatures.cpp:136-146); anything else is taken as uint8."""
+    im = _img(im)
     h, w = im.shape[:2]
     cn = _cn(im)
     desc = desc or model.to_desc()
@@ -224,10 +237,10 @@ def detect(model, im, capacity=8192, keep=False, correct_ptr=0, desc=None, dtype
     cnt = C.c_int(0)
     ms = (C.c_double * 5)()
     fp = C.c_void_p()
-    rc = _fn("orc_detect_u8", dtype)(C.byref(desc), _p(im), w, h, cn, w * cn, _p(heads), _p(boxes), _p(locs), capacity,
-                             C.byref(cnt), ms, C.byref(fp) if keep else None, correct_ptr)
+    rc = _fn("orc_detect_image", dtype)(C.byref(desc), _p(im), DEPTHS[im.dtype][0], w, h, cn, w * cn * im.itemsize, _p(heads), _p(boxes), _p(locs),
+                                        capacity, C.byref(cnt), ms, C.byref(fp) if keep else None, correct_ptr)
     if rc:
-        raise ValueError("orc_detect_u8 failed (image too small?)")
+        raise ValueError("orc_detect_image failed (image too small?)")
     n = min(cnt.value, capacity)
     res = (heads[:n].copy(), boxes[:n].copy(), locs[:n].copy(), list(ms))
     if keep:

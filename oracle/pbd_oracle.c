@@ -195,6 +195,145 @@ ORC_API void orc_pyrdown_8u(const uint8_t* src, int sw, int sh, int cn, int sstr
   }
 }
 
+/* ------------------------------------------------------------------------- */
+/* The same two functions for the other image depths HOGFeatures<T>::pyramid  */
+/* accepts (src/HOGFeatures.cpp:136-146: CV_16U, CV_32F, CV_64F).  OpenCV 2.4: */
+/*   resize  — non-8-bit depths interpolate in floating point, coefficients    */
+/*             are float: HResizeLinear<T, WT, float> computes                 */
+/*             S[sx]*a0 + S[sx+cn]*a1 in WT, VResizeLinear S0*b0 + S1*b1 in WT */
+/*             and casts (ushort: saturate_cast = cvRound + clamp; WT = float  */
+/*             for ushort / float, double for double);                         */
+/*   pyrDown — ushort: the 8-bit integer form ((sum + 128) >> 8); float /      */
+/*             double: FltCast<T, 8>, row = s2*6 + (s1 + s3)*4 + s0 + s4 on    */
+/*             the source row, the same expression over five such rows, times  */
+/*             1/256 — the SCALAR loop's association (a build whose pyrDown     */
+/*             runs the SSE row pass associates differently: unpinned twice).  */
+/* stride arguments are in ELEMENTS here.                                      */
+/* ------------------------------------------------------------------------- */
+static inline uint16_t sat_u16_f(float v) { int i = cv_round_f(v); return (uint16_t)(i < 0 ? 0 : (i > 65535 ? 65535 : i)); }
+#define ORC_DEFINE_RESIZE(NAME, PT, WT, CAST)                                                            \
+ORC_API void NAME(const PT* src, int sw, int sh, int cn, int sstride, PT* dst, int dw, int dh) {         \
+  if (sw == dw && sh == dh) {                                                                            \
+    for (int y = 0; y < sh; ++y) memcpy(dst + (size_t)y * dw * cn, src + (size_t)y * sstride, sizeof(PT) * (size_t)sw * cn); \
+    return;                                                                                              \
+  }                                                                                                      \
+  const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;                             \
+  const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;                                   \
+  int* xofs = (int*)malloc(sizeof(int) * dw);                                                            \
+  float* alpha = (float*)malloc(sizeof(float) * dw * 2);                                                 \
+  int xmax = dw;                                                                                         \
+  for (int dx = 0; dx < dw; ++dx) {                                                                      \
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);                                                      \
+    int sx = (int)floorf(fx);                                                                            \
+    fx -= sx;                                                                                            \
+    if (sx < 0) { fx = 0; sx = 0; }                                                                      \
+    if (sx + 1 >= sw) {                                                                                  \
+      xmax = imin(xmax, dx);                                                                             \
+      if (sx >= sw - 1) { fx = 0; sx = sw - 1; }                                                         \
+    }                                                                                                    \
+    xofs[dx] = sx;                                                                                       \
+    alpha[dx * 2] = 1.f - fx;                                                                            \
+    alpha[dx * 2 + 1] = fx;                                                                              \
+  }                                                                                                      \
+  WT* rows[2];                                                                                           \
+  rows[0] = (WT*)malloc(sizeof(WT) * dw * cn);                                                           \
+  rows[1] = (WT*)malloc(sizeof(WT) * dw * cn);                                                           \
+  for (int dy = 0; dy < dh; ++dy) {                                                                      \
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);                                                      \
+    int sy0 = (int)floorf(fy);                                                                           \
+    fy -= sy0;                                                                                           \
+    for (int k = 0; k < 2; ++k) {                                                                        \
+      int sy = sy0 + k;                                                                                  \
+      sy = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);                                                        \
+      const PT* S = src + (size_t)sy * sstride;                                                          \
+      WT* D = rows[k];                                                                                   \
+      for (int dx = 0; dx < dw; ++dx) {                                                                  \
+        const int sx = xofs[dx] * cn;                                                                    \
+        const float a0 = alpha[dx * 2], a1 = alpha[dx * 2 + 1];                                          \
+        for (int c = 0; c < cn; ++c)                                                                     \
+          D[dx * cn + c] = dx < xmax ? (WT)(S[sx + c] * a0 + S[sx + cn + c] * a1) : (WT)(S[sx + c] * 1); \
+      }                                                                                                  \
+    }                                                                                                    \
+    const WT b0 = 1.f - fy, b1 = fy;                                                                     \
+    PT* out = dst + (size_t)dy * dw * cn;                                                                \
+    for (int x = 0; x < dw * cn; ++x) out[x] = CAST(rows[0][x] * b0 + rows[1][x] * b1);                  \
+  }                                                                                                      \
+  free(rows[0]); free(rows[1]); free(xofs); free(alpha);                                                 \
+}
+#define ORC_CAST_ID(v) (v)
+ORC_DEFINE_RESIZE(orc_resize_linear_16u, uint16_t, float, sat_u16_f)
+ORC_DEFINE_RESIZE(orc_resize_linear_32f, float, float, ORC_CAST_ID)
+ORC_DEFINE_RESIZE(orc_resize_linear_64f, double, double, ORC_CAST_ID)
+
+ORC_API void orc_pyrdown_16u(const uint16_t* src, int sw, int sh, int cn, int sstride, uint16_t* dst) {
+  const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+  static const int wt[5] = {1, 4, 6, 4, 1};
+  for (int y = 0; y < dh; ++y)
+    for (int x = 0; x < dw; ++x)
+      for (int c = 0; c < cn; ++c) {
+        int sum = 0;
+        for (int i = 0; i < 5; ++i) {
+          const int sy = reflect101(2 * y + i - 2, sh);
+          int rs = 0;
+          for (int j = 0; j < 5; ++j) rs += wt[j] * src[(size_t)sy * sstride + reflect101(2 * x + j - 2, sw) * cn + c];
+          sum += wt[i] * rs;
+        }
+        dst[((size_t)y * dw + x) * cn + c] = (uint16_t)((sum + 128) >> 8);
+      }
+}
+#define ORC_DEFINE_PYRDOWN_FLT(NAME, PT)                                                                 \
+ORC_API void NAME(const PT* src, int sw, int sh, int cn, int sstride, PT* dst) {                         \
+  const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;                                                        \
+  for (int y = 0; y < dh; ++y)                                                                           \
+    for (int x = 0; x < dw; ++x)                                                                         \
+      for (int c = 0; c < cn; ++c) {                                                                     \
+        PT row[5];                                                                                       \
+        for (int i = 0; i < 5; ++i) {                                                                    \
+          const PT* S = src + (size_t)reflect101(2 * y + i - 2, sh) * sstride + c;                       \
+          const PT s0 = S[reflect101(2 * x - 2, sw) * cn], s1 = S[reflect101(2 * x - 1, sw) * cn], s2 = S[reflect101(2 * x, sw) * cn], \
+                   s3 = S[reflect101(2 * x + 1, sw) * cn], s4 = S[reflect101(2 * x + 2, sw) * cn];      \
+          row[i] = s2 * 6 + (s1 + s3) * 4 + s0 + s4;                                                     \
+        }                                                                                                \
+        dst[((size_t)y * dw + x) * cn + c] = (row[2] * 6 + (row[1] + row[3]) * 4 + row[0] + row[4]) * (PT)(1. / 256); \
+      }                                                                                                  \
+}
+ORC_DEFINE_PYRDOWN_FLT(orc_pyrdown_32f, float)
+ORC_DEFINE_PYRDOWN_FLT(orc_pyrdown_64f, double)
+
+static int orc_depth_esz(int depth) {
+  return depth == PBD_DEPTH_8U ? 1 : depth == PBD_DEPTH_16U ? 2 : depth == PBD_DEPTH_32F ? 4 : depth == PBD_DEPTH_64F ? 8 : 0;
+}
+/* image pyramid of any accepted depth: `stride` and `offsets` in BYTES */
+ORC_API int orc_image_pyramid_u8(const uint8_t* im, int w, int h, int cn, int stride, int sbin, int interval, uint8_t* out, size_t* offsets);
+ORC_API int orc_image_pyramid(const void* im, int depth, int w, int h, int cn, int stride, int sbin,
+                              int interval, uint8_t* out, size_t* offsets) {
+  if (depth == PBD_DEPTH_8U) return orc_image_pyramid_u8((const uint8_t*)im, w, h, cn, stride, sbin, interval, out, offsets);
+  const int esz = orc_depth_esz(depth);
+  if (!esz || stride % esz) return -1;
+  int n;
+  int32_t iw[128], ih[128], cw[128], ch[128];
+  float sc[128];
+  if (orc_pyramid_geometry(w, h, sbin, interval, &n, iw, ih, cw, ch, sc)) return -1;
+  size_t off = 0;
+  for (int l = 0; l < n; ++l) { offsets[l] = off; off += (size_t)iw[l] * ih[l] * cn * esz; }
+  offsets[n] = off;
+#ifdef _OPENMP
+#pragma omp parallel for
+#endif
+  for (int i = 0; i < interval; ++i) {
+    if (depth == PBD_DEPTH_16U) orc_resize_linear_16u((const uint16_t*)im, w, h, cn, stride / 2, (uint16_t*)(out + offsets[i]), iw[i], ih[i]);
+    else if (depth == PBD_DEPTH_32F) orc_resize_linear_32f((const float*)im, w, h, cn, stride / 4, (float*)(out + offsets[i]), iw[i], ih[i]);
+    else orc_resize_linear_64f((const double*)im, w, h, cn, stride / 8, (double*)(out + offsets[i]), iw[i], ih[i]);
+    for (int j = i + interval; j < n; j += interval) {
+      const int pw = iw[j - interval], ph = ih[j - interval];
+      if (depth == PBD_DEPTH_16U) orc_pyrdown_16u((const uint16_t*)(out + offsets[j - interval]), pw, ph, cn, pw * cn, (uint16_t*)(out + offsets[j]));
+      else if (depth == PBD_DEPTH_32F) orc_pyrdown_32f((const float*)(out + offsets[j - interval]), pw, ph, cn, pw * cn, (float*)(out + offsets[j]));
+      else orc_pyrdown_64f((const double*)(out + offsets[j - interval]), pw, ph, cn, pw * cn, (double*)(out + offsets[j]));
+    }
+  }
+  return n;
+}
+
 /* image pyramid: src/HOGFeatures.cpp:111-127. out = level images back to back */
 ORC_API int orc_image_pyramid_u8(const uint8_t* im, int w, int h, int cn, int stride, int sbin,
                                  int interval, uint8_t* out, size_t* offsets) {
