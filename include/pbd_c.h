@@ -148,7 +148,7 @@ typedef struct pbd_options {
 int pbd_abi_version(void);
 /* Version history: 3 = rounds 3-4.  4 (round 5) = PBD_CONV_AUTO resolves to PBD_CONV_SPLIT for float handles (numerics of
  * AUTO change in the last bits: rounds 3-4 resolved to PBD_CONV_MFMA, and before that to EXACT for banks other than 5 x 5),
- * PBD_CONV_SPLIT, PBD_CONV_SPLIT_F16, pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state, pbd_group_comm_size.  Struct layouts unchanged.   */
+ * PBD_CONV_SPLIT, PBD_CONV_SPLIT_F16, pbd_detect_image / pbd_pyramid_image / pbd_get_level_image_raw (PBD_DEPTH_*), pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state, pbd_group_comm_size.  Struct layouts unchanged.   */
 
 /* ---- output record: include/Candidate.hpp:56-111 --------------------------
  * One candidate = head + max_parts boxes (x, y, width, height as cv::Rect)
@@ -193,10 +193,16 @@ int pbd_detect_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int 
                   int capacity, int* count);
 /* Input depth.  The reference dispatches features<uint8_t|uint16_t|float|double> on im.depth()
  * (src/HOGFeatures.cpp:136-146); its three callers (src/demo.cpp:90, ros/Node.cpp:183,
- * cells/detect.cpp:224) all pass CV_8U BGR.  This library takes 8-bit images only, BY DESIGN: for the other
- * depths cv::resize / cv::pyrDown use different (float / wider fixed-point) arithmetic that no reference
- * test or fixture pins, so a restatement could not be checked against anything; pass 16U/32F/64F images
- * through convertTo(CV_8U) first, or expect PBD_ERR_UNSUPPORTED from the adaptors in INTEGRATION.md.       */
+ * cells/detect.cpp:224) all pass CV_8U BGR, which is what the *_u8 entry points (device-resident images, batches,
+ * graph replay, groups) are built and tuned for.  pbd_detect_image takes a host image of any of the four depths
+ * (`depth` = PBD_DEPTH_*, stride in BYTES, a multiple of the element size): pyramid levels in the image's own type —
+ * cv::resize interpolating in floating point with float coefficients, cv::pyrDown as FltCast<T, 8> (ushort: the
+ * integer form), restated from OpenCV 2.4 like the 8-bit pair and equally unpinned (no reference test holds any
+ * pyramid value) —, gradients in the pixel type's promoted arithmetic, everything from the histograms on unchanged.
+ * Single frames, eager launches; PBD_DEPTH_8U forwards to pbd_detect_u8.  Any other depth: PBD_ERR_UNSUPPORTED, the
+ * counterpart of CV_Error(StsUnsupportedFormat) (:141-145).                                                       */
+int pbd_detect_image(pbd_handle* h, const void* im, int depth, int w, int hgt, int cn, int stride,
+                     pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count);
 /* same, image already resident in device memory (tightly packed or strided)  */
 int pbd_detect_dev_u8(pbd_handle* h, const void* d_im, int w, int hgt, int cn, int stride,
                       pbd_candidate_head* heads, int32_t* boxes, int32_t* locs,
@@ -271,6 +277,10 @@ int pbd_pyramid_geometry(const pbd_handle* h, int w, int hgt, int* nlevels,
 /* HOGFeatures<T>::pyramid (src/HOGFeatures.cpp:95-151): image pyramid + HOG  */
 int pbd_pyramid_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride);
 int pbd_get_level_image(pbd_handle* h, int level, uint8_t* out /* img_h*img_w*cn */);
+/* HOGFeatures<T>::pyramid for an image of any accepted depth (pbd_detect_image), and a level image in the frame's own pixel
+ * type (out_bytes >= img_h * img_w * cn * element size)                                                              */
+int pbd_pyramid_image(pbd_handle* h, const void* im, int depth, int w, int hgt, int cn, int stride);
+int pbd_get_level_image_raw(pbd_handle* h, int level, void* out, size_t out_bytes);
 int pbd_get_level_features(pbd_handle* h, int level, float* out /* cell_h*cell_w*flen */);
 int pbd_set_level_features(pbd_handle* h, int level, const float* in);
 int pbd_get_level_features_f64(pbd_handle* h, int level, double* out);

@@ -22,6 +22,9 @@ PBD_OK, PBD_ERR_ARG, PBD_ERR_UNSUPPORTED, PBD_ERR_CAPACITY, PBD_ERR_HIP, PBD_ERR
 PBD_GATHER_AUTO, PBD_GATHER_HOST, PBD_GATHER_RCCL = 0, 1, 2
 PBD_CONV_AUTO, PBD_CONV_EXACT, PBD_CONV_MFMA, PBD_CONV_SPLIT, PBD_CONV_SPLIT_F16 = 0, 1, 2, 3, 4
 PBD_SCALAR_F32, PBD_SCALAR_F64 = 0, 1
+PBD_DEPTH_8U, PBD_DEPTH_16U, PBD_DEPTH_32F, PBD_DEPTH_64F = 0, 2, 5, 6          # cv::Mat::depth() (src/HOGFeatures.cpp:136-146)
+DEPTH_OF = {np.dtype(np.uint8): PBD_DEPTH_8U, np.dtype(np.uint16): PBD_DEPTH_16U, np.dtype(np.float32): PBD_DEPTH_32F,
+            np.dtype(np.float64): PBD_DEPTH_64F}
 
 EXPORTS = [
     "pbd_create", "pbd_destroy", "pbd_last_error", "pbd_max_parts", "pbd_set_stream",
@@ -39,6 +42,7 @@ EXPORTS = [
     "pbd_set_root", "pbd_set_root_f64", "pbd_set_dp_pointers", "pbd_get_footprint", "pbd_abi_version",
     "pbd_detect_batch_u8", "pbd_detect_batch_enqueue_u8", "pbd_detect_batch_enqueue_dev_u8", "pbd_detect_batch_collect",
     "pbd_get_stage_state", "pbd_get_conv_mode", "pbd_group_comm_size",
+    "pbd_detect_image", "pbd_pyramid_image", "pbd_get_level_image_raw",
 ]
 PBD_ABI_VERSION = 4
 
@@ -160,6 +164,20 @@ class Handle:
                                        capacity, C.byref(cnt)))
         return self._out(heads, boxes, locs, cnt.value)
 
+    def detect_image(self, im: np.ndarray, capacity=4096):
+        """pbd_detect_image: the image in its own depth (uint8 / uint16 / float32 / float64 = CV_8U / 16U / 32F / 64F); other dtypes are refused
+        by the library the way the reference refuses them (CV_Error(StsUnsupportedFormat))"""
+        im = np.ascontiguousarray(im)
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        depth = DEPTH_OF.get(im.dtype, 1 if im.dtype == np.int8 else 3 if im.dtype == np.int16 else 4 if im.dtype == np.int32 else 7)
+        heads, boxes, locs = self._bufs(capacity)
+        cnt = C.c_int(0)
+        self._chk(self.L.pbd_detect_image(self.h, im.ctypes.data_as(C.c_void_p), depth, w, hgt, cn, w * cn * im.itemsize,
+                                          heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32), _p(locs, C.c_int32),
+                                          capacity, C.byref(cnt)))
+        return self._out(heads, boxes, locs, cnt.value)
+
     def detect_dev(self, dptr: int, w, hgt, cn, stride=None, capacity=4096):
         heads, boxes, locs = self._bufs(capacity)
         cnt = C.c_int(0)
@@ -259,6 +277,24 @@ class Handle:
         self._chk(self.L.pbd_pyramid_u8(self.h, _p(im, C.c_uint8), w, hgt, cn, w * cn))
         self._geo = self.geometry(w, hgt)
         self._cn = cn
+        self._imdtype = np.dtype(np.uint8)
+
+    def pyramid_image(self, im: np.ndarray):
+        """pbd_pyramid_image: pyramid() for an image of any accepted depth (its numpy dtype)"""
+        im = np.ascontiguousarray(im)
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        self._chk(self.L.pbd_pyramid_image(self.h, im.ctypes.data_as(C.c_void_p), DEPTH_OF[im.dtype], w, hgt, cn, w * cn * im.itemsize))
+        self._geo = self.geometry(w, hgt)
+        self._cn = cn
+        self._imdtype = im.dtype
+
+    def level_image_raw(self, l):
+        g = self._geo
+        shape = (g["img_h"][l], g["img_w"][l]) + ((self._cn,) if self._cn > 1 else ())
+        out = np.zeros(shape, getattr(self, "_imdtype", np.dtype(np.uint8)))
+        self._chk(self.L.pbd_get_level_image_raw(self.h, l, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
+        return out
 
     def level_image(self, l):
         g = self._geo

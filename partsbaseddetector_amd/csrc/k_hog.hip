@@ -74,7 +74,7 @@ struct HogLds {
   size_t mag_off, bin_off, hist_off, norm_off, ninv_off, tab_off, raw_off, out_off, total;
 };
 
-__host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int cn, int ts) {   // ts = sizeof(T)
+__host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int bpp, int ts) {   // ts = sizeof(T); bpp = bytes per pixel (channels x element size)
   HogLds L;
   L.NB = tc + 2;
   // A pixel y feeds the blocks floor((y + 0.5) / sbin - 0.5) and the next one (:252-255): block b receives exactly the
@@ -84,7 +84,7 @@ __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int cn, int t
   L.PT = L.NB * sbin + sbin + 2 * L.P0;
   L.MG = sbin / 2 + 2;
   L.RT = L.PT + L.MG + 1;
-  L.RP = (L.RT * cn + 3) & ~3;
+  L.RP = (bpp & 7) ? (L.RT * bpp + 3) & ~3 : (L.RT * bpp + 7) & ~7;   // (8-byte pixels elements: rows stay 8-byte aligned)
   L.MP = L.PT;
   size_t o = 0;
   // (|g|, bin) per window pixel are dead once the histograms are complete: the block energies, the normalisers and the
@@ -106,13 +106,15 @@ __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int cn, int t
   L.total = (o + 15) & ~(size_t)15;
   return L;
 }
-size_t hog_lds_bytes(int sbin, int tc, int ts) { return hog_lds_layout(sbin, tc, 3, ts).total; }
+size_t hog_lds_bytes(int sbin, int tc, int ts, int bpp) { return hog_lds_layout(sbin, tc, bpp, ts).total; }
 
 #define HOG_NT 384   // threads per workgroup: (TC+2)^2 = 324 block histograms finish in one pass
 
 // SBIN_T / TC_T > 0: compile-time cell size / tile side (index divisions become shifts, loops unroll);
 // 0: taken from the runtime arguments (generic fallback).
-template <typename T, int SBIN_T, int TC_T>
+// IT: pixel type of the level images (src/HOGFeatures.cpp:136-146: features<uint8_t | uint16_t | float | double>); everything but the
+// staging (bytes) and the gradient phase is the same code
+template <typename T, int SBIN_T, int TC_T, typename IT = uint8_t>
 __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ tiles, const LevelDev* __restrict__ levels,
                                                 const uint8_t* __restrict__ pyr, T* __restrict__ feat, int cn,
                                                 int sbin_rt, int tc_rt, const uint8_t* __restrict__ binlut, uint16_t* __restrict__ split, int split_parts) {
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
   HOG_STAMP(0);
   const HogTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
-  const HogLds L = hog_lds_layout(sbin, tc, cn, (int)sizeof(T));
+  const int bpp = cn * (int)sizeof(IT);
+  const HogLds L = hog_lds_layout(sbin, tc, bpp, (int)sizeof(T));
   T* mag = (T*)(smem + L.mag_off);
   uint8_t* bin = (uint8_t*)(smem + L.bin_off);
   uint8_t* raw = (uint8_t*)(smem + L.raw_off);
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
   const int w = lv.iw, h = lv.ih, bw = lv.bw, bh = lv.bh;
   const int vw = bw * sbin, vh = bh * sbin;  // :176 visible
   const uint8_t* im = pyr + lv.img_off;
-  const int stride = w * cn;
+  const int stride = w * bpp;
   // pixel window origin: first pixel that can touch block (cy0, cx0) (one more before it for odd cell sizes)
   const int py0 = t.cy0 * sbin - (sbin + 1) / 2 - L.P0, px0 = t.cx0 * sbin - (sbin + 1) / 2 - L.P0;
   const int ry0 = py0 - L.MG, rx0 = px0 - L.MG;  // raw tile origin (source coordinates)
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
     const int wpr = RP >> 2;                          // words per raw row
     const int nword = RT * wpr;
     const int rowbytes = stride;                      // bytes of a source row
-    const int b00 = rx0 * cn;                         // source byte of the raw row's first byte (may be negative)
+    const int b00 = rx0 * bpp;                        // source byte of the raw row's first byte (may be negative)
     constexpr int LBW = 4;                            // words in flight per thread and batch
     for (int i0 = tid; i0 < nword; i0 += HOG_NT * LBW) {
       unsigned wv[LBW];
@@ -211,6 +214,29 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
     int b = 0;
     if (y >= 1 && y < vh - 1 && x >= 1 && x < vw - 1) {
       const int sx = min(x, w - 2), sy = min(y, h - 2);  // :208,218 source clamp
+      if constexpr (sizeof(IT) > 1) {
+        // wider pixels: the differences in IT's promoted type (int / float / double), squares and comparisons in T, the snap by the
+        // reference's own chain (:205-249; no table: the differences are not 9-bit integers)
+        const IT* s = (const IT*)(raw + (sy - ry0) * RP + (sx - rx0) * bpp);
+        const int rs = RP / (int)sizeof(IT);
+        T dx, dy, v;
+        if (cn == 1) {
+          dy = (T)(s[rs] - s[-rs]);
+          dx = (T)(s[1] - s[-1]);
+          v = dx * dx + dy * dy;
+        } else {
+          const T dyb = (T)(s[rs] - s[-rs]), dxb = (T)(s[3] - s[-3]);
+          const T vb = dxb * dxb + dyb * dyb;
+          const T dyg = (T)(s[rs + 1] - s[-rs + 1]), dxg = (T)(s[4] - s[-2]);
+          const T vg = dxg * dxg + dyg * dyg;
+          dy = (T)(s[rs + 2] - s[-rs + 2]); dx = (T)(s[5] - s[-1]);
+          v = dx * dx + dy * dy;
+          if (vg > v) { v = vg; dx = dxg; dy = dyg; }
+          if (vb > v) { v = vb; dx = dxb; dy = dyb; }
+        }
+        b = hog_snap<T>(dx, dy);
+        m = t_sqrt(v);
+      } else {
       const uint8_t* s = raw + (sy - ry0) * RP + (sx - rx0) * cn;
       int dxi, dyi, vi;
       if (cn == 1) {
@@ -230,6 +256,7 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
       vi = dxi * dxi + dyi * dyi;
       b = binlut[(dyi + 255) * HOG_LUT_SIDE + (dxi + 255)];
       m = t_sqrt((T)vi);
+      }
     }
     mag[wy * L.MP + wx] = m;
     bin[wy * L.MP + wx] = (uint8_t)b;
@@ -391,14 +418,18 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
 
 template <typename T>
 static void launch_hog_t(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, T* feat,
-                         int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, hipStream_t s) {
-  const size_t lds = hog_lds_bytes(sbin, tc, (int)sizeof(T));
+                         int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, int depth, hipStream_t s) {
+  const int esz = depth == PBD_DEPTH_16U ? 2 : depth == PBD_DEPTH_32F ? 4 : depth == PBD_DEPTH_64F ? 8 : 1;
+  const size_t lds = hog_lds_bytes(sbin, tc, (int)sizeof(T), cn * esz);
   auto go = [&](auto kern) {
     static LdsOptIn optin;  // one per instantiation (the lambda is instantiated per kernel), per-device state inside
     optin.ensure((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(HOG_NT), lds, s, tiles, levels, pyr, feat, cn, sbin, tc, binlut, split, split_parts);
   };
-  if (sbin == 4 && tc == 16) go(k_hog<T, 4, 16>);
+  if (depth == PBD_DEPTH_16U) go(k_hog<T, 0, 0, uint16_t>);      // (the generic cell size / tile side instantiation: pbd_detect_image's depths)
+  else if (depth == PBD_DEPTH_32F) go(k_hog<T, 0, 0, float>);
+  else if (depth == PBD_DEPTH_64F) go(k_hog<T, 0, 0, double>);
+  else if (sbin == 4 && tc == 16) go(k_hog<T, 4, 16>);
   else if (sbin == 4 && tc == 8) go(k_hog<T, 4, 8>);
   else if (sbin == 8 && tc == 8) go(k_hog<T, 8, 8>);
   else go(k_hog<T, 0, 0>);
@@ -408,8 +439,8 @@ static void launch_hog_t(const HogTile* tiles, int ntiles, const LevelDev* level
 // binlut: the orientation-snap table of the same T (launch_hog_binlut)
 // split != nullptr (float handles with a split-product filter bank): the features' parts are written too — split_parts 3: bfloat16, 2: binary16
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
-                int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, hipStream_t s) {
+                int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, int depth, hipStream_t s) {
   if (ntiles <= 0) return;
-  if (ts == 8) launch_hog_t<double>(tiles, ntiles, levels, pyr, (double*)feat, cn, sbin, tc, binlut, nullptr, 0, s);
-  else launch_hog_t<float>(tiles, ntiles, levels, pyr, (float*)feat, cn, sbin, tc, binlut, split, split_parts, s);
+  if (ts == 8) launch_hog_t<double>(tiles, ntiles, levels, pyr, (double*)feat, cn, sbin, tc, binlut, nullptr, 0, depth, s);
+  else launch_hog_t<float>(tiles, ntiles, levels, pyr, (float*)feat, cn, sbin, tc, binlut, split, split_parts, depth, s);
 }

@@ -6,6 +6,7 @@
 // bound by memory-instruction issue, not bytes: the level images are packed byte rows, so the
 // kernels move them as 4-byte words wherever a word lies inside a row (the hardware takes
 // unaligned dword accesses) and keep the 5x5 pyrDown window in LDS (separable passes).
+#include <algorithm>
 #include "pbd_internal.hpp"
 
 typedef __attribute__((aligned(1))) unsigned u32_unaligned;
@@ -191,4 +192,115 @@ void launch_pyrdown(const PyrJob* jobs, int njobs, int maxw, int maxh, int cn, u
   dim3 grid((maxw + PD_TW - 1) / PD_TW, (maxh + PD_TH - 1) / PD_TH, njobs);
   if (cn == 3) hipLaunchKernelGGL(k_pyrdown_u8<3>, grid, dim3(256), 0, s, jobs, pyr);
   else hipLaunchKernelGGL(k_pyrdown_u8<1>, grid, dim3(256), 0, s, jobs, pyr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The other image depths HOGFeatures<T>::pyramid accepts (src/HOGFeatures.cpp:136-146: CV_16U, CV_32F, CV_64F;
+// pbd_detect_image).  No caller of the reference passes them (src/demo.cpp, ros/Node.cpp, cells/detect.cpp hand over
+// 8-bit BGR), so these kernels are plain — one thread per output element — and follow oracle/pbd_oracle.c's
+// restatement of OpenCV 2.4 operation by operation (-ffp-contract=off):
+//   resize:  floating-point interpolation with float coefficients — row value S[sx] a0 + S[sx + cn] a1 in WT, then
+//            R0 b0 + R1 b1 in WT (WT = float for ushort / float pixels, double for double), ushort: cvRound + clamp;
+//   pyrDown: ushort = the 8-bit integer form; float / double: row = s2 6 + (s1 + s3) 4 + s0 + s4 per source row, the
+//            same expression over the five rows, times 1 / 256 (FltCast<T, 8>, scalar association).
+// Job offsets are in BYTES, strides in elements.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename PT> struct PyrWork { typedef float type; };
+template <> struct PyrWork<double> { typedef double type; };
+template <typename PT> __device__ __forceinline__ PT pyr_cast(typename PyrWork<PT>::type v) { return (PT)v; }
+template <> __device__ __forceinline__ uint16_t pyr_cast<uint16_t>(float v) {
+  const int i = __float2int_rn(v);   // cvRound: half to even
+  return (uint16_t)(i < 0 ? 0 : (i > 65535 ? 65535 : i));
+}
+
+template <typename PT>
+__global__ __launch_bounds__(256) void k_resize_linear_any(const PyrJob* __restrict__ jobs, int cn, int sstride,
+                                                           const uint8_t* __restrict__ src0, uint8_t* __restrict__ pyr) {
+  typedef typename PyrWork<PT>::type WT;
+  const PyrJob a = jobs[blockIdx.y];
+  const int dw = a.dw, dh = a.dh, sw = a.sw, sh = a.sh;
+  const PT* src = (const PT*)(src0 + a.soff);
+  PT* dst = (PT*)(pyr + a.doff);
+  const int n = dw * dh * cn;
+  if (dw == sw && dh == sh) {   // cv::resize to the same size: all fractions are zero — a copy
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const int y = i / (dw * cn), xc = i - y * (dw * cn);
+      dst[i] = src[(size_t)y * sstride + xc];
+    }
+    return;
+  }
+  const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int dy = i / (dw * cn), xc = i - dy * (dw * cn);
+    const int dx = xc / cn, c = xc - dx * cn;
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    const bool edge = (sx + 1 >= sw);
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    const float a0 = 1.f - fx, a1 = fx;
+    const WT b0 = 1.f - fy, b1 = fy;
+    const int sy0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+    const int sy1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+    const PT* S0 = src + (size_t)sy0 * sstride + sx * cn + c;
+    const PT* S1 = src + (size_t)sy1 * sstride + sx * cn + c;
+    WT r0, r1;
+    if (edge) { r0 = (WT)(S0[0] * 1); r1 = (WT)(S1[0] * 1); }
+    else { r0 = (WT)(S0[0] * a0 + S0[cn] * a1); r1 = (WT)(S1[0] * a0 + S1[cn] * a1); }
+    dst[i] = pyr_cast<PT>(r0 * b0 + r1 * b1);
+  }
+}
+
+template <typename PT>
+__global__ __launch_bounds__(256) void k_pyrdown_any(const PyrJob* __restrict__ jobs, int cn, uint8_t* __restrict__ pyr) {
+  const PyrJob a = jobs[blockIdx.y];
+  const int sw = a.sw, sh = a.sh, dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+  const PT* src = (const PT*)(pyr + a.soff);
+  PT* dst = (PT*)(pyr + a.doff);
+  const int n = dw * dh * cn;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int y = i / (dw * cn), xc = i - y * (dw * cn);
+    const int x = xc / cn, c = xc - x * cn;
+    int xs[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) xs[j] = reflect101_dev(2 * x + j - 2, sw) * cn + c;
+    if constexpr (sizeof(PT) == 2) {
+      int row[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const PT* S = src + (size_t)reflect101_dev(2 * y + k - 2, sh) * sw * cn;
+        row[k] = (int)S[xs[0]] + 4 * (int)S[xs[1]] + 6 * (int)S[xs[2]] + 4 * (int)S[xs[3]] + (int)S[xs[4]];
+      }
+      dst[i] = (PT)((row[0] + 4 * row[1] + 6 * row[2] + 4 * row[3] + row[4] + 128) >> 8);
+    } else {
+      PT row[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const PT* S = src + (size_t)reflect101_dev(2 * y + k - 2, sh) * sw * cn;
+        const PT s0 = S[xs[0]], s1 = S[xs[1]], s2 = S[xs[2]], s3 = S[xs[3]], s4 = S[xs[4]];
+        row[k] = s2 * 6 + (s1 + s3) * 4 + s0 + s4;
+      }
+      dst[i] = (row[2] * 6 + (row[1] + row[3]) * 4 + row[0] + row[4]) * (PT)(1. / 256);
+    }
+  }
+}
+
+// depth: PBD_DEPTH_16U / 32F / 64F; sstride: bytes
+void launch_resize_any(const PyrJob* jobs, int njobs, int maxpix, int cn, int depth, int sstride, const uint8_t* src, uint8_t* pyr, hipStream_t s) {
+  if (njobs <= 0) return;
+  dim3 grid((unsigned)std::min<long long>(((long long)maxpix * cn + 255) / 256, 4096), njobs);
+  if (depth == PBD_DEPTH_16U) hipLaunchKernelGGL(k_resize_linear_any<uint16_t>, grid, dim3(256), 0, s, jobs, cn, sstride / 2, src, pyr);
+  else if (depth == PBD_DEPTH_32F) hipLaunchKernelGGL(k_resize_linear_any<float>, grid, dim3(256), 0, s, jobs, cn, sstride / 4, src, pyr);
+  else hipLaunchKernelGGL(k_resize_linear_any<double>, grid, dim3(256), 0, s, jobs, cn, sstride / 8, src, pyr);
+}
+void launch_pyrdown_any(const PyrJob* jobs, int njobs, int maxpix, int cn, int depth, uint8_t* pyr, hipStream_t s) {
+  if (njobs <= 0) return;
+  dim3 grid((unsigned)std::min<long long>(((long long)maxpix * cn + 255) / 256, 4096), njobs);
+  if (depth == PBD_DEPTH_16U) hipLaunchKernelGGL(k_pyrdown_any<uint16_t>, grid, dim3(256), 0, s, jobs, cn, pyr);
+  else if (depth == PBD_DEPTH_32F) hipLaunchKernelGGL(k_pyrdown_any<float>, grid, dim3(256), 0, s, jobs, cn, pyr);
+  else hipLaunchKernelGGL(k_pyrdown_any<double>, grid, dim3(256), 0, s, jobs, cn, pyr);
 }

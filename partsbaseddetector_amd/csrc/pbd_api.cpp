@@ -394,7 +394,7 @@ static void free_frame(pbd_handle* h) {
   h->frame_allocs.clear();
   h->frame_bytes = 0;
   h->d_extx = h->d_exty = nullptr; h->d_ext_base = nullptr; h->ext_ptr = false;
-  h->fw = h->fh = h->fcn = 0;
+  h->fw = h->fh = h->fcn = 0; h->fdepth = 0; h->fesz = 1;
   h->have_pyr = h->have_feat = h->have_resp = h->have_dp = false;
   h->min_ran = false;
   h->feat_split_ok = false;
@@ -473,9 +473,13 @@ static DtMap dt_map(const void* src, void* dst, int16_t* ptr, float wq, float wl
   return m;
 }
 
-static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
-  if (h->fw == w && h->fh == hgt && h->fcn == cn && h->batch == batch) return PBD_OK;
-  if (cn != 1 && cn != 3) return fail(h, PBD_ERR_UNSUPPORTED, "image: 1 or 3 channels of 8 bits");
+static int depth_esz(int depth) { return depth == PBD_DEPTH_8U ? 1 : depth == PBD_DEPTH_16U ? 2 : depth == PBD_DEPTH_32F ? 4 : depth == PBD_DEPTH_64F ? 8 : 0; }
+static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1, int depth = PBD_DEPTH_8U) {
+  if (h->fw == w && h->fh == hgt && h->fcn == cn && h->batch == batch && h->fdepth == depth) return PBD_OK;
+  if (cn != 1 && cn != 3) return fail(h, PBD_ERR_UNSUPPORTED, "image: 1 or 3 channels");
+  const int esz = depth_esz(depth);
+  if (!esz) return fail(h, PBD_ERR_UNSUPPORTED, "Unsupported image type (src/HOGFeatures.cpp:136-146: CV_8U, CV_16U, CV_32F, CV_64F)");
+  if (esz > 1 && batch != 1) return fail(h, PBD_ERR_UNSUPPORTED, "batches of frames: 8-bit images");
   if (batch < 1 || batch > 64) return fail(h, PBD_ERR_ARG, "batch: 1..64 frames");
   hipStreamSynchronize(h->stream);
   free_frame(h);
@@ -503,13 +507,13 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
     if (L.cw > 32767 || L.ch > 32767) return fail(h, PBD_ERR_UNSUPPORTED, "level too large for 16-bit pointers");
     // the fold loader addresses a level's planes with 32-bit offsets: cell * sizeof(T) and plane * cells + cell (<= 8 planes of a child)
     if ((size_t)L.cw * L.ch >= ((size_t)1 << 28)) return fail(h, PBD_ERR_UNSUPPORTED, "level too large (2^28 cells)");
-    L.img_off = pyr; pyr += (size_t)L.iw * L.ih * cn;
+    L.img_off = pyr; pyr += (size_t)L.iw * L.ih * cn * esz;
     L.cell_off = cells; cells += (size_t)L.cw * L.ch;
   }
   h->cells = cells; h->pyr_bytes = pyr;
   if (cells >= (1u << 31)) return fail(h, PBD_ERR_UNSUPPORTED, "frame too large");
   int rc;
-  if ((rc = dev_alloc(h, &h->d_img, (size_t)w * hgt * cn * batch))) return rc;
+  if ((rc = dev_alloc(h, &h->d_img, (size_t)w * hgt * cn * esz * batch))) return rc;
   {  // image pyramid jobs: the first octave of every frame from the frame (tightly packed, back to back), then the chains
     std::vector<PyrJob> jobs;
     h->pyr_launches.clear();
@@ -517,7 +521,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
     for (int f = 0; f < batch; ++f)
       for (int i = 0; i < m.interval; ++i) {
         const Level& L = h->lv[f * n1 + i];
-        jobs.push_back(PyrJob{(unsigned long long)f * w * hgt * cn, (unsigned long long)L.img_off, w, hgt, L.iw, L.ih});
+        jobs.push_back(PyrJob{(unsigned long long)f * w * hgt * cn * esz, (unsigned long long)L.img_off, w, hgt, L.iw, L.ih});
         R.maxpix = std::max(R.maxpix, L.iw * L.ih);
       }
     R.njobs = (int)jobs.size();
@@ -579,9 +583,10 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
 
   // HOG tiles: TC x TC cells; shrink the tile until its LDS footprint fits
   h->hog_tc = 16;
+  const int hog_bpp = esz == 1 ? 3 : cn * esz;    // (8-bit frames: the tile side does not depend on the channel count)
   if (const char* e = PBD_PROBE_ENV("PBD_HOG_TC")) h->hog_tc = std::max(2, std::min(16, atoi(e)));   // tuning builds
-  while (h->hog_tc > 2 && hog_lds_bytes(m.sbin, h->hog_tc, h->ts) > 150 * 1024) h->hog_tc /= 2;
-  if (hog_lds_bytes(m.sbin, h->hog_tc, h->ts) > 150 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "sbin too large");
+  while (h->hog_tc > 2 && hog_lds_bytes(m.sbin, h->hog_tc, h->ts, hog_bpp) > 150 * 1024) h->hog_tc /= 2;
+  if (hog_lds_bytes(m.sbin, h->hog_tc, h->ts, hog_bpp) > 150 * 1024) return fail(h, PBD_ERR_UNSUPPORTED, "sbin too large");
   std::vector<HogTile> ht;
   std::vector<ConvTile> ct;
   for (int l = 0; l < n; ++l) {
@@ -958,7 +963,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1) {
     for (size_t fp = 0; fp < h->parts.size(); ++fp)
       if (h->parts[fp].p > 0 && h->lv[l].active) h->scr_base[(size_t)l * h->parts.size() + fp] = scr_of((int)fp, l, 0);
   if ((rc = dev_upload(h, &h->d_scr_base, h->scr_base))) return rc;
-  h->fw = w; h->fh = hgt; h->fcn = cn;
+  h->fw = w; h->fh = hgt; h->fcn = cn; h->fdepth = depth; h->fesz = esz;
   return PBD_OK;
 }
 
@@ -969,6 +974,10 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
   // one launch for the first octave of every frame of the batch (cv::resize), one per octave step below it (cv::pyrDown)
   for (size_t i = 0; i < h->pyr_launches.size(); ++i) {
     const pbd_handle::PyrLaunch& P = h->pyr_launches[i];
+    if (h->fdepth != PBD_DEPTH_8U) {   // 16-bit / float / double frames (pbd_detect_image): the plain per-element kernels
+      if (i == 0) launch_resize_any(h->d_pyrjobs + P.job0, P.njobs, P.maxpix, h->fcn, h->fdepth, stride, d_src, h->d_pyr, h->stream);
+      else launch_pyrdown_any(h->d_pyrjobs + P.job0, P.njobs, P.maxpix, h->fcn, h->fdepth, h->d_pyr, h->stream);
+    } else
     if (i == 0) launch_resize(h->d_pyrjobs + P.job0, P.njobs, P.maxpix, h->fcn, stride, d_src, h->d_pyr, h->stream);
     else launch_pyrdown(h->d_pyrjobs + P.job0, P.njobs, P.maxw, P.maxh, h->fcn, h->d_pyr, h->stream);
   }
@@ -981,7 +990,7 @@ static int run_image_pyramid(pbd_handle* h, const uint8_t* d_src, int stride) {
 
 static int run_hog(pbd_handle* h) {
   uint16_t* split = h->split_parts ? h->d_feat_split : nullptr;
-  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->d_hog_lut, split, h->split_parts, h->stream);
+  launch_hog(h->d_hog_tiles, h->n_hog_tiles, h->d_levels, h->d_pyr, h->d_feat, h->ts, h->fcn, h->md.sbin, h->hog_tc, h->d_hog_lut, split, h->split_parts, h->fdepth, h->stream);
   LAUNCHCHK(h, "HOG");
   h->feat_split_ok = split != nullptr;
   h->have_feat = true;
@@ -1219,7 +1228,7 @@ static int enqueue_stages(pbd_handle* h, const uint8_t* d_src, int stride) {
 // an image that lives elsewhere in HBM is copied there first (0.9 MB, on the same stream).  Profiling runs (stage
 // events) and level groups on extra streams use the eager path.
 static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
-  const bool graphable = h->opt.graph && !h->profiling;
+  const bool graphable = h->opt.graph && !h->profiling && h->fdepth == PBD_DEPTH_8U;
   if (!graphable || h->frames_on_plan == 0) {
     h->frames_on_plan++;
     return enqueue_stages(h, d_src, stride);
@@ -1412,6 +1421,40 @@ int pbd_detect_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int 
   return pbd_detect_collect(h, heads, boxes, locs, capacity, count);
 }
 
+// ---- images of the other depths the reference accepts (src/HOGFeatures.cpp:136-146): single frames, host images, eager launches ----
+static int upload_image_any(pbd_handle* h, const void* im, int depth, int w, int hgt, int cn, int stride) {
+  const int esz = depth_esz(depth);
+  if (!esz) return fail(h, PBD_ERR_UNSUPPORTED, "Unsupported image type (src/HOGFeatures.cpp:136-146: CV_8U, CV_16U, CV_32F, CV_64F)");
+  const size_t row = (size_t)w * cn * esz;
+  if (stride < 0 || (size_t)stride < row || stride % esz) return fail(h, PBD_ERR_ARG, "stride: bytes, >= w * cn * element size and a multiple of the element size");
+  ON_DEVICE(h);
+  int rc = plan_frame(h, w, hgt, cn, 1, depth);
+  if (rc) return rc;
+  if ((size_t)stride == row) HIPCHK(h, hipMemcpyAsync(h->d_img, im, row * hgt, hipMemcpyHostToDevice, h->stream));
+  else HIPCHK(h, hipMemcpy2DAsync(h->d_img, row, im, stride, row, hgt, hipMemcpyHostToDevice, h->stream));
+  return PBD_OK;
+}
+int pbd_detect_image(pbd_handle* h, const void* im, int depth, int w, int hgt, int cn, int stride, pbd_candidate_head* heads,
+                     int32_t* boxes, int32_t* locs, int capacity, int* count) {
+  if (!h || !im) return PBD_ERR_ARG;
+  if (depth == PBD_DEPTH_8U) return pbd_detect_u8(h, (const uint8_t*)im, w, hgt, cn, stride, heads, boxes, locs, capacity, count);
+  if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
+  int rc = upload_image_any(h, im, depth, w, hgt, cn, stride);
+  if (rc) return rc;
+  if ((rc = enqueue_all(h, h->d_img, w * cn * h->fesz))) return rc;
+  return pbd_detect_collect(h, heads, boxes, locs, capacity, count);
+}
+int pbd_pyramid_image(pbd_handle* h, const void* im, int depth, int w, int hgt, int cn, int stride) {
+  if (!h || !im) return PBD_ERR_ARG;
+  if (depth == PBD_DEPTH_8U) return pbd_pyramid_u8(h, (const uint8_t*)im, w, hgt, cn, stride);
+  int rc = upload_image_any(h, im, depth, w, hgt, cn, stride);
+  if (rc) return rc;
+  if ((rc = run_image_pyramid(h, h->d_img, w * cn * h->fesz))) return rc;
+  if ((rc = run_hog(h))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PBD_OK;
+}
+
 // ---- a batch of same-sized frames through ONE handle ---------------------------------------------------------
 // (SURVEY 8b lists pbd_detect_batch_u8; configs[2] hands every GPU 4 frames.)  The frames of a batch are planned as
 // extra "virtual levels" (pbd_internal.hpp), so every stage is one launch — or one chain of launches — for the whole
@@ -1528,7 +1571,20 @@ int pbd_get_level_image(pbd_handle* h, int level, uint8_t* out) {
   const Level& L = h->lv[level];
   ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->fdepth != PBD_DEPTH_8U) return fail(h, PBD_ERR_STATE, "the planned frame is not 8-bit: pbd_get_level_image_raw");
   HIPCHK(h, hipMemcpy(out, h->d_pyr + L.img_off, (size_t)L.iw * L.ih * h->fcn, hipMemcpyDeviceToHost));
+  return PBD_OK;
+}
+int pbd_get_level_image_raw(pbd_handle* h, int level, void* out, size_t out_bytes) {
+  CHECK_LEVEL(h, level);
+  if (!out) return PBD_ERR_ARG;
+  if (!h->have_pyr) return fail(h, PBD_ERR_STATE, "pyramid not computed");
+  const Level& L = h->lv[level];
+  const size_t bytes = (size_t)L.iw * L.ih * h->fcn * h->fesz;
+  if (out_bytes < bytes) return fail(h, PBD_ERR_CAPACITY, "pbd_get_level_image_raw: iw * ih * cn * element size bytes");
+  ON_DEVICE(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_pyr + L.img_off, bytes, hipMemcpyDeviceToHost));
   return PBD_OK;
 }
 // The float / _f64 entry points share one body; a handle only answers the pair that matches the
@@ -1894,7 +1950,7 @@ static int hog_u8_(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int
   HIPCHK(h, hipMemcpy2D(d_im, (size_t)w * cn, im, stride, (size_t)w * cn, hgt, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_lv, &L, sizeof(L), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d_tiles, tiles.data(), sizeof(HogTile) * tiles.size(), hipMemcpyHostToDevice));
-  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, ts, cn, sbin, tc, h->d_hog_lut, nullptr, 0, h->stream);
+  launch_hog(d_tiles, (int)tiles.size(), d_lv, d_im, d_feat, ts, cn, sbin, tc, h->d_hog_lut, nullptr, 0, PBD_DEPTH_8U, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, d_feat, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyDeviceToHost));
   hipFree(d_im); hipFree(d_feat); hipFree(d_lv); hipFree(d_tiles);

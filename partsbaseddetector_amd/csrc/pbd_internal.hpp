@@ -161,6 +161,7 @@ struct pbd_handle {
 
   // frame plan
   int fw = 0, fh = 0, fcn = 0, nlevels = 0;     // nlevels: levels of ONE frame
+  int fdepth = 0, fesz = 1;                      // depth of the planned frame's pixels (PBD_DEPTH_*: cv::Mat::depth()), bytes per element
   // A batch of B same-sized frames is planned as B x nlevels "virtual levels" (frame f's level l = f * nlevels + l):
   // every stage is driven by per-level tables, so one launch of a stage then covers all frames of the batch — four
   // times the blocks per launch, the thin rounds of the DP fill the chip and launch tails are paid once per batch.
@@ -302,8 +303,11 @@ int pbd_i_emit(pbd_handle* h, const std::vector<const char*>& recs, pbd_candidat
 void launch_resize(const PyrJob* jobs, int njobs, int maxpix, int cn, int sstride, const uint8_t* src, uint8_t* pyr, hipStream_t s);
 void launch_pyrdown(const PyrJob* jobs, int njobs, int maxw, int maxh, int cn, uint8_t* pyr, hipStream_t s);
 void launch_hog(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, void* feat, int ts,
-                int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, hipStream_t s);
-size_t hog_lds_bytes(int sbin, int tc, int ts);
+                int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, int depth, hipStream_t s);   // depth: PBD_DEPTH_* of the level images
+size_t hog_lds_bytes(int sbin, int tc, int ts, int bpp = 3);      // bpp: bytes per pixel (channels x element size)
+// the image depths beyond 8 bits (k_pyramid.hip): job offsets in bytes, sstride in bytes
+void launch_resize_any(const PyrJob* jobs, int njobs, int maxpix, int cn, int depth, int sstride, const uint8_t* src, uint8_t* pyr, hipStream_t s);
+void launch_pyrdown_any(const PyrJob* jobs, int njobs, int maxpix, int cn, int depth, uint8_t* pyr, hipStream_t s);
 size_t hog_binlut_bytes();                                        // orientation-snap table: best_o for every (dx, dy) in [-255, 255]^2
 void launch_hog_binlut(uint8_t* lut, int ts, hipStream_t s);      // evaluated in T (ts = sizeof(T)) with the reference's own chain (k_hog.hip)
 // split-product filter bank (k_conv_split.hip): fp32 features -> three exact bfloat16 parts; kh x kw x 32 filters, float responses

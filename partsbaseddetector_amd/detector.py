@@ -117,8 +117,14 @@ class HOGFeatures:
 
     def pyramid(self, im: np.ndarray) -> List[np.ndarray]:
         """HOGFeatures<T>::pyramid: returns the feature pyramid (fine to coarse),
-        each level H x (W*flen) like the reference's cv::Mat; it also stays resident."""
-        self._h.pyramid(im)
+        each level H x (W*flen) like the reference's cv::Mat; it also stays resident.  The image's dtype is its depth (:136-146:
+        uint8, uint16, float32, float64; anything else raises like CV_Error(StsUnsupportedFormat))."""
+        if np.asarray(im).dtype == np.uint8:
+            self._h.pyramid(im)
+        elif np.asarray(im).dtype in capi.DEPTH_OF:
+            self._h.pyramid_image(im)
+        else:
+            raise capi.PbdError(capi.PBD_ERR_UNSUPPORTED, "Unsupported image type")
         g = self._h._geo
         self._nscales, self._scales = g["nlevels"], g["scales"]
         return [self._h.level_features(l).reshape(g["cell_h"][l], -1) for l in range(g["nlevels"])]
@@ -231,5 +237,7 @@ class PartsBasedDetector:
         """src/PartsBasedDetector.cpp:69-95.  `depth` is accepted and ignored like the
         reference (:91-93); results are APPENDED to `candidates` (DynamicProgram.cpp:250)."""
         out = candidates if candidates is not None else []
-        out.extend(Candidate._unpack(*self.handle.detect(im, self._cap)))
+        # (the image's dtype is its depth: uint8 -> pbd_detect_u8, the other accepted depths -> pbd_detect_image; unsupported ones raise)
+        res = self.handle.detect(im, self._cap) if np.asarray(im).dtype == np.uint8 else self.handle.detect_image(im, self._cap)
+        out.extend(Candidate._unpack(*res))
         return out

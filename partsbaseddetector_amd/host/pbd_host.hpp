@@ -30,7 +30,7 @@
 
 namespace pbd {
 
-enum { PBD_8U = 0, PBD_32S = 4, PBD_32F = 5, PBD_64F = 6 };  // depth codes (numerically OpenCV's CV_8U/32S/32F/64F)
+enum { PBD_8U = 0, PBD_16U = 2, PBD_32S = 4, PBD_32F = 5, PBD_64F = 6 };  // depth codes (numerically OpenCV's CV_8U/16U/32S/32F/64F = pbd_c.h's PBD_DEPTH_*)
 template <typename T> struct DataType;               // cv::DataType<T>::type
 template <> struct DataType<float> { enum { type = PBD_32F, scalar = PBD_SCALAR_F32 }; };
 template <> struct DataType<double> { enum { type = PBD_64F, scalar = PBD_SCALAR_F64 }; };
@@ -53,7 +53,7 @@ class Mat {
   bool empty() const { return buf_.empty(); }
   int depth() const { return depth_; }
   int channels() const { return cn_; }
-  size_t elem1() const { return depth_ == PBD_8U ? 1 : depth_ == PBD_64F ? 8 : 4; }
+  size_t elem1() const { return depth_ == PBD_8U ? 1 : depth_ == PBD_16U ? 2 : depth_ == PBD_64F ? 8 : 4; }
   size_t step() const { return (size_t)cols * cn_ * elem1(); }
   size_t bytes() const { return buf_.size(); }
   template <typename T> T* ptr(int r = 0) { return (T*)(buf_.data() + (size_t)r * step()); }
@@ -346,8 +346,8 @@ class HipHOGFeatures : public IFeatures {          // include/HOGFeatures.hpp:52
   size_t nscales() const override { return nscales_; }
   vectorf scales() const override { return scales_; }
   void pyramid(const Mat& im, vectorMat& pyrafeatures) override {   // src/HOGFeatures.cpp:95-151
-    if (im.depth() != PBD_8U) throw Exception(PBD_ERR_UNSUPPORTED, "Unsupported image type");  // :141-145
-    dev_->check(pbd_pyramid_u8(dev_->h, im.ptr<uint8_t>(), im.cols, im.rows, im.channels(), (int)im.step()));
+    // :136-146 dispatches features<uint8_t | uint16_t | float | double> on im.depth(); any other depth: StsUnsupportedFormat (the library refuses it)
+    dev_->check(pbd_pyramid_image(dev_->h, im.ptr<uint8_t>(), im.depth(), im.cols, im.rows, im.channels(), (int)im.step()));
     dev_->geometry(im.cols, im.rows);
     const int n = (int)dev_->cell_w.size();
     const std::vector<int32_t>&cw = dev_->cell_w, &ch = dev_->cell_h;
@@ -597,13 +597,13 @@ class PartsBasedDetector {
   // src/PartsBasedDetector.cpp:69-95: fused path, everything stays in HBM; `depth` ignored (:91-93)
   void detect(const Mat& im, const Mat& /*depth*/, vectorCandidate& candidates) {
     if (!dev_) throw Exception(PBD_ERR_STATE, "detect() before distributeModel()");
-    if (im.depth() != PBD_8U) throw Exception(PBD_ERR_UNSUPPORTED, "Unsupported image type");
     const int cap = dev_->max_candidates, mp = pbd_max_parts(dev_->h);
     std::vector<pbd_candidate_head> heads(cap);
     std::vector<int32_t> boxes((size_t)cap * mp * 4), locs((size_t)cap * mp * 3);
     int n = 0;
-    dev_->check(pbd_detect_u8(dev_->h, im.ptr<uint8_t>(), im.cols, im.rows, im.channels(), (int)im.step(),
-                              heads.data(), boxes.data(), locs.data(), cap, &n));
+    // (CV_8U forwards to pbd_detect_u8; CV_16U / CV_32F / CV_64F: src/HOGFeatures.cpp:136-146; anything else: PBD_ERR_UNSUPPORTED = StsUnsupportedFormat)
+    dev_->check(pbd_detect_image(dev_->h, im.ptr<uint8_t>(), im.depth(), im.cols, im.rows, im.channels(), (int)im.step(),
+                                 heads.data(), boxes.data(), locs.data(), cap, &n));
     append_candidates(candidates, heads, boxes, locs, n, mp);
   }
 };

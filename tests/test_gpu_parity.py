@@ -1816,3 +1816,85 @@ def test_fuzz_split_bank_one_seed(gpu_required):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools_fuzz_split.py"), "20", "3"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "")
+
+
+# ---------------------------------------------------------------- image depths beyond 8 bits (pbd_detect_image)
+def _wide_image(kind, seed, w, h, cn=3):
+    """an image of the given depth whose values use the depth's range (not an 8-bit image in a wider container)"""
+    rng = np.random.default_rng(seed)
+    base = make_image(seed, w, h, cn)
+    if kind == np.uint16:
+        return (base.astype(np.uint16) * 257) ^ rng.integers(0, 256, base.shape, dtype=np.uint16)
+    noise = rng.uniform(-0.5, 0.5, base.shape)
+    if kind == np.float32:
+        return ((base + noise) / 255.0).astype(np.float32)          # [0, 1] floats
+    return (base + noise).astype(np.float64) * 3.0 - 100.0          # doubles, negative values included
+
+
+@pytest.mark.parametrize("kind", [np.uint16, np.float32, np.float64])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_pyramid_and_hog_of_wide_images_bit_exact(gpu_required, orc, kind, dtype):
+    """HOGFeatures<T>::pyramid on CV_16U / CV_32F / CV_64F images (src/HOGFeatures.cpp:136-146): every level image in the image's own
+    type and every feature, bit for bit against the oracle, colour and gray, sizes with ragged tiles; then an 8-bit frame on the same handle"""
+    m = make_tree_model([-1, 0, 0], 2, seed=2)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dtype=dtype)
+    for seed, (w, hh, cn) in enumerate([(150, 110, 3), (97, 131, 1), (203, 77, 3)]):
+        im = _wide_image(kind, 10 + seed, w, hh, cn)
+        h.pyramid_image(im)
+        _, _, _, _, fr = orc.detect(m, im, capacity=1, keep=True, dtype=dtype)
+        g = h._geo
+        for l in range(g["nlevels"]):
+            np.testing.assert_array_equal(h.level_image_raw(l).view(np.uint8), fr.image(l, cn, kind).view(np.uint8))
+            np.testing.assert_array_equal(h.level_features(l).view(np.uint8), fr.feat(l).view(np.uint8))
+        fr.free()
+    im8 = make_image(4, 150, 110)
+    h.pyramid(im8)
+    np.testing.assert_array_equal(h.level_features(3).view(np.uint8), orc.hog(h.level_image(3), m.sbin, dtype=dtype).view(np.uint8))
+    np.testing.assert_array_equal(h.level_image_raw(3), h.level_image(3))
+    h.close()
+
+
+@pytest.mark.parametrize("kind", [np.uint16, np.float32, np.float64])
+def test_detect_image_wide_depths_vs_oracle(gpu_required, orc, kind):
+    """detect() end to end on 16-bit / float / double images, both instantiations: the candidates of the oracle, bit for bit (exact bank);
+    the default bank within the north_star's 1e-4 with every differing candidate classified"""
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    im = _wide_image(kind, 21, 200, 150)
+    for dtype in (np.float32, np.float64):
+        m.thresh = thresh_from_oracle(orc, m, im, 99.0)
+        h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dtype=dtype)
+        got = h.detect_image(im, capacity=4096)
+        ref = orc.detect(m, im, capacity=4096, dtype=dtype)[:3]
+        assert len(ref[0]) > 20
+        assert_candidates_equal(got, ref)
+        im8 = make_image(3, 200, 150)
+        got8 = h.detect(im8, capacity=4096)                                      # an 8-bit frame of the same size re-plans the handle
+        assert_candidates_equal(got8, orc.detect(m, im8, capacity=4096, dtype=dtype)[:3])
+        again = h.detect_image(im, capacity=4096)
+        assert_candidates_equal(again, ref)
+        h.close()
+    mm = make_tree_model([-1] + [0] * 19, 1, seed=8)                              # 20 filters: PBD_CONV_AUTO -> the split bank
+    mm.thresh = thresh_from_oracle(orc, mm, im, 99.0)
+    h = capi.Handle(mm)
+    assert h.conv_mode == capi.PBD_CONV_SPLIT
+    got = h.detect_image(im, capacity=4096)
+    ref = orc.detect(mm, im, capacity=4096)
+    ka = {(int(r["level"]), tuple(int(v) for v in l[0])): float(r["score"]) for r, l in zip(got[0], got[2])}
+    kb = {(int(r["level"]), tuple(int(v) for v in l[0])): float(r["score"]) for r, l in zip(ref[0], ref[2])}
+    common = set(ka) & set(kb)
+    assert len(common) >= 0.95 * max(len(ka), len(kb)) and len(common) > 20        # (threshold straddlers may differ)
+    assert max(abs(ka[k] - kb[k]) for k in common) < 1e-4
+    h.close()
+
+
+def test_detect_image_rejects_what_the_reference_rejects(gpu_required):
+    m = make_tree_model([-1, 0], 1, seed=1)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    im = make_image(1, 120, 90)
+    for bad in (im.astype(np.int8), im.astype(np.int16), im.astype(np.int32)):     # CV_8S, CV_16S, CV_32S
+        with pytest.raises(capi.PbdError) as e:
+            h.detect_image(bad)
+        assert e.value.code == capi.PBD_ERR_UNSUPPORTED
+    a, b = h.detect_image(im), h.detect(im)                                          # CV_8U forwards to pbd_detect_u8
+    assert_candidates_equal(a, b)
+    h.close()
