@@ -148,7 +148,7 @@ typedef struct pbd_options {
 int pbd_abi_version(void);
 /* Version history: 3 = rounds 3-4.  4 (round 5) = PBD_CONV_AUTO resolves to PBD_CONV_SPLIT for float handles (numerics of
  * AUTO change in the last bits: rounds 3-4 resolved to PBD_CONV_MFMA, and before that to EXACT for banks other than 5 x 5),
- * PBD_CONV_SPLIT, PBD_CONV_SPLIT_F16, pbd_detect_image / pbd_pyramid_image / pbd_get_level_image_raw (PBD_DEPTH_*), pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state, pbd_group_comm_size.  Struct layouts unchanged.   */
+ * PBD_CONV_SPLIT, PBD_CONV_SPLIT_F16, pbd_detect_image / pbd_pyramid_image / pbd_get_level_image_raw (PBD_DEPTH_*), pbd_tune_plan, pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state, pbd_group_comm_size.  Struct layouts unchanged.   */
 
 /* ---- output record: include/Candidate.hpp:56-111 --------------------------
  * One candidate = head + max_parts boxes (x, y, width, height as cv::Rect)
@@ -366,6 +366,12 @@ int pbd_get_work(const pbd_handle* h, double work[6]);
 /* device memory held by the handle: the buffers and work tables of the current frame geometry (everything a
  * re-plan frees) and the model-sized allocations made at create.  Either pointer may be NULL.                     */
 int pbd_get_footprint(const pbd_handle* h, size_t* frame_bytes, size_t* model_bytes);
+/* Measure the planner's distance-transform block geometry on the caller's own frames instead of trusting its rule (float handles:
+ * 256 lanes / 40 KB against 128 lanes / 25 KB per block; results are bit-identical under either): `batch` copies of the host image
+ * per call (1 = single frames, the reference's call shape; > 1 = pbd_detect_batch_u8), 2 warm-up + 3 timed calls per geometry, the
+ * dp_min stage's GPU time.  The faster one is kept for every later plan of this handle; *chosen = 1 / 2 (0: nothing to choose —
+ * double handles), ms[0..1] = the two medians.  im == NULL: back to the rule.  Synchronous; costs ten calls.                   */
+int pbd_tune_plan(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, int batch, int* chosen, double ms[2]);
 /* average GPU ms of the DP-min kernels alone over frames since the last reset
  * (HIP events on the handle's stream around the DP stage)                    */
 int pbd_dp_timer(pbd_handle* h, int reset, double* avg_ms, int* nframes);

@@ -42,7 +42,7 @@ EXPORTS = [
     "pbd_set_root", "pbd_set_root_f64", "pbd_set_dp_pointers", "pbd_get_footprint", "pbd_abi_version",
     "pbd_detect_batch_u8", "pbd_detect_batch_enqueue_u8", "pbd_detect_batch_enqueue_dev_u8", "pbd_detect_batch_collect",
     "pbd_get_stage_state", "pbd_get_conv_mode", "pbd_group_comm_size",
-    "pbd_detect_image", "pbd_pyramid_image", "pbd_get_level_image_raw",
+    "pbd_detect_image", "pbd_pyramid_image", "pbd_get_level_image_raw", "pbd_tune_plan",
 ]
 PBD_ABI_VERSION = 4
 
@@ -177,6 +177,19 @@ class Handle:
                                           heads.ctypes.data_as(C.c_void_p), _p(boxes, C.c_int32), _p(locs, C.c_int32),
                                           capacity, C.byref(cnt)))
         return self._out(heads, boxes, locs, cnt.value)
+
+    def tune_plan(self, im, batch=1):
+        """pbd_tune_plan: (chosen geometry 1 / 2 — 0 for double handles —, [ms with 256 lanes / 40 KB, ms with 128 lanes / 25 KB]); im=None: the rule again"""
+        chosen = C.c_int(0)
+        ms = (C.c_double * 2)()
+        if im is None:
+            self._chk(self.L.pbd_tune_plan(self.h, None, 0, 0, 0, 0, 1, C.byref(chosen), ms))
+            return 0, [0.0, 0.0]
+        im = np.ascontiguousarray(im, np.uint8)
+        hgt, w = im.shape[:2]
+        cn = 1 if im.ndim == 2 else im.shape[2]
+        self._chk(self.L.pbd_tune_plan(self.h, _p(im, C.c_uint8), w, hgt, cn, w * cn, int(batch), C.byref(chosen), ms))
+        return chosen.value, [ms[0], ms[1]]
 
     def detect_dev(self, dptr: int, w, hgt, cn, stride=None, capacity=4096):
         heads, boxes, locs = self._bufs(capacity)

@@ -663,12 +663,14 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1, int 
   const bool byte_links = dt_stride_for(maxlen) <= 256;
   // double (17 B per line element): two wavefronts and 40 KB per block — round 4, session 34: 0.473 / 0.721 ms per frame (batches / alone)
   // against 0.485 / 0.770 with one wavefront and 20 KB; round 5, session 3: 0.477 against 0.497 in batches, 893 against 879 frames/s
-  h->dt_nt = h->ts == 8 ? 128 : (byte_links ? 256 : PBD_DT_NT_DEFAULT);
+  // pbd_tune_plan: the other geometry measured on this handle's own frames (results are bit-identical under any geometry)
+  const bool big_blocks = h->ts == 4 && h->dt_geom ? h->dt_geom == 1 : byte_links;
+  h->dt_nt = h->ts == 8 ? 128 : (big_blocks ? 256 : PBD_DT_NT_DEFAULT);
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT")) h->dt_nt = std::max(64, std::min(256, atoi(e) & ~63));
   h->dt_nt_x = h->dt_nt;      // lanes of a fold x-pass block
   if (const char* e = PBD_PROBE_ENV("PBD_DT_NT_X")) h->dt_nt_x = std::max(64, std::min(256, atoi(e) & ~63));
   if (const char* e = PBD_PROBE_ENV("PBD_DT_SEG")) h->dt_seg = atoi(e);
-  size_t dt_base = (h->ts == 8 ? 40 : (byte_links ? 40 : 25)) * 1024;
+  size_t dt_base = (h->ts == 8 ? 40 : (big_blocks ? 40 : 25)) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_KB")) dt_base = (size_t)atoi(e) * 1024;
   if (const char* e = PBD_PROBE_ENV("PBD_DT_BUDGET_B")) dt_base = (size_t)atoi(e);
   int max_mix = 4;
@@ -1516,6 +1518,51 @@ int pbd_detect_batch_u8(pbd_handle* h, const uint8_t* const* ims, int nframes, i
   int rc = pbd_detect_batch_enqueue_u8(h, ims, nframes, w, hgt, cn, stride);
   if (rc) return rc;
   return pbd_detect_batch_collect(h, heads, boxes, locs, capacity, counts);
+}
+
+// ---- the planner's one measured rule, re-measured on the caller's own frames ---------------------------------
+// The distance transform's block geometry (lanes and LDS per block) changes the stage's time by a few per cent either way depending on
+// the frame size, the model and whether frames come singly or in batches, and never its results (dt_core.hpp: the same exact
+// algorithm under any segmentation).  plan_frame picks by a rule measured on seven sizes with the person model;
+// pbd_tune_plan runs the caller's frame through both geometries of a float handle — `batch` copies per call, 2 warm-up + 3 timed
+// calls each, the dp_min stage's GPU time from the stage events — and keeps the faster one for every later plan of this handle.
+// im == NULL: back to the rule.  chosen: 1 = 256 lanes / 40 KB, 2 = 128 lanes / 25 KB, 0 = nothing to choose (double handles).
+int pbd_tune_plan(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, int batch, int* chosen, double ms[2]) {
+  if (!h) return PBD_ERR_ARG;
+  if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
+  if (chosen) *chosen = 0;
+  if (ms) ms[0] = ms[1] = 0.0;
+  if (!im) { h->dt_geom = 0; h->fw = 0; return PBD_OK; }
+  if (h->ts != 4) return PBD_OK;
+  if (batch < 1 || batch > 64) return fail(h, PBD_ERR_ARG, "batch: 1..64 frames");
+  const int cap = h->opt.max_candidates;            // per frame (pbd_detect_batch_collect: heads[batch][capacity])
+  std::vector<pbd_candidate_head> heads((size_t)cap * batch);
+  std::vector<int> counts((size_t)batch);
+  std::vector<const uint8_t*> ims((size_t)batch, im);
+  const bool prof = h->profiling;
+  const int before = h->dt_geom;
+  double t[2] = {0, 0};
+  int rc = PBD_OK;
+  h->profiling = true;
+  for (int g = 1; g <= 2 && !rc; ++g) {
+    h->dt_geom = g; h->fw = 0;                      // (plan_frame re-plans: the key no longer matches)
+    double v[3] = {0, 0, 0};
+    for (int i = 0; i < 5 && !rc; ++i) {
+      rc = batch == 1 ? pbd_detect_u8(h, im, w, hgt, cn, stride, heads.data(), nullptr, nullptr, cap, counts.data())
+                      : pbd_detect_batch_u8(h, ims.data(), batch, w, hgt, cn, stride, heads.data(), nullptr, nullptr, cap, counts.data());
+      if (rc == PBD_ERR_CAPACITY) rc = PBD_OK;      // (a low threshold: the stage times are what is wanted)
+      if (i >= 2) v[i - 2] = h->stage_ms[3];
+    }
+    std::sort(v, v + 3);
+    t[g - 1] = v[1];
+  }
+  h->profiling = prof;
+  if (rc) { h->dt_geom = before; h->fw = 0; return rc; }
+  h->dt_geom = t[0] <= t[1] ? 1 : 2;
+  h->fw = 0;
+  if (chosen) *chosen = h->dt_geom;
+  if (ms) { ms[0] = t[0]; ms[1] = t[1]; }
+  return PBD_OK;
 }
 
 // ---- stage entry points -----------------------------------------------------

@@ -161,6 +161,7 @@ struct pbd_handle {
 
   // frame plan
   int fw = 0, fh = 0, fcn = 0, nlevels = 0;     // nlevels: levels of ONE frame
+  int dt_geom = 0;                               // distance-transform block geometry of float handles: 0 = the measured rule (plan_frame), 1 = 256 lanes / 40 KB, 2 = 128 lanes / 25 KB (pbd_tune_plan)
   int fdepth = 0, fesz = 1;                      // depth of the planned frame's pixels (PBD_DEPTH_*: cv::Mat::depth()), bytes per element
   // A batch of B same-sized frames is planned as B x nlevels "virtual levels" (frame f's level l = f * nlevels + l):
   // every stage is driven by per-level tables, so one launch of a stage then covers all frames of the batch — four

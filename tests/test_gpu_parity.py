@@ -1898,3 +1898,33 @@ def test_detect_image_rejects_what_the_reference_rejects(gpu_required):
     a, b = h.detect_image(im), h.detect(im)                                          # CV_8U forwards to pbd_detect_u8
     assert_candidates_equal(a, b)
     h.close()
+
+
+def test_tune_plan_keeps_results_and_picks_a_geometry(gpu_required, orc):
+    """pbd_tune_plan: the distance transform's block geometry measured on the caller's frames.  The candidates are
+    bit-identical before, after, and under the geometry the tuner did NOT pick; double handles have nothing to choose; im=None restores
+    the rule."""
+    from partsbaseddetector_amd.model import make_person_model
+    m = make_person_model(K=2)
+    im = make_image(6, 320, 240)
+    m.thresh = thresh_from_oracle(orc, m, im, 99.5)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
+    ref = h.detect(im)
+    assert len(ref[0]) > 10
+    chosen, ms = h.tune_plan(im)
+    assert chosen in (1, 2) and ms[0] > 0 and ms[1] > 0
+    assert_candidates_equal(h.detect(im), ref)
+    chosen_b, ms_b = h.tune_plan(im, batch=4)
+    assert chosen_b in (1, 2) and ms_b[0] > 0 and ms_b[1] > 0
+    outs = h.detect_batch([im] * 3)
+    for o in outs:
+        assert_candidates_equal(o, ref)
+    other = make_image(7, 200, 150)                  # another frame size plans with the kept geometry
+    assert_candidates_equal(h.detect(other), orc.detect(m, other)[:3])
+    h.tune_plan(None)
+    assert_candidates_equal(h.detect(im), ref)
+    h.close()
+    hd = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, dtype=np.float64)
+    assert hd.tune_plan(im)[0] == 0
+    hd.close()
+    print("tune_plan 320x240 person K=2: single frames", chosen, ms, "batches of 4", chosen_b, ms_b)
