@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path per GPU over one BATCH of B synthetic 640x480 frames (default B = 8:
+One "step" = one pass of the hot path per GPU over one BATCH of B synthetic 640x480 frames (default B = 16 —
+round 5's last sessions: 3 x 16 measures 2.4-4.1 % above 3 x 8 on two boxes, 3 x 24 / 3 x 32 / 4 x 12 / 4 x 16 below it —:
 pbd_detect_batch_enqueue_dev_u8 — every frame the full pyramid of 46 levels, HOG -> filter bank -> DP min -> argmin, one
 launch per stage for the whole batch; the candidates of every frame are copied back to the host every step).  S steps
 are in flight per GPU on S handles / streams (default S = 3).  --batch 1 = one frame per step (pbd_detect_enqueue_dev_u8).
@@ -152,7 +153,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--conv", choices=["auto", "exact", "mfma", "split", "split16"], default="auto")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("PBD_INFLIGHT", "3")),
-                    help="steps in flight per GPU on independent handles/streams (default 3 handles x batches of 8 frames: "
+                    help="steps in flight per GPU on independent handles/streams (default 3 handles x batches of 16 frames: "
                          "best measured throughput); 1 = strictly sequential calls (latency mode)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -168,7 +169,7 @@ def main():
                     help="ONE process driving --gpus N devices through pbd_group (no torchrun): every device listed --inflight "
                          "times, frames round-robin and software-pipelined over the members, host images in (H2D inside "
                          "the timed region), host gather of the candidates")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PBD_BATCH", "8")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PBD_BATCH", "16")),
                     help="frames per step and handle: >1 hands every handle a BATCH of same-sized frames (pbd_detect_batch_*: one "
                          "launch per stage for the whole batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -497,7 +498,7 @@ def main():
                     "algorithmic_bytes": B * work["B_dp"], "algorithmic_bytes_per_frame": work["B_dp"],
                     "launch_mode": "eager launches, per-stage HIP events on (the timed loop replays a hipGraph)",
                     "timing": "HIP events around the stage, mean of 12 sequential batches after the timed loop; the rocprofv3 kernel trace of the "
-                              "same leg (bench.py --legs batchseq --graph 0 --inflight 1) is profiles/*_kernel_stats_batch8.csv"}
+                              "same leg (bench.py --legs batchseq --graph 0 --inflight 1) is profiles/*_kernel_stats_batch<B>.csv"}
         elif stage["dp_min"] >= stage["pdf"]:
             roof = roof_single
         else:

@@ -22,7 +22,7 @@ mkdir -p "$OUT"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py"
-B8="$BENCH --legs batchseq --graph 0 --inflight 1 --no-prewarm --warmup 2"          # only batch-of-8 chains (+ the one single-frame chain of the threshold pick)
+B8="$BENCH --legs batchseq --graph 0 --inflight 1 --no-prewarm --warmup 2"          # only launch chains of the benched batch size (bench.py's default) (+ the one single-frame chain of the threshold pick)
 B1="$BENCH --legs seq --graph 0 --inflight 1 --no-prewarm --warmup 2 --batch 1"      # only single-frame chains
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 reduce() {  # <dir> <out prefix>: per-(kernel, grid) stats + dp_min chains, then drop the big per-dispatch files
@@ -33,7 +33,7 @@ if has bench; then
   $BENCH --steps 300 > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
   $BENCH --steps 20 --warmup 5 > "$OUT/bench_n1_driverflags.json" 2>> "$OUT/bench_n1.err"
   $BENCH --steps 300 --inflight 4 --batch 1 --legs timed > "$OUT/bench_n1_b1.json" 2>> "$OUT/bench_n1.err"
-  python $REPO/tests/tools_batch_stages.py 1 2 4 8 > "$OUT/batch_stages.txt" 2>/dev/null
+  python $REPO/tests/tools_batch_stages.py 1 2 4 8 16 > "$OUT/batch_stages.txt" 2>/dev/null
 fi
 if has trace8; then
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace8" -o run -- $B8 > "$OUT/trace8.json" 2> "$OUT/trace8.err"

@@ -19,7 +19,7 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 HERE = os.path.dirname(os.path.abspath(__file__))
-BF = 8
+BF = 8      # frames per launch chain of the batch runs: read from the trace run's own bench line below (config.frames_per_batch)
 
 
 def short(name):
@@ -54,15 +54,26 @@ def last_json_line(path):
     return None
 
 
+_l = None
+for _f in ("trace8.json", "bench_n1_driverflags.json", "bench_n1.json"):
+    if os.path.exists(os.path.join(src, _f)):
+        for _ln in reversed(open(os.path.join(src, _f)).read().splitlines()):
+            if _ln.startswith("{"):
+                _l = json.loads(_ln); break
+    if _l:
+        break
+if _l and _l.get("config", {}).get("frames_per_batch"):
+    BF = int(_l["config"]["frames_per_batch"])
 md = [f"# {tag}: rocprofv3 evidence (MI355X, gfx950), collected by `profiles/collect_r05.sh {tag}`, summarised by `profiles/summarize_r05.py`.",
-      "bench.py = 26 x 6 person model, 640x480, batches of 8 frames.", ""]
-for name, what in (("batch8", "batches of 8 frames, one launch chain at a time, eager launches (bench.py --legs batchseq --graph 0 --inflight 1): the unit `roofline` is quoted on"),
+      f"bench.py = 26 x 6 person model, 640x480, batches of {BF} frames.", ""]
+for name, what in (("batch8", f"batches of {BF} frames, one launch chain at a time, eager launches (bench.py --legs batchseq --graph 0 --inflight 1): the unit `roofline` is quoted on"),
                    ("seq", "single frames, one at a time (bench.py --legs seq --batch 1 --graph 0 --inflight 1): `roofline_single_frame`"),
                    ("seq1080", "1920x1080 single frames, one at a time")):
     ks, cj = os.path.join(src, f"{name}_kernel_stats.csv"), os.path.join(src, f"{name}_chains.json")
     if not (os.path.exists(ks) and os.path.exists(cj)):
         continue
-    shutil.copy(ks, os.path.join(HERE, f"{tag}_kernel_stats_{name}.csv"))
+    oname = f"batch{BF}" if name == "batch8" else name            # (the collector's directory label stays "batch8"; the committed files carry the batch size)
+    shutil.copy(ks, os.path.join(HERE, f"{tag}_kernel_stats_{oname}.csv"))
     ch = json.load(open(cj))
     line = last_json_line(os.path.join(src, {"batch8": "trace8.json", "seq": "traceseq.json", "seq1080": "trace1080.json"}[name]))
     g = max(ch["groups"], key=lambda x: x["k_root_grid_threads"]) if ch["groups"] else None
@@ -72,7 +83,7 @@ for name, what in (("batch8", "batches of 8 frames, one launch chain at a time, 
         if line:
             ch["bench_line_of_this_run"] = {"roofline.launch_ms (HIP events, same process, under the profiler)": line["roofline"]["launch_ms"],
                                             "roofline.frac": line["roofline"]["frac"], "stage_ms_per_frame_batched": line.get("stage_ms_per_frame_batched")}
-    json.dump(ch, open(os.path.join(HERE, f"{tag}_chains_{name}.json"), "w"), indent=1)
+    json.dump(ch, open(os.path.join(HERE, f"{tag}_chains_{oname}.json"), "w"), indent=1)
     md += [f"## kernel trace: {what}", "| kernel | grid (threads) | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(ks)):
         if float(r["total_ms"]) < 0.02:
@@ -128,7 +139,7 @@ for r in counter_rows("sq8") + [r for r in counter_rows("sq8b") if r["Counter_Na
     a[0] += 1; a[1] += float(r["Counter_Value"])
 if sq:
     cs = sorted({c for k in sq for c in sq[k]})
-    md += ["## SQ counters per launch (one rocprofv3 --pmc pass, eight SQ counters; batches of 8, one chain at a time; *_CYCLES / ACTIVE / WAIT count quad-cycles summed over all waves)",
+    md += [f"## SQ counters per launch (one rocprofv3 --pmc pass, eight SQ counters; batches of {BF}, one chain at a time; *_CYCLES / ACTIVE / WAIT count quad-cycles summed over all waves)",
            "| kernel | grid | calls | " + " | ".join(c.replace("SQ_", "") for c in cs) + " | ACTIVE_INST_ANY / WAVE_CYCLES | LDS conflict cycles per LDS inst | active lanes per VALU inst (THREAD_CYCLES_VALU / ACTIVE_INST_VALU, of 64) |", "|---|---|---|" + "---|" * (len(cs) + 3)]
     tot_valu = {}
     for (k, g), v in sorted(sq.items()):

@@ -1444,9 +1444,10 @@ def test_detect_batch_person_model_640x480(gpu_required, orc):
     h.close()
 
 
-def test_benched_unit_batch8_mfma_graph_vs_oracle(gpu_required, orc):
-    """bench.py's unit of work held to the ORACLE: a batch of 8 person-model frames at 640x480 through
-    PBD_CONV_AUTO (-> the MFMA bank), graph replay, 3 repetitions; every frame of the batch against orc.detect
+def test_benched_unit_batch_graph_vs_oracle(gpu_required, orc):
+    """bench.py's unit of work held to the ORACLE: a batch of bench.py's DEFAULT size (read from bench.py: 16 since the end of
+    round 5, 8 before) of person-model frames at 640x480 through
+    PBD_CONV_AUTO (-> the split-product bank since round 5), graph replay, 3 repetitions; every frame of the batch against orc.detect
     (src/PartsBasedDetector.cpp:69-95) with every part-location difference classified (north_star: "argmax part locations
     exact, scores within 1e-4") — plus 8 further seeds frame by frame, so that the flip rate of the MFMA bank is a number
     with a denominator: printed, and asserted < 0.5 % of > 1 000 candidates.
@@ -1455,8 +1456,10 @@ def test_benched_unit_batch8_mfma_graph_vs_oracle(gpu_required, orc):
     distance transform, the message passing and the back-tracking are bit-exact and the flip comes from the <= 2e-5
     response perturbation alone: THIS is what carries the classification — and (ii) the two alternatives are a near-tie
     in the oracle's numbers (the bound grows with the subtree: each of its parts can move either alternative)."""
+    import re
+    NB = int(re.search(r'os\.environ\.get\("PBD_BATCH", "(\d+)"\)', open(os.path.join(ROOT, "bench.py")).read()).group(1))
     m = make_person_model()
-    frames8 = [make_image(10 + i, 640, 480) for i in range(8)]
+    frames8 = [make_image(10 + i, 640, 480) for i in range(NB)]
     singles = [make_image(100 + i, 640, 480) for i in range(8)]
 
     def pct999(frames):
@@ -1474,18 +1477,18 @@ def test_benched_unit_batch8_mfma_graph_vs_oracle(gpu_required, orc):
     p8, p1 = pct999(frames8), pct999(singles)
     cap = 16384
     m.thresh = min(p8)                                       # one threshold per handle: every frame of the batch has >= ~140 candidates
-    ha = capi.Handle(m, graph=1, max_candidates=8 * cap)     # PBD_CONV_AUTO, as in bench.py
+    ha = capi.Handle(m, graph=1, max_candidates=NB * cap)    # PBD_CONV_AUTO, as in bench.py
     for rep in range(3):
         outs8 = ha.detect_batch(frames8, capacity=cap)
     ha.close()
     tot_n = tot_flips = tot_ties = 0
     for idx, im in enumerate(frames8 + singles):
-        if idx >= 8:
-            m.thresh = p1[idx - 8]
+        if idx >= NB:
+            m.thresh = p1[idx - NB]
         hs = capi.Handle(m, max_candidates=cap)              # the same frame on its own: the batch must equal it bit for bit
         rh, rb, rl, _, fr = orc.detect(m, im, keep=True, capacity=cap)
         got = hs.detect(im, capacity=cap)
-        if idx < 8:
+        if idx < NB:
             assert_candidates_equal(outs8[idx], got)
             got = outs8[idx]
         n, flips, ties, bugs, worst = _classified_compare(orc, m, im, hs, got, (rh, rb, rl), fr)
@@ -1494,7 +1497,7 @@ def test_benched_unit_batch8_mfma_graph_vs_oracle(gpu_required, orc):
         assert not bugs, (idx, bugs)
         tot_n += n; tot_flips += flips; tot_ties += ties
     rate = tot_flips / max(tot_n, 1)
-    print(f"MFMA bank vs oracle, person 26x6 640x480, 8 frames of a graph-replayed batch + 8 single frames: {tot_n} common candidates, "
+    print(f"default bank vs oracle, person 26x6 640x480, {NB} frames of a graph-replayed batch + 8 single frames: {tot_n} common candidates, "
           f"{tot_flips} with different part locations = {100 * rate:.3f} % (all {tot_ties} classified near-ties, 0 bugs)")
     assert tot_n > 1000 and rate < 0.005, (tot_n, tot_flips)
 
@@ -1582,7 +1585,9 @@ def test_bench_lines_parse(gpu_required):
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-6000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["value"] is None and line["config"]["legs"] == ["batchseq"] and "cpu_baseline" not in line
-    assert line["roofline"]["units_per_launch"] == 8 and 0.05 < line["roofline"]["frac"] < 1.0
+    import re
+    nb = int(re.search(r'os\.environ\.get\("PBD_BATCH", "(\d+)"\)', open(os.path.join(root, "bench.py")).read()).group(1))     # bench.py's default batch
+    assert line["roofline"]["units_per_launch"] == nb and 0.05 < line["roofline"]["frac"] < 1.0
 
 
 def test_group_level_sharding_more_members_than_needed(gpu_required, orc):
