@@ -2130,7 +2130,7 @@ int pbd_get_work(const pbd_handle* h, double work[6]) {
   for (int l = 0; l < h->nlevels; ++l) {
     if (!h->lv[l].active) continue;
     C += (double)h->lv[l].cw * h->lv[l].ch;
-    pix += (double)h->lv[l].iw * h->lv[l].ih * h->fcn;
+    pix += (double)h->lv[l].iw * h->lv[l].ih * h->fcn * h->fesz;   // (bytes: pixels of the frame's own depth)
   }
   // reference element types (scores of type T: 4 or 8 bytes, int32 pointers)
   const double ts = h->ts;
