@@ -91,6 +91,22 @@ static void run_frame(const std::string& dir, const std::string& tag, Model& mod
   rec(tag + "_cand_boxes", 1, {(unsigned)boxes.size() / 4, 4u}, boxes.data(), boxes.size() * 4);
 }
 
+// HOGFeatures<T>::pyramid on an image of depth CV_16U / CV_32F / CV_64F (src/HOGFeatures.cpp:136-146): the feature pyramid pins the linked
+// OpenCV's cv::resize / cv::pyrDown of that depth and features<IT>
+template <typename T>
+static void run_wide(const std::string& dir, const std::string& tag, int w, int h, int cn, int depth, int sbin, int interval) {
+  const size_t esz = depth == CV_16U ? 2 : depth == CV_32F ? 4 : 8;
+  std::vector<unsigned char> px((size_t)w * h * cn * esz);
+  std::ifstream f((dir + "/image_" + tag + ".raw").c_str(), std::ios::binary);
+  f.read((char*)px.data(), px.size());
+  cv::Mat im(h, w, CV_MAKETYPE(depth, cn), px.data());
+  HOGFeatures<T> features(sbin, interval, 32, 18);
+  vectorMat pyramid;
+  features.pyramid(im, pyramid);
+  const std::string t = tag + (sizeof(T) == 4 ? "_f32" : "_f64");
+  for (size_t l = 0; l < pyramid.size(); ++l) rec_mat(idx((t + "_feat").c_str(), (int)l), pyramid[l]);
+}
+
 template <typename T>
 static void run_dt(const std::string& dir, int i) {
   // dt_<i>.bin: i32 rows, cols, osx, osy | f64 ax, bx, ay, by | f32 rows*cols
@@ -115,7 +131,7 @@ int main(int argc, char** argv) {
   if (!g_out) return 2;
   const std::string ver = PBD_OPENCV_VERSION;
   rec("opencv_version", 0, {(unsigned)ver.size()}, ver.data(), ver.size());
-  // manifest.txt: lines "frame <tag> <model file> <w> <h> <cn>" and "dt <count>"
+  // manifest.txt: lines "frame <tag> <model file> <w> <h> <cn>", "wide <tag> <w> <h> <cn> <cv depth>" and "dt <count>"
   std::ifstream mf((dir + "/manifest.txt").c_str());
   std::string kind;
   while (mf >> kind) {
@@ -124,6 +140,10 @@ int main(int argc, char** argv) {
       mf >> tag >> mfile >> w >> h >> cn;
       { FileStorageModel model; if (!model.deserialize(dir + "/" + mfile)) { fprintf(stderr, "cannot read %s\n", mfile.c_str()); return 3; } run_frame<float>(dir, tag + "_f32", model, w, h, cn); }
       { FileStorageModel model; model.deserialize(dir + "/" + mfile); run_frame<double>(dir, tag + "_f64", model, w, h, cn); }
+    } else if (kind == "wide") {
+      std::string tag; int w, h, cn, depth;
+      mf >> tag >> w >> h >> cn >> depth;
+      run_wide<float>(dir, tag, w, h, cn, depth, 4, 10); run_wide<double>(dir, tag, w, h, cn, depth, 4, 10);   // cell size 4, 10 levels per octave (make_tree_model's defaults: tests/test_reference_pins.py)
     } else if (kind == "dt") {
       int n; mf >> n;
       for (int i = 0; i < n; ++i) { run_dt<float>(dir, i); run_dt<double>(dir, i); }

@@ -311,3 +311,19 @@ def make_image(seed: int, w: int, h: int, cn: int = 3) -> np.ndarray:
     if cn == 1:
         out = np.ascontiguousarray(out[..., 1])
     return np.ascontiguousarray(out)
+
+
+def make_wide_image(kind, seed: int, w: int, h: int, cn: int = 3) -> np.ndarray:
+    """A test image of one of the other depths the reference accepts (src/HOGFeatures.cpp:136-146) whose values USE the depth's range (not
+    an 8-bit image in a wider container): np.uint16 -> the full 16 bits; np.float32 -> [0, 1] floats; np.float64 -> doubles incl. negative ones."""
+    rng = np.random.default_rng(seed)
+    base = make_image(seed, w, h, cn)
+    kind = np.dtype(kind)
+    if kind == np.uint16:
+        return (base.astype(np.uint16) * 257) ^ rng.integers(0, 256, base.shape, dtype=np.uint16)
+    noise = rng.uniform(-0.5, 0.5, base.shape)
+    if kind == np.float32:
+        return ((base + noise) / 255.0).astype(np.float32)
+    if kind == np.float64:
+        return (base + noise).astype(np.float64) * 3.0 - 100.0
+    raise ValueError("make_wide_image: uint16, float32 or float64")

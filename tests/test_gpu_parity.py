@@ -1825,15 +1825,8 @@ def test_fuzz_split_bank_one_seed(gpu_required):
 
 # ---------------------------------------------------------------- image depths beyond 8 bits (pbd_detect_image)
 def _wide_image(kind, seed, w, h, cn=3):
-    """an image of the given depth whose values use the depth's range (not an 8-bit image in a wider container)"""
-    rng = np.random.default_rng(seed)
-    base = make_image(seed, w, h, cn)
-    if kind == np.uint16:
-        return (base.astype(np.uint16) * 257) ^ rng.integers(0, 256, base.shape, dtype=np.uint16)
-    noise = rng.uniform(-0.5, 0.5, base.shape)
-    if kind == np.float32:
-        return ((base + noise) / 255.0).astype(np.float32)          # [0, 1] floats
-    return (base + noise).astype(np.float64) * 3.0 - 100.0          # doubles, negative values included
+    from partsbaseddetector_amd.model import make_wide_image
+    return make_wide_image(kind, seed, w, h, cn)
 
 
 @pytest.mark.parametrize("kind", [np.uint16, np.float32, np.float64])

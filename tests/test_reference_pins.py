@@ -55,6 +55,26 @@ def test_frame_stages_match_the_reference(orc, pins, tag, dtype, sfx):
     frame.free()
 
 
+@pytest.mark.parametrize("tag,kind,shape,seed", [("w16u", np.uint16, (150, 110, 3), 10), ("w32f", np.float32, (97, 131, 1), 11), ("w64f", np.float64, (203, 77, 3), 12)])
+@pytest.mark.parametrize("dtype,sfx", [(np.float32, "f32"), (np.float64, "f64")])
+def test_wide_depth_feature_pyramids_match_the_reference(orc, pins, tag, kind, shape, seed, dtype, sfx):
+    """CV_16U / CV_32F / CV_64F images (src/HOGFeatures.cpp:136-146): pins cv::resize / cv::pyrDown of those depths (the restatement follows
+    OpenCV 2.4's scalar loops: a build whose pyrDown takes the SSE row pass may differ in the last bit for float images — then THIS is where it
+    shows) and features<IT>"""
+    from partsbaseddetector_amd.model import make_tree_model, make_wide_image
+    if f"{tag}_{sfx}_feat_0" not in pins:
+        pytest.skip("pins file predates the wide-depth frames")
+    w, h, cn = shape
+    im = make_wide_image(kind, seed, w, h, cn)
+    m = make_tree_model([-1, 0], 1, seed=1)                      # sbin 4, interval 10 (what dump_reference.cpp's run_wide passes): only the pyramid is compared
+    assert (m.sbin, m.interval) == (4, 10)
+    m.thresh = 3e38
+    _, _, _, _, frame = orc.detect(m, im, capacity=1, keep=True, dtype=dtype)
+    for l in range(frame.nlevels):
+        np.testing.assert_array_equal(pins[f"{tag}_{sfx}_feat_{l}"].ravel(), frame.feat(l).ravel())
+    frame.free()
+
+
 @pytest.mark.parametrize("dtype,sfx", [(np.float32, "f32"), (np.float64, "f64")])
 def test_distance_transform_matches_the_reference(orc, pins, dtype, sfx):
     rng = np.random.default_rng(20260927)
