@@ -53,6 +53,10 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PREWARM_S = 1.5       # fixed wall time every rank spends running frames before --warmup / the timed region
+# Version of the JSON line's keys.  1 = rounds 1-4 (a step = one batch of 8 on one handle).  2 = round 5 (a step = one batch on EACH of the S
+# handles in flight, default batch 16: `frames_per_step_per_gpu`, `ms_per_step` changed meaning; `frame_ms` = per-batch completion pacing).
+# 3 = round 6: `frame_ms` renamed `batch_completion_ms` (it never was a frame latency), `child_legs` reports how the child-process legs ended.
+BENCH_SCHEMA = 3
 
 
 def pick_threshold(capi, model, d_img, w, h, q=99.9, dtype=np.float32):
@@ -366,39 +370,44 @@ def main():
     # (a SEPARATE process: fresh handles created beside the timed ones in this process stalled for tens of ms at a time — r05 session 2 —,
     #  and a second process repeats the protocol exactly: pre-warm, warm-up, K steps.  This process's handles are idle meanwhile.)
     value_mfma32, steps_mfma32 = None, min(args.steps, 100)
-    if "mfma32" in legs and world == 1 and conv_resolved == capi.PBD_CONV_SPLIT:
+    child_status = {}     # leg -> how its child process ended (a failed child is reported, not a silent null)
+
+    def run_child(leg, conv_name, legs_arg):
+        """the same protocol in a second process with another filter bank; returns its JSON line or None, and records the exit"""
         import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps_mfma32), "--warmup", str(args.warmup), "--conv", "mfma",
-               "--legs", "timed", "--inflight", str(S), "--batch", str(B), "--width", str(W), "--height", str(H), "--mixtures", str(args.mixtures),
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps_mfma32), "--warmup", str(args.warmup), "--conv", conv_name,
+               "--legs", legs_arg, "--inflight", str(S), "--batch", str(B), "--width", str(W), "--height", str(H), "--mixtures", str(args.mixtures),
                "--dtype", args.dtype, "--graph", str(args.graph)]
         torch.cuda.synchronize()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-            sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode == 0 and sub:
-                value_mfma32 = json.loads(sub[-1])["value"]
-        except (subprocess.TimeoutExpired, ValueError, KeyError):
-            value_mfma32 = None
+        except subprocess.TimeoutExpired:
+            child_status[leg] = {"returncode": None, "error": "timeout after 300 s"}
+            return None
+        sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        child_status[leg] = {"returncode": r.returncode}
+        if r.returncode != 0 or not sub:
+            child_status[leg]["stderr_tail"] = r.stderr[-400:]
+            return None
+        try:
+            return json.loads(sub[-1])
+        except ValueError as e:
+            child_status[leg]["error"] = f"unparsable line: {e}"
+            return None
+
+    if "mfma32" in legs and world == 1 and conv_resolved == capi.PBD_CONV_SPLIT:
+        j = run_child("mfma32", "mfma", "timed")
+        value_mfma32 = j.get("value") if j else None
     # ---- and with the opt-in binary16 bank (PBD_CONV_SPLIT_F16: half the matrix instructions; NOT the benched path) ----
     split16 = None
     if "split16" in legs and world == 1 and conv_resolved == capi.PBD_CONV_SPLIT:
-        import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps_mfma32), "--warmup", str(args.warmup), "--conv", "split16",
-               "--legs", "timed,batchseq", "--inflight", str(S), "--batch", str(B), "--width", str(W), "--height", str(H), "--mixtures", str(args.mixtures),
-               "--dtype", args.dtype, "--graph", str(args.graph)]
-        torch.cuda.synchronize()
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-            sub = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode == 0 and sub:
-                j = json.loads(sub[-1])
-                split16 = {"value": j["value"], "unit": "frames/s", "steps": steps_mfma32, "pdf_ms_per_frame_batched": j.get("pdf", {}).get("ms_per_frame_batched"),
-                           "pdf_fp32_equivalent_TFLOP/s": j.get("pdf", {}).get("TFLOP/s_batched"), "dp_min_ms_per_batch": j.get("roofline", {}).get("launch_ms"),
-                           "what": "`bench.py --conv split16 --legs timed,batchseq` as a child process: PBD_CONV_SPLIT_F16, the OPT-IN bank of two scaled binary16 "
-                                   "parts per operand and three products (include/pbd_c.h; errors against fp64 measured equal to the benched bank's, operands carried "
-                                   "to 23 of their 24 bits) — reported beside `value`, never as it"}
-        except (subprocess.TimeoutExpired, ValueError, KeyError):
-            split16 = None
+        j = run_child("split16", "split16", "timed,batchseq")
+        if j:
+            split16 = {"value": j.get("value"), "unit": "frames/s", "steps": steps_mfma32, "pdf_ms_per_frame_batched": j.get("pdf", {}).get("ms_per_frame_batched"),
+                       "pdf_fp32_equivalent_TFLOP/s": j.get("pdf", {}).get("TFLOP/s_batched"), "dp_min_ms_per_batch": j.get("roofline", {}).get("launch_ms"),
+                       "what": "`bench.py --conv split16 --legs timed,batchseq` as a child process: PBD_CONV_SPLIT_F16, the OPT-IN bank of two scaled binary16 "
+                               "parts per operand and three products (include/pbd_c.h; errors against fp64 measured equal to the benched bank's, operands carried "
+                               "to 23 of their 24 bits) — reported beside `value`, never as it"}
     if world > 1:
         ncand_all = sum(len(g[0]) for g in gathered_last[0]) if (rank == 0 and gathered_last[0]) else 0   # the last step's gather (inside the timed region)
     else:
@@ -558,8 +567,9 @@ def main():
             "value": rnd(value), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": rnd(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if by_levels else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "schema": BENCH_SCHEMA,
             "config": config,
-            "frame_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),
+            "batch_completion_ms": {"median": pct(per_frame_ms, 50), "p10": pct(per_frame_ms, 10), "p90": pct(per_frame_ms, 90),
                          "what": f"completion-to-completion wall time per BATCH in the timed loop (rank 0): completions of the {S} batches in flight "
                                  f"arrive in bursts — throughput pacing, not latency (latency: `sequential`)"},
             "value_resident": rnd(value), "value_incl_h2d": rnd(value_h2d),
@@ -567,11 +577,12 @@ def main():
             "value_fp32_mfma_is": (f"`value` of `bench.py --conv mfma --legs timed --steps {steps_mfma32}` (PBD_CONV_MFMA: the fp32 v_mfma_f32_16x16x4_f32 bank, the default of "
                                    f"rounds 3-4), run as a child process after this process's timed legs" if value_mfma32 else None),
             "opt_in_split_f16": split16,
+            "child_legs": child_status or None,
             "value_single_frame_calls": (round(args.steps * B * S / dt_single, 3) if dt_single else None),
             "value_is": "frames resident in HBM when the timed region starts (the tier's contract, DESIGN.md 7); value_incl_h2d = the same steps "
                         "from pinned host images; value_single_frame_calls = ONE GPU's handles fed one frame per call",
             "incl_h2d": {"value": rnd(value_h2d), "unit": "frames/s", "ms_per_step": rnd(dt_h2d / args.steps * 1e3 if dt_h2d else None, 4),
-                         "frame_ms": {"median": pct(per_frame_ms_h2d, 50), "p10": pct(per_frame_ms_h2d, 10), "p90": pct(per_frame_ms_h2d, 90)},
+                         "batch_completion_ms": {"median": pct(per_frame_ms_h2d, 50), "p10": pct(per_frame_ms_h2d, 10), "p90": pct(per_frame_ms_h2d, 90)},
                          "what": "the same K steps with every frame handed over as a pinned host image (pbd_detect_[batch_]enqueue_u8: "
                                  "H2D + kernels + D2H of the candidates per step)"},
             "sequential": {"latency_ms": ({"median": pct(seq_ms_graph, 50), "p10": pct(seq_ms_graph, 10), "p90": pct(seq_ms_graph, 90)} if seq_ms_graph else None),

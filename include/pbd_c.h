@@ -91,7 +91,10 @@ enum {
                          three-way splits (x = h + m + l, three bfloat16 of 8 significant bits; the six partial products above
                          2^-24 relative on v_mfma_f32_32x32x16_bf16, fp32 accumulators): fp32 in, fp32 out, errors of the size of
                          PBD_CONV_MFMA's, on hardware the vector ALU does not share.  Weights must be finite
-                         and below 3e38 in magnitude (bfloat16's range)                                          */
+                         and below 3e38 in magnitude (bfloat16's range) — checked by pbd_create —, and so must features
+                         handed in through pbd_set_level_features (HOG features are <= 0.4): an out-of-domain or non-finite
+                         feature is refused there with PBD_ERR_ARG (PBD_CONV_MFMA / PBD_CONV_EXACT carry such values as
+                         ordinary fp32)                                                                          */
   PBD_CONV_SPLIT_F16 = 4 /* opt-in, never what AUTO resolves to.  float handles: TWO binary16 parts per operand (11 significant
                          bits each, operands scaled by powers of two into binary16's range: features by 2^12, a bank's weights to
                          max |w| 2^e in [2^13, 2^14)) and the THREE products above 2^-22 relative on v_mfma_f32_32x32x16_f16, fp32
@@ -282,6 +285,8 @@ int pbd_get_level_image(pbd_handle* h, int level, uint8_t* out /* img_h*img_w*cn
 int pbd_pyramid_image(pbd_handle* h, const void* im, int depth, int w, int hgt, int cn, int stride);
 int pbd_get_level_image_raw(pbd_handle* h, int level, void* out, size_t out_bytes);
 int pbd_get_level_features(pbd_handle* h, int level, float* out /* cell_h*cell_w*flen */);
+/* (a handle on a split-product bank refuses features outside the bank's domain — PBD_CONV_SPLIT: finite, |f| < 3e38;
+ *  PBD_CONV_SPLIT_F16: |f| < 16 — with PBD_ERR_ARG; nothing is uploaded then)                                          */
 int pbd_set_level_features(pbd_handle* h, int level, const float* in);
 int pbd_get_level_features_f64(pbd_handle* h, int level, double* out);
 int pbd_set_level_features_f64(pbd_handle* h, int level, const double* in);
@@ -370,7 +375,9 @@ int pbd_get_footprint(const pbd_handle* h, size_t* frame_bytes, size_t* model_by
  * 256 lanes / 40 KB against 128 lanes / 25 KB per block; results are bit-identical under either): `batch` copies of the host image
  * per call (1 = single frames, the reference's call shape; > 1 = pbd_detect_batch_u8), 2 warm-up + 3 timed calls per geometry, the
  * dp_min stage's GPU time.  The faster one is kept for every later plan of this handle; *chosen = 1 / 2 (0: nothing to choose —
- * double handles), ms[0..1] = the two medians.  im == NULL: back to the rule.  Synchronous; costs ten calls.                   */
+ * double handles), ms[0..1] = the two medians.  im == NULL: back to the rule.  Synchronous; costs ten calls.  The handle's plan is
+ * dropped on return (as after pbd_set_levels): stage getters answer PBD_ERR_STATE until the next frame; pbd_get_stage_ms keeps the
+ * caller's last figures.  Refused (PBD_ERR_STATE) on a member of an RCCL-gathering pbd_group and while a frame is pending.          */
 int pbd_tune_plan(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, int batch, int* chosen, double ms[2]);
 /* average GPU ms of the DP-min kernels alone over frames since the last reset
  * (HIP events on the handle's stream around the DP stage)                    */

@@ -183,8 +183,8 @@ DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const dou
 // have been stitched: speculation.  What a stitch reads from the left is correct as long as it stays strictly
 // above the element F that the left neighbour's own stitch finally leaves as its lowest survivor — entries above
 // F have their final z and links from the local scan — so the stitch reports `dmin`, the lowest element below
-// s0 it tested, and the validation pass (dt_stitch_validate) redoes, in order, the few stitches that went
-// deeper.  Outputs: f = lowest element of the segment left on the stack, patched to its global z / link (the
+// s0 it tested, and the validation rounds redo, in order, the few stitches that went
+// deeper (rounds: dt_stitch_stale / dt_stitch_redo).  Outputs: f = lowest element of the segment left on the stack, patched to its global z / link (the
 // local values are returned in zsave / bsave so that a redo can restore them).  Returns true if the invariant
 // was lost or a quotient was suspect (the caller redoes the whole line sequentially).
 template <bool EXACT, typename T, typename IT>
@@ -246,35 +246,31 @@ DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const doub
   return bad || DT_SUSPECT_MINE(suspect);
 }
 
-// Validation of the speculative stitches of one line, left to right (one lane per line).  The only elements whose
-// (z, link) ever change after the local scans are the F of each segment: patched by its speculative stitch, and —
-// if that stitch is redone here — un-patched again and a (possibly different) F patched instead.  A speculative
-// stitch p read elements >= DMIN[p] only, so what it read was final iff DMIN[p] lies strictly above BOTH the F its
-// left neighbour's speculative stitch patched (F_spec[p-1]: the patch may have been written, by another wavefront,
-// while p was reading) and the F the neighbour finally has (F_new[p-1]); the F of segments further left are lower
-// still.  Otherwise p is redone now, with everything to its left final (boundary 1 is always valid: segment 0's
-// local scan IS the global run).  F / DMIN / ZSAVE / BSAVE: per-segment tables (stride tstride).
+// Validation of the speculative stitches, in ROUNDS, every boundary by its own lane (round 6; rounds 2-5: one lane per line walked
+// its P boundaries in order while the block waited — 2 us of a 21 us block on average, 10-18 us in the slowest blocks).
+// The only elements whose (z, link) ever change after the local scans are the F of each segment: patched by its speculative
+// stitch, and — if that stitch is redone — un-patched again and a (possibly different) F patched instead.  A speculative
+// stitch p read elements >= DMIN[p] only, so what it read was final iff DMIN[p] lies strictly above BOTH the F its left
+// neighbour's speculative stitch patched (F_spec[p-1]: the patch may have been written, by another wavefront, while p was
+// reading) and the F the neighbour finally has (F_new[p-1]); the F of segments further left are lower still.  Boundary 1 is
+// always valid (segment 0's local scan IS the global run).
+//   round: every lane p >= 2 evaluates dt_stitch_stale() with the F its left neighbour has NOW; the LOWEST stale boundary of
+//   a line has only valid — by induction final — boundaries to its left, so its own lane redoes it at once (un-patch, stitch
+//   again: dt_stitch_redo), after which it is final; boundaries to its right are judged again in the next round (the one next
+//   to it against a new F_new).  Lines proceed independently; a block's rounds end when no lane is stale (typically after the
+//   first evaluation: one barrier).
+DT_HD bool dt_stitch_stale(int dmin_p, int fspec_prev, int fnew_prev) {
+  return dmin_p <= (fspec_prev > fnew_prev ? fspec_prev : fnew_prev);
+}
+// the redo of boundary [s0, s1) with everything to its left final: fo / zsave / bsave = the speculative stitch's F and its local
+// (z, link); returns dt_stitch1's flag, the final F in f_out (patched; its local values in zsave / bsave again)
 template <bool EXACT, typename T, typename IT>
-DT_HD bool dt_stitch_validate(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a,
-                              const int* __restrict__ seg, int P, double a, double b, IT* __restrict__ F,
-                              const IT* __restrict__ DMIN, const T* __restrict__ ZSAVE, const IT* __restrict__ BSAVE, int tstride) {
-  bool bad = false;
-  F[0] = (IT)0;
-  int fspec_prev = P > 1 ? (int)F[tstride] : 0;     // F_spec[p - 1]
-  for (int p = 2; p < P; ++p) {
-    const int fnew_prev = (int)F[(p - 1) * tstride];
-    const int fo = (int)F[p * tstride];
-    const int lim = fspec_prev > fnew_prev ? fspec_prev : fnew_prev;
-    fspec_prev = fo;
-    if ((int)DMIN[p * tstride] > lim) continue;
-    YZ[fo].y = ZSAVE[p * tstride];           // undo the speculative patch, then stitch again
-    B[fo] = BSAVE[p * tstride];
-    int f, dmin, bs;
-    T zs;
-    bad |= dt_stitch1<EXACT, T, IT>(YZ, B, RDX, i2a, seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
-    F[p * tstride] = (IT)f;
-  }
-  return bad;
+DT_HD bool dt_stitch_redo(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a, int s0, int s1,
+                          double a, double b, int fo, int& f_out, T& zsave, int& bsave) {
+  YZ[fo].y = zsave;                          // undo the speculative patch, then stitch again
+  B[fo] = (IT)bsave;
+  int dmin;
+  return dt_stitch1<EXACT, T, IT>(YZ, B, RDX, i2a, s0, s1, a, b, f_out, dmin, zsave, bsave);
 }
 
 // After the stitches every segment p has F[p], its lowest element left on the stack when the run finished the

@@ -193,8 +193,11 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   constexpr bool EX = sizeof(T) == 8;          // DistanceTransform<double>: s is not narrowed, every intersection takes the IEEE division
   const T** lptr = (const T**)smem;            // [lpb] source pointer of each line of this block (plain)
   int* FLAG = (int*)(smem + lpb * 8);          // [lpb] per line: redo sequentially (suspect quotient / lost stitch invariant)
-  int* FIX = FLAG + lpb;                       // [lpb] per line: a speculative stitch has to be redone
+  int* FIX = FLAG + lpb;                       // [lpb] per line: the lowest stale boundary of the line in an even validation round
+  int* FIX2 = (int*)smem;                      // [lpb] ... in an odd round (the line-pointer table is dead after the loader)
   int* SEG = FIX + lpb;                        // [P + 1 <= 65] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
+  int* ANY = SEG + DT_SEGS - 6;                // [2] a line has a stale stitch (even / odd validation round)
+  int* NFLAG = SEG + DT_SEGS - 4;              // [1] a line of the block is flagged for the sequential redo
   T* ZLO = (T*)(SEG + DT_SEGS);                // [NT] per lane (p * lpb + line): z of the segment's lowest surviving element
   T* ZSAVE = ZLO + NT;                         // [NT] per lane: that element's local z (before the stitch patched it)
   IT* FT = (IT*)(ZSAVE + NT);                  // [NT] per lane: that element
@@ -221,12 +224,12 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       lptr[lane] = (const T*)mp0.src + (size_t)li * len;
     }
     FLAG[lane] = 0;
-    FIX[lane] = 0;
   }
+  if (lane < lpb) FIX[lane] = 0x7fffffff;
   const int nsub = g.nsub;                       // lanes per line
   const int P = g.P;                             // segments per line (dt_segments(nsub, len))
   if (lane <= P) SEG[lane] = P > 1 ? (int)__umulhi((unsigned)__mul24(lane, len), g.magic_P) : lane * len;   // dt_seg_start(lane, P, len)
-  if (lane == 0) { SEG[DT_SEGS - 2] = 0; SEG[DT_SEGS - 1] = len; }
+  if (lane == 0) { SEG[DT_SEGS - 2] = 0; SEG[DT_SEGS - 1] = len; ANY[0] = 0; *NFLAG = 0; }
   const int p = lpb > 1 ? (int)__umulhi((unsigned)lane, g.magic_lpb) : lane, line = lane - __mul24(p, lpb);
   const bool mine = line < nl && p < nsub;
   // line -> (map, line of the map): plain: map-major; FOLD: mixture-major inside the block's rows
@@ -337,7 +340,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 
   // ---- local scans: the envelope of every segment (DistanceTransform.hpp:156-170 on the segment alone) ----
   if (mine && p < P) {
-    if (dt_seg_scan<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b)) FLAG[line] = 1;
+    if (dt_seg_scan<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b)) { FLAG[line] = 1; *NFLAG = 1; }
   }
   __syncthreads();
   DT_STAMP(3);
@@ -347,41 +350,68 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     T zs;
     const bool bad = dt_stitch1<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b, f, dmin, zs, bs);
     FT[lane] = (IT)f; DMIN[lane] = (IT)dmin; ZSAVE[lane] = zs; BSAVE[lane] = (IT)bs;
-    if (bad) FLAG[line] = 1;
+    if (bad) { FLAG[line] = 1; *NFLAG = 1; }
   }
+  if (mine && p == 0) FT[lane] = (IT)0;
   __syncthreads();
-  // ---- validate the speculation: a stitch is final iff everything it tested below its segment lies strictly
-  // above the lowest element its left neighbour's stitch left (dt_core.hpp); every lane checks its own, and
-  // publishes what the read-out needs to know about its segment ----
-  if (mine && p < P && !FLAG[line]) {
-    const int f = p ? (int)FT[lane] : 0;
-    if (p >= 2 && (int)DMIN[lane] <= (int)FT[lane - lpb]) FIX[line] = 1;
-    if (!p) FT[lane] = (IT)0;
-    BELOW[lane] = Bl[f];
-    ZLO[lane] = YZl[f].y;
-  }
-  __syncthreads();
-  DT_STAMP(6);
-  // the few lines with a stitch to redo (in order, everything to the left final), a suspect quotient or a lost
-  // invariant (the whole line sequentially, IEEE divisions): one lane per line
-  if (mine && p == 0 && (FLAG[line] | FIX[line])) {
-    bool redo = FLAG[line] != 0;
-    if (!redo) redo = dt_stitch_validate<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG, P, mp.a, mp.b, FT + line, DMIN + line, ZSAVE + line, BSAVE + line, lpb);
-    if (redo) {
-      DT_COUNT_REDO();
-      dt_seg_scan<true, T, IT>(YZl, Bl, RDX, mp.r2a, 0, len, mp.a, mp.b);
-      FLAG[line] = 1;                            // the read-out takes the line as one segment
-      BELOW[line] = Bl[0];
-      ZLO[line] = YZl[0].y;
-    } else {
-      for (int pp = 1; pp < P; ++pp) {
-        const int f = (int)FT[pp * lpb + line];
-        BELOW[pp * lpb + line] = Bl[f];
-        ZLO[pp * lpb + line] = YZl[f].y;
+  // ---- validate the speculation (dt_core.hpp): a stitch is final iff everything it tested below its segment lies strictly
+  // above the lowest element its left neighbour's stitch left; every lane judges its own and publishes what the read-out needs
+  // to know about its segment.  Usually no lane is stale and that is all.  Else: rounds — the LOWEST stale boundary of a line
+  // (everything to its left is final) is redone, the others are judged again against their neighbour's new F.  The redo is
+  // done by the line's FIRST lane (p = 0: the block's first wavefront or two): the stale boundaries of different lines sit in
+  // different wavefronts, and every wavefront that holds one would run the whole stitch loop for one live lane.
+  // FIX / FIX2 [line] = lowest stale boundary of the line in an even / odd round, ANY[parity] = some line has one.
+  {
+    const bool cand = mine && p >= 2 && p < P;
+    const bool live = mine && p < P && !FLAG[line];
+    const int fspec_prev = cand ? (int)FT[lane - lpb] : 0;       // F_spec[p - 1]: what the neighbour's SPECULATIVE stitch patched
+    if (cand && live && dt_stitch_stale((int)DMIN[lane], fspec_prev, fspec_prev)) { atomicMin(&FIX[line], p); ANY[0] = 1; }
+    if (live) {
+      const int f = (int)FT[lane];
+      BELOW[lane] = Bl[f];
+      ZLO[lane] = YZl[f].y;
+    }
+    __syncthreads();
+    DT_STAMP(6);
+    if (ANY[0]) {                                  // (block-uniform; rare)
+      for (int round = 0;; ++round) {
+        int* FIXr = (round & 1) ? FIX2 : FIX;
+        int* FIXn = (round & 1) ? FIX : FIX2;
+        if (mine && p == 0 && FIXr[line] != 0x7fffffff) {
+          const int ps = FIXr[line], ls = __mul24(ps, lpb) + line;
+          int f, bs = (int)BSAVE[ls];
+          T zs = ZSAVE[ls];
+          const bool bad = dt_stitch_redo<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[ps], SEG[ps + 1], mp.a, mp.b, (int)FT[ls], f, zs, bs);
+          FT[ls] = (IT)f; ZSAVE[ls] = zs; BSAVE[ls] = (IT)bs;
+          DMIN[ls] = (IT)SEG[ps];                  // final: never stale again (every F to its left lies below its segment)
+          if (bad) { FLAG[line] = 1; *NFLAG = 1; }
+        }
+        if (lane < lpb) FIXn[lane] = 0x7fffffff;   // the next round's tables (last read a round ago)
+        if (lane == 0) ANY[(round + 1) & 1] = 0;
+        __syncthreads();
+        if (cand && !FLAG[line] && dt_stitch_stale((int)DMIN[lane], fspec_prev, (int)FT[lane - lpb])) { atomicMin(&FIXn[line], p); ANY[(round + 1) & 1] = 1; }
+        __syncthreads();
+        if (!ANY[(round + 1) & 1]) break;
       }
+      if (mine && p < P && !FLAG[line]) {          // the segments' entries once more (a redo moves F)
+        const int f = (int)FT[lane];
+        BELOW[lane] = Bl[f];
+        ZLO[lane] = YZl[f].y;
+      }
+      __syncthreads();
     }
   }
-  __syncthreads();
+  // the rare line with a suspect quotient or a lost invariant is redone as a whole by one lane (IEEE divisions) and read out
+  // as one segment (NFLAG: lines flagged in this block)
+  if (*NFLAG) {                                    // (block-uniform)
+    if (mine && p == 0 && FLAG[line]) {
+      DT_COUNT_REDO();
+      dt_seg_scan<true, T, IT>(YZl, Bl, RDX, mp.r2a, 0, len, mp.a, mp.b);
+      BELOW[line] = Bl[0];
+      ZLO[line] = YZl[0].y;
+    }
+    __syncthreads();
+  }
   DT_STAMP(4);
 
   // ---- read out (:172-178) ----

@@ -1256,6 +1256,8 @@ static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
   h->have_pyr = h->have_feat = h->have_resp = !h->compact;
   compact_mark_feat(h, false);
   compact_mark_resp(h, false);
+  // k_hog's epilogue has rewritten the features' split copy; a compact plan's copy shares the x pass's pointer planes and is dead again
+  h->feat_split_ok = h->split_parts != 0 && !h->compact;
   h->have_dp = true;
   h->min_ran = true;
   h->ext_ptr = false;
@@ -1530,9 +1532,16 @@ int pbd_detect_batch_u8(pbd_handle* h, const uint8_t* const* ims, int nframes, i
 int pbd_tune_plan(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int stride, int batch, int* chosen, double ms[2]) {
   if (!h) return PBD_ERR_ARG;
   if (h->pending) return fail(h, PBD_ERR_STATE, "previous frame not collected");
+  // (a member of an RCCL-gathering group collects through the group only: the measurement's own collect() would fail with the frame
+  //  left pending — ADVICE r05)
+  if (h->d_gsend) return fail(h, PBD_ERR_STATE, "handle belongs to an RCCL-gathering pbd_group: tune a handle of its own");
   if (chosen) *chosen = 0;
   if (ms) ms[0] = ms[1] = 0.0;
-  if (!im) { h->dt_geom = 0; h->fw = 0; return PBD_OK; }
+  ON_DEVICE(h);
+  // the plan is dropped as a whole (buffers, stage flags, captured graph): a stage getter after pbd_tune_plan answers "no frame
+  // geometry" AND the stage flags say so — nothing can run on the last measured geometry
+  auto drop_plan = [&]() { if (h->stream) hipStreamSynchronize(h->stream); h->pending = false; free_frame(h); };
+  if (!im) { h->dt_geom = 0; drop_plan(); return PBD_OK; }
   if (h->ts != 4) return PBD_OK;
   if (batch < 1 || batch > 64) return fail(h, PBD_ERR_ARG, "batch: 1..64 frames");
   const int cap = h->opt.max_candidates;            // per frame (pbd_detect_batch_collect: heads[batch][capacity])
@@ -1541,11 +1550,13 @@ int pbd_tune_plan(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int 
   std::vector<const uint8_t*> ims((size_t)batch, im);
   const bool prof = h->profiling;
   const int before = h->dt_geom;
+  float stage_before[6];
+  for (int i = 0; i < 6; ++i) stage_before[i] = h->stage_ms[i];
   double t[2] = {0, 0};
   int rc = PBD_OK;
   h->profiling = true;
   for (int g = 1; g <= 2 && !rc; ++g) {
-    h->dt_geom = g; h->fw = 0;                      // (plan_frame re-plans: the key no longer matches)
+    h->dt_geom = g; drop_plan();                    // (plan_frame re-plans under the geometry)
     double v[3] = {0, 0, 0};
     for (int i = 0; i < 5 && !rc; ++i) {
       rc = batch == 1 ? pbd_detect_u8(h, im, w, hgt, cn, stride, heads.data(), nullptr, nullptr, cap, counts.data())
@@ -1557,9 +1568,11 @@ int pbd_tune_plan(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int 
     t[g - 1] = v[1];
   }
   h->profiling = prof;
-  if (rc) { h->dt_geom = before; h->fw = 0; return rc; }
-  h->dt_geom = t[0] <= t[1] ? 1 : 2;
-  h->fw = 0;
+  for (int i = 0; i < 6; ++i) h->stage_ms[i] = stage_before[i];   // the caller's last stage times, not the measurement's
+  const std::string err = h->err;
+  h->dt_geom = rc ? before : (t[0] <= t[1] ? 1 : 2);
+  drop_plan();                                      // whatever happened: nothing in flight, no plan of the measurement's call shape left behind
+  if (rc) { h->err = err; return rc; }
   if (chosen) *chosen = h->dt_geom;
   if (ms) { ms[0] = t[0]; ms[1] = t[1]; }
   return PBD_OK;
@@ -1654,6 +1667,19 @@ static int set_level_features_(pbd_handle* h, int level, const void* in, int ts)
   CHECK_LEVEL(h, level);
   CHECK_SCALAR(h, ts);
   const Level& L = h->lv[level];
+  if (!in) return fail(h, PBD_ERR_ARG, "null feature matrix");
+  // The split-product banks carry a feature as bfloat16 / binary16 parts: a value outside the parts' finite range would become inf / NaN parts
+  // and poison every response the MFMA sums it into, where the EXACT / MFMA banks propagate it as ordinary fp32.  HOG features
+  // are in [0, 0.4]; a caller's own features are held to the bank's domain here, on the host copy that is being uploaded anyway.
+  if (ts == 4 && (h->conv_mode == PBD_CONV_SPLIT || h->conv_mode == PBD_CONV_SPLIT_F16)) {
+    const float lim = h->conv_mode == PBD_CONV_SPLIT_F16 ? 16.0f : 3.0e38f;
+    const float* f = (const float*)in;
+    const size_t nf = (size_t)L.cw * L.ch * PBD_FLEN;
+    for (size_t i = 0; i < nf; ++i)
+      if (!(std::fabs(f[i]) < lim))
+        return fail(h, PBD_ERR_ARG, h->conv_mode == PBD_CONV_SPLIT_F16 ? "PBD_CONV_SPLIT_F16: a feature outside the bank's domain (|f| < 16, finite)"
+                                                                        : "PBD_CONV_SPLIT: a feature outside bfloat16's finite range (|f| < 3e38, finite): use PBD_CONV_MFMA / PBD_CONV_EXACT");
+  }
   ON_DEVICE(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->d_feat + L.cell_off * PBD_FLEN * ts, in, (size_t)L.cw * L.ch * PBD_FLEN * ts, hipMemcpyHostToDevice));

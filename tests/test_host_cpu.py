@@ -261,8 +261,9 @@ def test_batch_chain_trace_matches_the_bench_defaults():
 def test_bench_line_schema_fields():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "schema", "batch_completion_ms", "child_legs"):
         assert f'"{key}"' in src
+    assert '"frame_ms"' not in src        # schema 3: the per-batch completion pacing is no longer called a frame time
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):

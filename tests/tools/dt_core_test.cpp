@@ -16,7 +16,7 @@ extern "C" void orc_dt1d_f64(const double* src, double* dst, int32_t* ptr, int N
 static void ref1d(const float* s, float* d, int32_t* p, int n, double a, double b, int os) { orc_dt1d(s, d, p, n, a, b, os); }
 static void ref1d(const double* s, double* d, int32_t* p, int n, double a, double b, int os) { orc_dt1d_f64(s, d, p, n, a, b, os); }
 
-struct Stats { long lines = 0, suspect = 0, inconsistent = 0, events = 0; };
+struct Stats { long lines = 0, suspect = 0, inconsistent = 0, events = 0, redos = 0; };
 
 // one line exactly as k_dt_pass processes it: `lanes` lanes per line
 template <typename T, typename IT>
@@ -53,12 +53,26 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
       bad |= dt_stitch1<EX, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
       F[p] = (IT)f; DM[p] = (IT)dmin; ZS[p] = zs; BS[p] = (IT)bs;
     }
-    bool fix = false;                // every lane checks its own stitch (k_dt_pass); only then the sequential fix-up
-    for (int p = 2; p < P; ++p) if ((int)DM[p] <= (int)F[p - 1]) fix = true;
-    if (fix) {
-      st.events++;
-      bad |= dt_stitch_validate<EX, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg.data(), P, a, b, F.data(), DM.data(), ZS.data(), BS.data(), 1);
+    // the validation rounds of k_dt_pass: every lane p >= 2 judges its own stitch against the F its left neighbour's speculative stitch
+    // patched (remembered before any redo) and the F the neighbour has now; the lowest stale boundary is redone by its own lane
+    std::vector<int> fspec(P, 0);
+    for (int p = 2; p < P; ++p) fspec[p] = (int)F[p - 1];
+    F[0] = 0;
+    bool any = false;
+    for (int round = 0; round <= P; ++round) {
+      int lowest = -1;
+      for (int p = 2; p < P && lowest < 0; ++p)
+        if (dt_stitch_stale((int)DM[p], fspec[p], (int)F[p - 1])) lowest = p;
+      if (lowest < 0) break;
+      if (round == P) { fprintf(stderr, "validation rounds do not terminate\n"); exit(2); }
+      any = true;
+      int f, bs = (int)BS[lowest];
+      T zs = ZS[lowest];
+      bad |= dt_stitch_redo<EX, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[lowest], seg[lowest + 1], a, b, (int)F[lowest], f, zs, bs);
+      F[lowest] = (IT)f; ZS[lowest] = zs; BS[lowest] = (IT)bs; DM[lowest] = (IT)seg[lowest];
+      st.redos++;
     }
+    if (any) st.events++;
     if (bad) st.inconsistent++;
     flag |= bad;
   }
@@ -131,7 +145,7 @@ static int sweep(long nlines, unsigned seed) {
       }
   }
   printf("T=%s: %ld lines bit-identical to the sequential reference (%ld redone for a suspect quotient, %ld for a lost stitch invariant; "
-         "%ld lines had a speculative stitch re-done)\n", sizeof(T) == 4 ? "float" : "double", st.lines, st.suspect, st.inconsistent, st.events);
+         "%ld lines had a speculative stitch re-done, %ld redos)\n", sizeof(T) == 4 ? "float" : "double", st.lines, st.suspect, st.inconsistent, st.events, st.redos);
   return 0;
 }
 
