@@ -151,7 +151,10 @@ typedef struct pbd_options {
 int pbd_abi_version(void);
 /* Version history: 3 = rounds 3-4.  4 (round 5) = PBD_CONV_AUTO resolves to PBD_CONV_SPLIT for float handles (numerics of
  * AUTO change in the last bits: rounds 3-4 resolved to PBD_CONV_MFMA, and before that to EXACT for banks other than 5 x 5),
- * PBD_CONV_SPLIT, PBD_CONV_SPLIT_F16, pbd_detect_image / pbd_pyramid_image / pbd_get_level_image_raw (PBD_DEPTH_*), pbd_tune_plan, pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state, pbd_group_comm_size.  Struct layouts unchanged.   */
+ * PBD_CONV_SPLIT, PBD_CONV_SPLIT_F16, pbd_detect_image / pbd_pyramid_image / pbd_get_level_image_raw (PBD_DEPTH_*), pbd_tune_plan, pbd_options.reserved[0] = nms_sz, pbd_get_conv_mode, pbd_get_stage_state, pbd_group_comm_size.  Struct layouts unchanged.
+ * Round 6 keeps version 4 (no entry point, layout or result changed); refinements of existing entries: pbd_set_level_features refuses
+ * features outside a split bank's domain (PBD_ERR_ARG), pbd_tune_plan drops the handle's plan on return, pbd_detect_image replays a
+ * hipGraph under pbd_options.graph.                                                                                             */
 
 /* ---- output record: include/Candidate.hpp:56-111 --------------------------
  * One candidate = head + max_parts boxes (x, y, width, height as cv::Rect)
@@ -202,8 +205,10 @@ int pbd_detect_u8(pbd_handle* h, const uint8_t* im, int w, int hgt, int cn, int 
  * cv::resize interpolating in floating point with float coefficients, cv::pyrDown as FltCast<T, 8> (ushort: the
  * integer form), restated from OpenCV 2.4 like the 8-bit pair and equally unpinned (no reference test holds any
  * pyramid value) —, gradients in the pixel type's promoted arithmetic, everything from the histograms on unchanged.
- * Single frames, eager launches; PBD_DEPTH_8U forwards to pbd_detect_u8.  Any other depth: PBD_ERR_UNSUPPORTED, the
- * counterpart of CV_Error(StsUnsupportedFormat) (:141-145).                                                       */
+ * Single host frames (replayed as a hipGraph under pbd_options.graph like 8-bit plans, round 6); batches, device-resident entry points
+ * and groups stay 8-bit — by design: no caller of the reference hands over anything else, and every further entry point is a surface
+ * to test against an oracle that is itself unpinned for these depths.  PBD_DEPTH_8U forwards to pbd_detect_u8.  Any other depth:
+ * PBD_ERR_UNSUPPORTED, the counterpart of CV_Error(StsUnsupportedFormat) (:141-145).                               */
 int pbd_detect_image(pbd_handle* h, const void* im, int depth, int w, int hgt, int cn, int stride,
                      pbd_candidate_head* heads, int32_t* boxes, int32_t* locs, int capacity, int* count);
 /* same, image already resident in device memory (tightly packed or strided)  */

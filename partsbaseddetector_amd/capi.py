@@ -452,13 +452,13 @@ class Group:
     """pbd_group: one process driving several GPUs (include/pbd_c.h).  devices may repeat an ordinal."""
 
     def __init__(self, model, devices, gather=PBD_GATHER_AUTO, conv_mode=PBD_CONV_AUTO, max_candidates=4096,
-                 dtype=np.float32, graph=0):
+                 dtype=np.float32, graph=0, nms_sz=0):
         self.L = lib()
         self.model = model
         self.desc = model.to_desc()
         f64 = np.dtype(dtype) == np.dtype(np.float64)
         opt = pbd_options(0, conv_mode, max_candidates, 0, 0, 0, PBD_SCALAR_F64 if f64 else PBD_SCALAR_F32, graph,
-                          (C.c_int32 * 2)(0, 0))
+                          (C.c_int32 * 2)(int(nms_sz), 0))
         dv = np.ascontiguousarray(list(devices), np.int32)
         self.g = C.c_void_p()
         rc = self.L.pbd_group_create(C.byref(self.desc), C.byref(opt), _p(dv, C.c_int32), len(dv), gather, C.byref(self.g))

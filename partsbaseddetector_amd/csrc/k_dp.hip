@@ -216,8 +216,11 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const int q = g.nlines > 1 ? (int)__umulhi((unsigned)x, g.magic_nlines) : x;
     mi = t.m0 + q; li = x - __mul24(q, g.nlines);
   };
+  // plain: a block whose lines lie back to back in memory (DtTask::src0: the y pass always, plan_frame) loads them as ONE run — no line
+  // pointers, hence no map descriptor in front of the loads (a dependent memory round trip of ~1 us) and no barrier in front of the loader
+  const bool contig = !FOLD && t.src0 != nullptr;   // (block-uniform)
   if (lane < nl) {
-    if (!FOLD) {
+    if (!FOLD && !contig) {
       int mi, li;
       map_line(lane, mi, li);
       const DtMap& mp0 = maps[g.map0 + mi];
@@ -249,7 +252,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   P2* YZl = YZ + line * S;
   IT* Bl = B + line * S;
   if (mine) mp = maps[g.map0 + mi];
-  if (!FOLD) __syncthreads();
+  if (!FOLD && !contig) __syncthreads();
   DT_STAMP(1);
   if constexpr (FOLD) {
     // ---- fold loader: U (row, element) cells per lane and step, all mixtures of the part at once; the loads of the U
@@ -309,27 +312,34 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     if (len > 1) {
       // f / len = umulhi(f, magic), magic = ceil(2^32 / len): exact for f * len < 2^32
       const unsigned magic = 0xFFFFFFFFu / (unsigned)len + 1u;
-      for (int f0 = 0; f0 < n; f0 += LB * NT) {
-        T r[LB];
-        int la[LB];
+      auto load_lines = [&](auto run) {             // run: the block's elements are one contiguous run at t.src0
+        constexpr bool RUN = decltype(run)::value;
+        GP(T) s0 = (GP(T))t.src0;
+        for (int f0 = 0; f0 < n; f0 += LB * NT) {
+          T r[LB];
+          int la[LB];
 #pragma unroll
-        for (int j = 0; j < LB; ++j) {
-          const int f = min(f0 + j * NT + lane, n - 1);
-          const int i = (int)__umulhi((unsigned)f, magic);
-          const unsigned pos = (unsigned)(f - __mul24(i, len));
-          r[j] = ((GP(T))lptr[i])[pos];
-          la[j] = __mul24(i, S) + (int)pos;
-        }
-        // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
-        if constexpr (!EX) {
-          if (f0 == 0)
-            for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
-        }
-        // (unpredicated: a lane past the block's last element holds that element's value again — its load address was
-        // clamped — and stores it once more; a predicate per element made hipcc emit 24 nested exec-mask regions)
+          for (int j = 0; j < LB; ++j) {
+            const int f = min(f0 + j * NT + lane, n - 1);
+            const int i = (int)__umulhi((unsigned)f, magic);
+            const unsigned pos = (unsigned)(f - __mul24(i, len));
+            if constexpr (RUN) r[j] = s0[f];
+            else r[j] = ((GP(T))lptr[i])[pos];
+            la[j] = __mul24(i, S) + (int)pos;
+          }
+          // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
+          if constexpr (!EX) {
+            if (f0 == 0)
+              for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
+          }
+          // (unpredicated: a lane past the block's last element holds that element's value again — its load address was
+          // clamped — and stores it once more; a predicate per element made hipcc emit 24 nested exec-mask regions)
 #pragma unroll
-        for (int j = 0; j < LB; ++j) YZ[la[j]].x = r[j];
-      }
+          for (int j = 0; j < LB; ++j) YZ[la[j]].x = r[j];
+        }
+      };
+      if (contig) load_lines(std::true_type{});
+      else load_lines(std::false_type{});
     } else {   // lines of ONE element (a 1-wide level, or pbd_dt2d on a vector): element f is line f
       for (int f = lane; f < n; f += NT) YZ[f * S].x = ((GP(T))lptr[f])[0];
       if constexpr (!EX) { if (lane == 0) RDX[0] = 0.0; }

@@ -455,13 +455,25 @@ static DtGroup dt_group(int map0, int nmaps, int nlines, int len, size_t budget,
   g.magic_P = dt_magic((unsigned)g.P);
   return g;
 }
-static void dt_add_tasks(const DtGroup& g, std::vector<DtTask>& out) {
+// maps: the descriptor table the group indexes (plain groups: a block whose lines are contiguous in memory gets their address, DtTask::src0)
+static void dt_add_tasks(const DtGroup& g, std::vector<DtTask>& out, const std::vector<DtMap>* maps = nullptr, int ts = 4) {
   if (g.fold >= 0) {
     const int R = g.lpb / g.nmaps;
-    for (int r0 = 0; r0 < g.nlines; r0 += R) out.push_back(DtTask{r0, std::min(R, g.nlines - r0) * g.nmaps, 0, r0, g});
+    for (int r0 = 0; r0 < g.nlines; r0 += R) out.push_back(DtTask{r0, std::min(R, g.nlines - r0) * g.nmaps, 0, r0, g, nullptr});
   } else {
     const int total = g.nmaps * g.nlines;
-    for (int g0 = 0; g0 < total; g0 += g.lpb) out.push_back(DtTask{g0, std::min(g.lpb, total - g0), g0 / g.nlines, g0 % g.nlines, g});
+    const size_t map_bytes = (size_t)g.nlines * g.len * ts;
+    for (int g0 = 0; g0 < total; g0 += g.lpb) {
+      DtTask t{g0, std::min(g.lpb, total - g0), g0 / g.nlines, g0 % g.nlines, g, nullptr};
+      if (maps && g.len > 1) {
+        const int mlast = (g0 + t.nl - 1) / g.nlines;
+        bool contig = true;
+        for (int m = t.m0; m < mlast && contig; ++m)
+          contig = (const char*)(*maps)[(size_t)g.map0 + m + 1].src == (const char*)(*maps)[(size_t)g.map0 + m].src + map_bytes;
+        if (contig) t.src0 = (const char*)(*maps)[(size_t)g.map0 + t.m0].src + (size_t)t.l0 * g.len * ts;
+      }
+      out.push_back(t);
+    }
   }
 }
 static DtMap dt_map(const void* src, void* dst, int16_t* ptr, float wq, float wl, int os, int natural) {
@@ -830,14 +842,15 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1, int 
       const int gx_map0 = (int)maps.size();
       int gx_nmaps = 0;
       std::vector<DtMap> ymaps;
-      size_t tmp_round = 0;   // fold: offset of the part's block in the round's x-pass output
+      size_t tmp_round = 0;   // fold: maps of this level in front of the part's, in the round's x-pass output (level-major: all maps of a
+                              // level back to back, so that every block of the y pass reads ONE contiguous run — DtTask::src0)
       for (int fp : rnd) {
         const PartInfo& P = h->parts[fp];
         const int part_map0 = (int)maps.size();
         for (int mm = 0; mm < P.K; ++mm) {
           const int fid = P.filterid[mm], did = P.defid[mm];
           const size_t so = scr_of(fp, l, mm);
-          const size_t to = fold ? tmp_round + (size_t)P.K * lvl_scr[l] + (size_t)mm * HW : so;
+          const size_t to = fold ? roundK[r] * lvl_scr[l] + (tmp_round + (size_t)mm) * HW : so;
           const char* src = (!fold && slot_init[P.slot[mm]]) ? h->d_acc + (L.cell_off * h->nslots + (size_t)P.slot[mm] * HW) * ts
                                                             : resp_plane(l, fid);
           const float* wv = &h->defw[(size_t)did * 4];
@@ -845,13 +858,13 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1, int 
           ymaps.push_back(dt_map(h->d_dt_tmpT + to * ts, sdt_plane(fp, l, mm), h->d_dt_iy + so, wv[2], wv[3], h->anchors[did * 2 + 1], 0));
           gx_nmaps++;
         }
-        tmp_round += (size_t)P.K * act_cells;
+        tmp_round += (size_t)P.K;
         if (fold_x) dt_add_tasks(dt_group(part_map0, P.K, L.ch, L.cw, budget_x, h->ts, h->dt_nt_x, h->dt_seg, make_fold(fp, l)), xt);
       }
-      if (!fold_x) dt_add_tasks(dt_group(gx_map0, gx_nmaps, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg, -1, geox.round), xt);
+      if (!fold_x) dt_add_tasks(dt_group(gx_map0, gx_nmaps, L.ch, L.cw, budget_x, h->ts, h->dt_nt, h->dt_seg, -1, geox.round), xt, &maps, h->ts);
       const DtGroup gy = dt_group((int)maps.size(), gx_nmaps, L.cw, L.ch, budget, h->ts, h->dt_nt, h->dt_seg, -1, geoy.round);
       for (auto& my : ymaps) maps.push_back(my);
-      dt_add_tasks(gy, yt);
+      dt_add_tasks(gy, yt, &maps, h->ts);
       if (dbg_plan)
         fprintf(stderr, "plan: round %zu level %d  x: len %d lines %d maps %d lpb %d  y: len %d lines %d lpb %d  (budget %zu)\n", r, l,
                 L.cw, L.ch, gx_nmaps, xt.empty() ? 0 : xt.back().g.lpb, gy.len, gy.nlines, gy.lpb, budget);
@@ -1230,12 +1243,12 @@ static int enqueue_stages(pbd_handle* h, const uint8_t* d_src, int stride) {
 // an image that lives elsewhere in HBM is copied there first (0.9 MB, on the same stream).  Profiling runs (stage
 // events) and level groups on extra streams use the eager path.
 static int enqueue_all(pbd_handle* h, const uint8_t* d_src, int stride) {
-  const bool graphable = h->opt.graph && !h->profiling && h->fdepth == PBD_DEPTH_8U;
+  const bool graphable = h->opt.graph && !h->profiling;   // (frames of any depth: the launches depend on the plan only; round 5 replayed 8-bit plans only)
   if (!graphable || h->frames_on_plan == 0) {
     h->frames_on_plan++;
     return enqueue_stages(h, d_src, stride);
   }
-  const size_t row = (size_t)h->fw * h->fcn;
+  const size_t row = (size_t)h->fw * h->fcn * h->fesz;
   if (d_src != h->d_img) {
     if ((size_t)stride == row) HIPCHK(h, hipMemcpyAsync(h->d_img, d_src, row * h->fh * h->batch, hipMemcpyDeviceToDevice, h->stream));
     else HIPCHK(h, hipMemcpy2DAsync(h->d_img, row, d_src, stride, row, h->fh, hipMemcpyDeviceToDevice, h->stream));   // (strided sources: single frames only)

@@ -73,8 +73,10 @@ struct DtGroup {
   unsigned magic_P;          // (p * len) / P           (p * len < 2^21, P <= 64)
   int pad;
 };
-struct DtTask { int g0, nl, m0, l0; DtGroup g; };   // g0: first line (plain) / first row (fold); nl: lines of this block; plain: g0 = m0 * nlines + l0
+struct DtTask { int g0, nl, m0, l0; DtGroup g;     // g0: first line (plain) / first row (fold); nl: lines of this block; plain: g0 = m0 * nlines + l0
                                                     // (first map of the block, first line inside it); the group travels with the task
+  const void* src0; };                              // plain: the block's first line when its nl lines are CONTIGUOUS in memory (consecutive maps of a group
+                                                    // back to back — the y pass's input always, plan_frame), else null: the loader then needs no map descriptor
 static inline unsigned dt_magic(unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }   // d == 1: the quotient is the numerator itself (callers test)
 #ifndef PBD_DT_NT_DEFAULT
 #define PBD_DT_NT_DEFAULT 128   // lanes of a k_dt_pass block

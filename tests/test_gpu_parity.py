@@ -1234,7 +1234,8 @@ def test_detect_7x7_filters_mfma_classified(gpu_required, orc):
 
 # ---------------------------------------------------------------- the timed configuration, classified
 def _classified_compare(orc, model, im, hd, got, ref, fr, dtype=np.float32, tol=1e-4):
-    """MFMA filter bank vs the oracle on one frame.  Root scores within `tol`; candidates on one side only sit on the
+    """A tolerance filter bank (fp32 MFMA, or the split-product bank PBD_CONV_AUTO resolves float handles to since round 5) vs the oracle on
+    one frame.  Root scores within `tol`; candidates on one side only sit on the
     threshold; every common candidate whose part locations differ is CLASSIFIED:
       * DP-consistent: the oracle's DP (tests/dp_ref.py over orc.dt2d) run on the GPU's own responses back-tracks to
         exactly the GPU's locations — the distance transform / reduce / back-tracking are bit-exact, so the flip
@@ -1289,7 +1290,8 @@ def _classified_compare(orc, model, im, hd, got, ref, fr, dtype=np.float32, tol=
 
 def test_detect_person_timed_configuration_classified(gpu_required, orc):
     """The configuration bench.py times (BASELINE configs[1]): 26 parts x 6 mixtures, 640x480, PBD_CONV_AUTO ->
-    k_conv_mfma16<float>, against orc.detect (src/PartsBasedDetector.cpp:69-95) with every mismatch classified."""
+    the split-product bank (k_conv_split32: six exact bfloat16 partial products per fp32 product; rounds 3-4: k_conv_mfma16<float>),
+    against orc.detect (src/PartsBasedDetector.cpp:69-95) with every mismatch classified."""
     m = make_person_model()
     for seed in (0, 3):
         im = make_image(seed, 640, 480)
@@ -1308,7 +1310,8 @@ def test_detect_person_timed_configuration_classified(gpu_required, orc):
 @pytest.mark.parametrize("K", [8, 12])
 def test_config5_large_mixture_640x480_vs_oracle(gpu_required, orc, K):
     """BASELINE configs[4]: large-mixture person model (26 x 8 = 208 and 26 x 12 = 312 filters) at 640x480 against the
-    oracle: the exact filter bank bit for bit, the MFMA filter bank (what PBD_CONV_AUTO selects) classified."""
+    oracle: the exact filter bank bit for bit, the split-product bank (what PBD_CONV_AUTO selects for float handles: n-tile groups of
+    five + a remainder instantiation) classified."""
     m = make_person_model(K=K)
     im = make_image(1, 640, 480)
     m.thresh = thresh_from_oracle(orc, m, im, 99.9)
@@ -1317,7 +1320,8 @@ def test_config5_large_mixture_640x480_vs_oracle(gpu_required, orc, K):
     he = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT)
     assert_candidates_equal(he.detect(im), (rh, rb, rl))
     he.close()
-    hm = capi.Handle(m)                                      # AUTO -> MFMA for N x K this size
+    hm = capi.Handle(m)                                      # AUTO -> the split-product bank (round 5)
+    assert hm.conv_mode == capi.PBD_CONV_SPLIT
     got = hm.detect(im)
     n, flips, ties, bugs, worst = _classified_compare(orc, m, im, hm, got, (rh, rb, rl), fr)
     hm.close(); fr.free()
@@ -1768,6 +1772,66 @@ def test_argmin_with_device_nms_matches_filtered_oracle(gpu_required, orc, sz):
     h.close()
 
 
+def test_device_nms_person_model_default_bank_and_group(gpu_required, orc):
+    """The device NMS (pbd_options.reserved[0]) on the BENCHED configuration — 26 x 6 person model, 640x480, the default (split-product)
+    bank — single frames, a batch under graph replay, and through pbd_group_detect_batch_u8.  Two checks:
+      * exactly: the candidates are the same handle configuration's unfiltered candidates whose root is a local maximum of
+        orc.nms_map on the GPU's OWN root plane (pbd_get_root: same bank, same bits);
+      * against the oracle filtered by orc.nms_map on the ORACLE's plane, classified: a candidate on one side only either sits on the
+        threshold or has a rival within 2e-4 in its (2 sz + 1)^2 neighbourhood (the tolerance bank moves root scores by <= 1e-4, which
+        can move a strict local maximum between near-equal neighbours)."""
+    sz = 2
+    m = make_person_model()
+    ims = [make_image(s, 640, 480) for s in (0, 3, 5, 6)]
+    m.thresh = thresh_from_oracle(orc, m, ims[0], 99.5)
+    key = lambda r, i: (int(r[0][i]["level"]), int(r[0][i]["component"]), int(r[2][i][0][0]), int(r[2][i][0][1]))
+    plain = capi.Handle(m)
+    assert plain.conv_mode == capi.PBD_CONV_SPLIT
+    expected = []
+    onesided = rivals = 0
+    for im in ims:
+        allc = plain.detect(im, capacity=16384)
+        plain._geo = plain.geometry(640, 480)
+        planes = {l: plain.root(l, 0)[0] for l in range(plain._geo["nlevels"])}
+        masks = {l: orc.nms_map(np.ascontiguousarray(v, np.float32), sz) for l, v in planes.items() if v.size}
+        keep = np.array([masks[int(r["level"])][int(loc[0][1]), int(loc[0][0])] != 0 for r, loc in zip(allc[0], allc[2])], bool)
+        assert 0 < keep.sum() < len(keep)
+        expected.append((allc[0][keep], allc[1][keep], allc[2][keep]))
+        # the oracle's filtered set, classified against the GPU's
+        rh, rb, rl, _, fr = orc.detect(m, im, capacity=16384, keep=True)
+        omask = {l: orc.nms_map(np.ascontiguousarray(fr.root(l)[0][0], np.float32), sz) for l in range(fr.nlevels) if fr.root(l)[0][0].size}
+        okeep = np.array([omask[int(r["level"])][int(loc[0][1]), int(loc[0][0])] != 0 for r, loc in zip(rh, rl)], bool)
+        oref = (rh[okeep], rb[okeep], rl[okeep])
+        gk = {key(expected[-1], i) for i in range(len(expected[-1][0]))}
+        ok = {key(oref, i) for i in range(len(oref[0]))}
+        assert len(gk & ok) >= 0.9 * len(ok) > 10
+        for (l, c, x, y) in gk ^ ok:
+            onesided += 1
+            pl = planes[l]
+            v = float(pl[y, x])
+            if abs(v - m.thresh) < 1e-4:
+                continue
+            nb = pl[max(0, y - sz):y + sz + 1, max(0, x - sz):x + sz + 1].astype(np.float64).copy()
+            nb[min(y, sz), min(x, sz)] = -np.inf
+            assert nb.max() > v - 2e-4, ("a local maximum on one side only without a near-equal rival", (l, c, x, y), v, float(nb.max()))
+            rivals += 1
+        fr.free()
+    plain.close()
+    print(f"device NMS sz {sz}, person 26x6 640x480, split bank: {sum(len(e[0]) for e in expected)} kept; against the filtered oracle {onesided} one-sided "
+          f"({rivals} with a near-equal rival, the rest on the threshold)")
+    for graph in (0, 1):
+        h = capi.Handle(m, nms_sz=sz, graph=graph, max_candidates=16384)
+        for im, ref in zip(ims, expected):
+            assert_candidates_equal(h.detect(im, capacity=16384), ref)
+        for got, ref in zip(h.detect_batch(ims, capacity=16384), expected):
+            assert_candidates_equal(got, ref)
+        h.close()
+    g = capi.Group(m, [0, 0], nms_sz=sz, max_candidates=16384)
+    for got, ref in zip(g.detect_batch(ims, capacity=16384), expected):
+        assert_candidates_equal(got, ref)
+    g.close()
+
+
 def test_config1_face_like_320x240_interval10(gpu_required, orc):
     """configs[0] at the shape SURVEY 8(d) states (C1: interval = 10 -> 36 levels, ~33 k cells; the r01-r04 case above runs the model
     file's interval = 5): exact bank bit for bit, the default bank classified."""
@@ -1785,16 +1849,17 @@ def test_config1_face_like_320x240_interval10(gpu_required, orc):
 
 
 def test_person_1080p_full_model_candidates_classified(gpu_required, orc):
-    """configs[3] geometry with the FULL 26 x 6 model and the default filter bank: the candidates (not only the root scores) of four
-    levels incl. level 0 against the oracle, every location difference classified."""
+    """configs[3] geometry with the FULL 26 x 6 model and the default filter bank: the candidates (not only the root scores) of eight
+    levels incl. levels 0 and 1 (lines of 478 / 268 and 446 / 250 elements: 16-bit links) against the oracle, every location difference
+    classified."""
     m = make_person_model()
     im = make_image(0, 1920, 1080)
     m.thresh = thresh_from_oracle(orc, m, im, 99.97)
     rh, rb, rl, _, fr = orc.detect(m, im, capacity=65536, keep=True)
-    levels = [0, 9, 21, 40]
+    levels = [0, 1, 5, 9, 14, 21, 30, 40]
     sel = np.isin(rh["level"], levels)
     ref = (rh[sel], rb[sel], rl[sel])
-    assert len(ref[0]) > 40 and (ref[0]["level"] == 0).sum() > 10
+    assert len(ref[0]) > 80 and (ref[0]["level"] == 0).sum() > 10 and (ref[0]["level"] == 1).sum() > 10
     h = capi.Handle(m, max_candidates=65536)
     h.set_levels(levels)
     got = h.detect(im, capacity=65536)
@@ -1882,6 +1947,22 @@ def test_detect_image_wide_depths_vs_oracle(gpu_required, orc, kind):
     common = set(ka) & set(kb)
     assert len(common) >= 0.95 * max(len(ka), len(kb)) and len(common) > 20        # (threshold straddlers may differ)
     assert max(abs(ka[k] - kb[k]) for k in common) < 1e-4
+    h.close()
+
+
+@pytest.mark.parametrize("kind", [np.uint16, np.float32, np.float64])
+def test_detect_image_wide_depths_graph_replay(gpu_required, orc, kind):
+    """Frames of depth CV_16U / 32F / 64F under pbd_options.graph (round 6: round 5 replayed 8-bit plans only): the first frame of a plan
+    runs eagerly, the second is captured, the third is a replay — three DIFFERENT frames, each the oracle's candidates bit for bit."""
+    m = make_tree_model([-1, 0, 1, 1, 0], 3, seed=5)
+    ims = [_wide_image(kind, 30 + i, 200, 150) for i in range(3)]
+    m.thresh = thresh_from_oracle(orc, m, ims[0], 98.0)
+    h = capi.Handle(m, conv_mode=capi.PBD_CONV_EXACT, graph=1)
+    for im in ims:
+        got = h.detect_image(im, capacity=4096)
+        ref = orc.detect(m, im, capacity=4096)[:3]
+        assert len(ref[0]) > 5
+        assert_candidates_equal(got, ref)
     h.close()
 
 
