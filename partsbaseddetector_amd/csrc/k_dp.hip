@@ -96,7 +96,7 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // than the plain one.  Everything below is branch-free except the loop over the children.
 template <typename T, int M, int U>
 __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ /*biasw*/, const unsigned (&off)[U],
-                                              unsigned HW, int L, T (&acc)[U][M]) {
+                                              unsigned HW, int L, T (&acc)[U][M], unsigned live = ~0u) {
   const int nch = J->nch;
   unsigned ob[U];                                        // byte offsets of the cells inside a plane of T (< 2^32, plan_frame)
 #pragma unroll
@@ -142,6 +142,10 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
     const bool copy1 = C.K == 1;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      // (live: bit u = some lane of this WAVEFRONT holds a cell of its own in slot u.  A block's cells rarely fill the last slot — 632
+      // cells on 3 x 256 lanes: the slot's upper wavefronts hold clamped repeats only and skip the 36 add / compare / select pairs; the
+      // loads above stay unconditional)
+      if (U > 1 && !(live & (1u << u))) continue;
       T v[M];
       int bi[M];
       T w0[M];
@@ -289,11 +293,19 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         if (e0 == 0)
           for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
-      fold_children<T, M, U>(J, biasw, off, HW, L, acc);
+      unsigned live = 0;                                             // wave-uniform: slot u holds a cell of its own in this wavefront's first lane
+      {
+        const int wave0 = __builtin_amdgcn_readfirstlane(lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) live |= (e0 + u * NT + wave0 < n) ? (1u << u) : 0u;
+      }
+      fold_children<T, M, U>(J, biasw, off, HW, L, acc, live);
       const int mstride = nrows * S;                                 // LDS elements between the lines of consecutive mixtures of a row
-      // (unpredicated like the plain loader: a lane past the last cell holds the last cell's values and stores them once more)
+      // (unpredicated like the plain loader: a lane past the last cell holds the last cell's values and stores them once more; a whole
+      // wavefront past it — `live` — stores nothing: its accumulators were not folded)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        if (!(live & (1u << u))) continue;
 #pragma unroll
         for (int m = 0; m < M; ++m)      // (columns beyond L repeat mixture L - 1: the same value stored to its slot once more, no branch)
           YZ[min(m, L - 1) * mstride + slot[u]].x = acc[u][m];

@@ -70,7 +70,10 @@ struct HogLds {
   int MG;        // raw-tile margin before the window (source clamping can reach back sbin/2 pixels)
   int RT;        // raw tile side (pixels)
   int RP;        // raw tile row pitch in bytes (multiple of 4: rows are staged with 4-byte loads)
-  int MP;        // (|g|, bin) plane row pitch in elements (odd multiple... see hog_lds_layout)
+  int QS;        // (|g|, bin) planes: a row holds its pixels de-interleaved by the cell size — pixel wx at (wx % sbin) * QS + wx / sbin — so
+                 // that the histogram walk's lanes (one block each: sbin pixels apart) read CONSECUTIVE words instead of words sbin apart
+                 // (4-way bank conflicts on every read with 4-pixel cells; round 6)
+  int MP;        // (|g|, bin) plane row pitch in elements = sbin * QS >= PT
   size_t mag_off, bin_off, hist_off, norm_off, ninv_off, tab_off, raw_off, out_off, total;
 };
 
@@ -85,7 +88,8 @@ __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int bpp, int 
   L.MG = sbin / 2 + 2;
   L.RT = L.PT + L.MG + 1;
   L.RP = (bpp & 7) ? (L.RT * bpp + 3) & ~3 : (L.RT * bpp + 7) & ~7;   // (8-byte pixels elements: rows stay 8-byte aligned)
-  L.MP = L.PT;
+  L.QS = (L.PT + sbin - 1) / sbin;
+  L.MP = L.QS * sbin;
   size_t o = 0;
   // (|g|, bin) per window pixel are dead once the histograms are complete: the block energies, the normalisers and the
   // staging area of the finished features (half a tile of cells at a time) are written over them (barriers separate the phases)
@@ -258,8 +262,9 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
       m = t_sqrt((T)vi);
       }
     }
-    mag[wy * L.MP + wx] = m;
-    bin[wy * L.MP + wx] = (uint8_t)b;
+    const int wq = wx / sbin, pi = wy * L.MP + (wx - wq * sbin) * L.QS + wq;   // de-interleaved by the cell size (HogLds::QS)
+    mag[pi] = m;
+    bin[pi] = (uint8_t)b;
   }
   __syncthreads();                                       // every thread is done with the staged pixels ...
   for (int i = tid; i < NB * NB * PBD_NORIENT; i += HOG_NT) hist[i] = (T)0;   // ... whose LDS the histograms take over
@@ -272,7 +277,11 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
     const int lby = bl / NB, lbx = bl - lby * NB;
     const int by = t.cy0 + lby, bx = t.cx0 + lbx;
     if (by >= bh || bx >= bw) continue;
-    T* hb = hist + bl * PBD_NORIENT;
+    // hist is BIN-major — bin o of block bl at hist[o * NB * NB + bl] (rounds 1-5: [bl][18], whose 18-word pitch put lanes l and l + 16
+    // on one bank whatever their bins): with equal bins the lanes of a group sit on consecutive banks, and the energy / feature passes
+    // below read consecutive words
+    T* hb = hist + bl;
+    const int NBB = NB * NB;
     if constexpr (SBIN_T > 0 && (SBIN_T & 1) == 0) {
       // even cell size: block b receives exactly the 2 * sbin window rows / columns from b * sbin on, the first sbin of them
       // with the "upper" weight (the pixel's iy is b - 1: weight vy0), the rest with the "lower" one (iy == b: vy1)
@@ -284,11 +293,12 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
       for (int dy = 0; dy < 2 * SBIN_T; ++dy) {
         const int wy = wy_lo + dy;
         const T fy = dy < SBIN_T ? wy0[wy] : wy1[wy];
-        const uint8_t* brow = bin + wy * L.MP + wx_lo;
-        const T* mrow = mag + wy * L.MP + wx_lo;
+        const uint8_t* brow = bin + wy * L.MP + lbx;      // pixel wx_lo + dx of the row: (dx % sbin) * QS + lbx + dx / sbin
+        const T* mrow = mag + wy * L.MP + lbx;
 #pragma unroll
         for (int dx = 0; dx < 2 * SBIN_T; ++dx) {
-          hb[brow[dx]] += (fy * fxv[dx]) * mrow[dx];
+          const int pi = (dx % SBIN_T) * L.QS + dx / SBIN_T;
+          hb[brow[pi] * NBB] += (fy * fxv[dx]) * mrow[pi];
         }
       }
     } else {
@@ -306,7 +316,8 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
           const int ix = ipx[wx];
           T fx;
           if (ix == bx) fx = wx1[wx]; else if (ix == bx - 1) fx = wx0[wx]; else continue;
-          hb[bin[wy * L.MP + wx]] += (fy * fx) * mag[wy * L.MP + wx];
+          const int wq = wx / sbin, pi = wy * L.MP + (wx - wq * sbin) * L.QS + wq;
+          hb[bin[pi] * NBB] += (fy * fx) * mag[pi];
         }
       }
     }
@@ -316,11 +327,12 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
 
   // ---- block energy (:270-283) ----
   for (int i = tid; i < NB * NB; i += HOG_NT) {
-    const T* hsrc = hist + i * PBD_NORIENT;
+    const T* hsrc = hist + i;
+    const int NBB = NB * NB;
     T acc = (T)0;
 #pragma unroll
     for (int o = 0; o < 9; ++o) {
-      T s = hsrc[o] + hsrc[o + 9];
+      T s = hsrc[o * NBB] + hsrc[(o + 9) * NBB];
       acc += s * s;
     }
     norm[i] = acc;
@@ -353,12 +365,13 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
       if (t.cy0 + ly < lv.ch && t.cx0 + lx < lv.cw) {
         const T n1 = ninv[(ly + 1) * NC + lx + 1], n2 = ninv[ly * NC + lx + 1];
         const T n3 = ninv[(ly + 1) * NC + lx], n4 = ninv[ly * NC + lx];
-        const T* hsrc = hist + ((ly + 1) * NB + lx + 1) * PBD_NORIENT;
+        const T* hsrc = hist + ((ly + 1) * NB + lx + 1);
+        const int NBB = NB * NB;
         T* d = stg + tid * (PBD_FLEN + 1);
         T t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 #pragma unroll 6
         for (int o = 0; o < PBD_NORIENT; ++o) {                    // :305-317
-          const T val = hsrc[o];
+          const T val = hsrc[o * NBB];
           const T h1 = t_fmin(val * n1, (T)0.2), h2 = t_fmin(val * n2, (T)0.2);
           const T h3 = t_fmin(val * n3, (T)0.2), h4 = t_fmin(val * n4, (T)0.2);
           d[o] = (T)(0.5 * (double)(h1 + h2 + h3 + h4));
@@ -366,7 +379,7 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
         }
 #pragma unroll 3
         for (int o = 0; o < PBD_NORIENT / 2; ++o) {                // :320-328
-          const T sum = hsrc[o] + hsrc[o + PBD_NORIENT / 2];
+          const T sum = hsrc[o * NBB] + hsrc[(o + PBD_NORIENT / 2) * NBB];
           const T h1 = t_fmin(sum * n1, (T)0.2), h2 = t_fmin(sum * n2, (T)0.2);
           const T h3 = t_fmin(sum * n3, (T)0.2), h4 = t_fmin(sum * n4, (T)0.2);
           d[PBD_NORIENT + o] = (T)(0.5 * (double)(h1 + h2 + h3 + h4));
