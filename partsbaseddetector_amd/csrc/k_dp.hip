@@ -96,7 +96,7 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // than the plain one.  Everything below is branch-free except the loop over the children.
 template <typename T, int M, int U>
 __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ /*biasw*/, const unsigned (&off)[U],
-                                              unsigned HW, int L, T (&acc)[U][M], unsigned live = ~0u) {
+                                              unsigned HW, int L, T (&acc)[U][M]) {
   const int nch = J->nch;
   unsigned ob[U];                                        // byte offsets of the cells inside a plane of T (< 2^32, plan_frame)
 #pragma unroll
@@ -142,10 +142,6 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
     const bool copy1 = C.K == 1;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      // (live: bit u = some lane of this WAVEFRONT holds a cell of its own in slot u.  A block's cells rarely fill the last slot — 632
-      // cells on 3 x 256 lanes: the slot's upper wavefronts hold clamped repeats only and skip the 36 add / compare / select pairs; the
-      // loads above stay unconditional)
-      if (U > 1 && !(live & (1u << u))) continue;
       T v[M];
       int bi[M];
       T w0[M];
@@ -288,24 +284,20 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         const int jj = len > 1 ? (int)__umulhi((unsigned)ec, magic) : ec;
         slot[u] = __mul24(jj, S) + (ec - __mul24(jj, len));        // LDS element of mixture 0's line of that row
       }
-      // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
+      // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight (round 6: copying the
+        // entries from a per-device table instead — 30 fewer vector instructions per lane — measured 1.7 % SLOWER in batches: the divisions
+        // hide under the loads, a dependent global load in front of the LDS write does not)
       if constexpr (!EX) {
         if (e0 == 0)
           for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
-      unsigned live = 0;                                             // wave-uniform: slot u holds a cell of its own in this wavefront's first lane
-      {
-        const int wave0 = __builtin_amdgcn_readfirstlane(lane);
-#pragma unroll
-        for (int u = 0; u < U; ++u) live |= (e0 + u * NT + wave0 < n) ? (1u << u) : 0u;
-      }
-      fold_children<T, M, U>(J, biasw, off, HW, L, acc, live);
+      fold_children<T, M, U>(J, biasw, off, HW, L, acc);
       const int mstride = nrows * S;                                 // LDS elements between the lines of consecutive mixtures of a row
-      // (unpredicated like the plain loader: a lane past the last cell holds the last cell's values and stores them once more; a whole
-      // wavefront past it — `live` — stores nothing: its accumulators were not folded)
+      // (unpredicated like the plain loader: a lane past the last cell holds the last cell's values and stores them once more.  Round 6
+      //  measured the alternative — wavefronts whose slot holds clamped repeats only skip the mixture reduce —: 0.7 % faster alone, 1.6 %
+      //  slower in batches, profiles/r06/r06_session16_*)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (!(live & (1u << u))) continue;
 #pragma unroll
         for (int m = 0; m < M; ++m)      // (columns beyond L repeat mixture L - 1: the same value stored to its slot once more, no branch)
           YZ[min(m, L - 1) * mstride + slot[u]].x = acc[u][m];
@@ -339,7 +331,9 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
             else r[j] = ((GP(T))lptr[i])[pos];
             la[j] = __mul24(i, S) + (int)pos;
           }
-          // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight
+          // reciprocal table 1/dx: one IEEE division per entry, spread over the lanes — while the loads are in flight (round 6: copying the
+        // entries from a per-device table instead — 30 fewer vector instructions per lane — measured 1.7 % SLOWER in batches: the divisions
+        // hide under the loads, a dependent global load in front of the LDS write does not)
           if constexpr (!EX) {
             if (f0 == 0)
               for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
