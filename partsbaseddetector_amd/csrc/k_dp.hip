@@ -186,6 +186,7 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
 template <typename T, typename IT, int FM>   // FM: 0 = plain lines, else fold with at most FM mixtures per part
 __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps,
                                          const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
+
   constexpr bool FOLD = FM > 0;
   const int lane = threadIdx.x, NT = blockDim.x;
   const int len = g.len, S = g.stride, lpb = g.lpb;
