@@ -108,11 +108,18 @@ static inline int dt_segments(int lanes_per_line, int len) {
 // holds only where (float)q1 is a normal float; the smallest normal binade is left out with a margin, so a q1 just below
 // the normal range that rounds up into it is flagged too).  A flagged line is redone with EXACT = true (IEEE division), so
 // the result is always bit-identical to the reference's.
-template <bool EXACT, typename T>
+// FUSED (round 6; the caller's promise: a and b are doubles converted from FLOATS — the model's weights always are,
+// src/DynamicProgram.cpp:125-127 — and the line has at most DT_FUSE_MAXLEN elements): the two products of the numerator are then EXACT in fp64
+// (b * dx: 24 + 15 significant bits; a * (x1^2 - x0^2): 24 + 29), so RN(t - RN(b dx)) = RN(t - b dx) = fma(-b, dx, t) and
+// RN(t' + RN(a X)) = fma(a, X, t'): the same num, bit for bit, in two instructions fewer and a dependent chain two operations shorter.
+#define DT_FUSE_MAXLEN 16384   // x1^2 - x0^2 = dx (x1 + x0) < 2 len^2 <= 2^29; the read-out's d^2 < 2^28 needs |os| + len <= 2^14 as well (the planner checks both)
+template <bool EXACT, bool FUSED, typename T>
 DT_HD T dt_isect(T yk, int vk, T yq, int q, double a, double b, double twoa, double i2a, double rdx, DT_SUSPECT_T& suspect) {
   const int dx = q - vk;
   const double dxd = (double)dx;
-  const double num = (((double)yq - (double)yk) - b * dxd) + a * (double)DT_MUL24(dx, q + vk);   // x1^2 - x0^2 < 2^31, operands < 2^16
+  const double x2 = (double)DT_MUL24(dx, q + vk);                                               // x1^2 - x0^2 < 2^31, operands < 2^16
+  const double num = FUSED ? fma(a, x2, fma(-b, dxd, (double)yq - (double)yk))
+                           : ((((double)yq - (double)yk) - b * dxd) + a * x2);
   if (EXACT) {
     return (T)(num / (twoa * dxd));
   } else {
@@ -137,7 +144,7 @@ DT_HD T dt_isect(T yk, int vk, T yq, int q, double a, double b, double twoa, dou
 // (dead when the step pops: q is inserted again).  VALU issue is what bounds the kernel in batches (SQ counters:
 // every issue slot of the SIMDs is taken while a pass runs), so the loop carries the fewest selects that do the job.
 // RDX[dx] = RN(1 / dx), i2a = RN(1 / (2a)) (EXACT = false only).  Returns the sticky "suspect" flag.
-template <bool EXACT, typename T, typename IT>
+template <bool EXACT, bool FUSED, typename T, typename IT>
 DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a,
                        int s0, int s1, double a, double b) {
   const double twoa = 2 * a;
@@ -156,7 +163,7 @@ DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const dou
     const int below_link = (int)B[nv];
     const double rdx = EXACT ? 0.0 : RDX[q - vk];
     const T ynext = YZ[q + 1].x;            // q + 1 == s1 <= len: the slot exists (the stride is >= len + 1) and the value is never used
-    const T s = dt_isect<EXACT, T>(yk, vk, yq, q, a, b, twoa, i2a, rdx, suspect);
+    const T s = dt_isect<EXACT, FUSED, T>(yk, vk, yq, q, a, b, twoa, i2a, rdx, suspect);
     // :162.  EXACT = false: the bottom's z is -inf, so only s = -inf could pop it — an out-of-range quotient, which
     // dt_isect flags (the line is redone with EXACT = true): no `k > 0` test on this path
     const bool pop = EXACT ? ((s <= zk) && (vk != s0)) : (s <= zk);
@@ -187,7 +194,7 @@ DT_HD bool dt_seg_scan(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const dou
 // deeper (rounds: dt_stitch_stale / dt_stitch_redo).  Outputs: f = lowest element of the segment left on the stack, patched to its global z / link (the
 // local values are returned in zsave / bsave so that a redo can restore them).  Returns true if the invariant
 // was lost or a quotient was suspect (the caller redoes the whole line sequentially).
-template <bool EXACT, typename T, typename IT>
+template <bool EXACT, bool FUSED, typename T, typename IT>
 DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a,
                       int s0, int s1, double a, double b, int& f_out, int& dmin_out, T& zsave, int& bsave) {
   const double twoa = 2 * a;
@@ -215,7 +222,7 @@ DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const doub
     T s = qz.y;
     if (DT_ANY(!cheap)) {
       const double rdx = EXACT ? 0.0 : RDX[q - e];
-      const T si = dt_isect<EXACT, T>(ez.x, e, qz.x, q, a, b, twoa, i2a, rdx, suspect);   // (a lane that does not need it may flag itself: harmless)
+      const T si = dt_isect<EXACT, FUSED, T>(ez.x, e, qz.x, q, a, b, twoa, i2a, rdx, suspect);   // (a lane that does not need it may flag itself: harmless)
       s = cheap ? s : si;
     }
     dmin = (!testf && e < dmin) ? e : dmin;
@@ -264,13 +271,13 @@ DT_HD bool dt_stitch_stale(int dmin_p, int fspec_prev, int fnew_prev) {
 }
 // the redo of boundary [s0, s1) with everything to its left final: fo / zsave / bsave = the speculative stitch's F and its local
 // (z, link); returns dt_stitch1's flag, the final F in f_out (patched; its local values in zsave / bsave again)
-template <bool EXACT, typename T, typename IT>
+template <bool EXACT, bool FUSED, typename T, typename IT>
 DT_HD bool dt_stitch_redo(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const double* __restrict__ RDX, double i2a, int s0, int s1,
                           double a, double b, int fo, int& f_out, T& zsave, int& bsave) {
   YZ[fo].y = zsave;                          // undo the speculative patch, then stitch again
   B[fo] = (IT)bsave;
   int dmin;
-  return dt_stitch1<EXACT, T, IT>(YZ, B, RDX, i2a, s0, s1, a, b, f_out, dmin, zsave, bsave);
+  return dt_stitch1<EXACT, FUSED, T, IT>(YZ, B, RDX, i2a, s0, s1, a, b, f_out, dmin, zsave, bsave);
 }
 
 // After the stitches every segment p has F[p], its lowest element left on the stack when the run finished the

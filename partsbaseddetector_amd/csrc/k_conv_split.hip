@@ -248,6 +248,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, PIN 
   const uint16_t* bl = filt + (size_t)ntb * 512 + lane * 8;
   const size_t bs_split = (size_t)ntl_bank * 512, bs_kstep = NS * bs_split;
   const int nkstep = 2 * kh * kw;
+#ifdef PBD_BANK_PRIO   // experiment builds only: the K loop's wavefronts at a raised issue priority against the other batches' kernels on the SIMD
+  __builtin_amdgcn_s_setprio(PBD_BANK_PRIO);
+#endif
 
   auto k_loop = [&](auto mv_tag) __attribute__((always_inline)) {
     constexpr int MV = decltype(mv_tag)::value;

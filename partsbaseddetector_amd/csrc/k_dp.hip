@@ -72,8 +72,8 @@ void dt_debug_read(unsigned long long* out) { for (int i = 0; i < 8; ++i) out[i]
 // {(y, z) : T2[S]; B : u8[S] (S <= 256) or u16[S]}.
 // 9 bytes per line element for float: the lines resident on a CU are bounded by these bytes.
 #define DT_SEGS 72                                   // SEG entries: P + 1 <= 65 starts, then {0, len} for a line redone as one segment
-__host__ __device__ inline size_t dt_hdr_bytes(int nt, int ts, int its, int lpb) {   // per line 16 B, per lane 2 T + 4 IT
-  return ((size_t)lpb * 16 + DT_SEGS * 4 + (size_t)nt * (2 * ts + 4 * its) + 15) & ~(size_t)15;
+__host__ __device__ inline size_t dt_hdr_bytes(int nt, int ts, int its, int lpb) {   // per line 16 B, per lane T + 4 IT
+  return ((size_t)lpb * 16 + DT_SEGS * 4 + (size_t)nt * (ts + 4 * its) + 15) & ~(size_t)15;
 }
 size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): (y, z) is a float or a double pair
   const int its = stride <= 256 ? 1 : 2;
@@ -192,6 +192,9 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   const int len = g.len, S = g.stride, lpb = g.lpb;
   typedef DtPair<T> P2;
   constexpr bool EX = sizeof(T) == 8;          // DistanceTransform<double>: s is not narrowed, every intersection takes the IEEE division
+  // float maps whose weights are converted floats on lines of at most DT_FUSE_MAXLEN elements (every map of a detector; the planner says so per
+  // group): the numerator's products are exact, so they fuse into their additions (dt_core.hpp: dt_isect, FUSED) — block-uniform
+  const bool fz = !EX && g.fused != 0;
   const T** lptr = (const T**)smem;            // [lpb] source pointer of each line of this block (plain)
   int* FLAG = (int*)(smem + lpb * 8);          // [lpb] per line: redo sequentially (suspect quotient / lost stitch invariant)
   int* FIX = FLAG + lpb;                       // [lpb] per line: the lowest stale boundary of the line in an even validation round
@@ -199,9 +202,12 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   int* SEG = FIX + lpb;                        // [P + 1 <= 65] start of every segment (len and P are uniform over the block), [DT_SEGS - 2..]: {0, len}
   int* ANY = SEG + DT_SEGS - 6;                // [2] a line has a stale stitch (even / odd validation round)
   int* NFLAG = SEG + DT_SEGS - 4;              // [1] a line of the block is flagged for the sequential redo
-  T* ZLO = (T*)(SEG + DT_SEGS);                // [NT] per lane (p * lpb + line): z of the segment's lowest surviving element
-  T* ZSAVE = ZLO + NT;                         // [NT] per lane: that element's local z (before the stitch patched it)
-  IT* FT = (IT*)(ZSAVE + NT);                  // [NT] per lane: that element
+  T* ZLO = (T*)(SEG + DT_SEGS);                // [NT] per lane (p * lpb + line): z of the segment's lowest surviving element — what the read-out needs; while
+                                               // validation rounds run (rare path): that element's LOCAL z, before the stitch patched it (the stitch's lane keeps
+                                               // it in a register and stores it only if the block has a stale stitch: 4 B per lane less LDS than a table of its
+                                               // own — at 640x480 the person model's fold launches of a single frame drop from 1 040 to 1 016 blocks, under the
+                                               // 1 024 the chip holds at once)
+  IT* FT = (IT*)(ZLO + NT);                    // [NT] per lane: that element
   IT* BELOW = FT + NT;                         // [NT] the element FT sits on
   IT* DMIN = BELOW + NT;                         // [NT] lowest element the segment's speculative stitch tested
   IT* BSAVE = DMIN + NT;                       // [NT] local link of FT (before the patch)
@@ -357,16 +363,21 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 
   // ---- local scans: the envelope of every segment (DistanceTransform.hpp:156-170 on the segment alone) ----
   if (mine && p < P) {
-    if (dt_seg_scan<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b)) { FLAG[line] = 1; *NFLAG = 1; }
+    const bool sus = fz ? dt_seg_scan<EX, !EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b)
+                        : dt_seg_scan<EX, false, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b);
+    if (sus) { FLAG[line] = 1; *NFLAG = 1; }
   }
   __syncthreads();
   DT_STAMP(3);
   // ---- stitch the segments into the sequential result: every boundary by its own lane, concurrently ----
-  if (mine && p >= 1 && p < P && !FLAG[line]) {
+  T zs_mine = (T)0;                                // the local z of this lane's F (a redo restores it: dt_stitch_redo)
+  const bool stitched = mine && p >= 1 && p < P && !FLAG[line];
+  if (stitched) {
     int f, dmin, bs;
     T zs;
-    const bool bad = dt_stitch1<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b, f, dmin, zs, bs);
-    FT[lane] = (IT)f; DMIN[lane] = (IT)dmin; ZSAVE[lane] = zs; BSAVE[lane] = (IT)bs;
+    const bool bad = fz ? dt_stitch1<EX, !EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b, f, dmin, zs, bs)
+                        : dt_stitch1<EX, false, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[p], SEG[p + 1], mp.a, mp.b, f, dmin, zs, bs);
+    FT[lane] = (IT)f; DMIN[lane] = (IT)dmin; zs_mine = zs; BSAVE[lane] = (IT)bs;
     if (bad) { FLAG[line] = 1; *NFLAG = 1; }
   }
   if (mine && p == 0) FT[lane] = (IT)0;
@@ -391,16 +402,19 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     __syncthreads();
     DT_STAMP(6);
     if (ANY[0]) {                                  // (block-uniform; rare)
+      if (stitched) ZLO[lane] = zs_mine;           // the table holds the stitches' local z while the rounds run (the segments' entries are published again below)
+      __syncthreads();
       for (int round = 0;; ++round) {
         int* FIXr = (round & 1) ? FIX2 : FIX;
         int* FIXn = (round & 1) ? FIX : FIX2;
         if (mine && p == 0 && FIXr[line] != 0x7fffffff) {
           const int ps = FIXr[line], ls = __mul24(ps, lpb) + line;
           int f, bs = (int)BSAVE[ls];
-          T zs = ZSAVE[ls];
-          const bool bad = dt_stitch_redo<EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[ps], SEG[ps + 1], mp.a, mp.b, (int)FT[ls], f, zs, bs);
-          FT[ls] = (IT)f; ZSAVE[ls] = zs; BSAVE[ls] = (IT)bs;
-          DMIN[ls] = (IT)SEG[ps];                  // final: never stale again (every F to its left lies below its segment)
+          T zs = ZLO[ls];
+          const bool bad = fz ? dt_stitch_redo<EX, !EX, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[ps], SEG[ps + 1], mp.a, mp.b, (int)FT[ls], f, zs, bs)
+                              : dt_stitch_redo<EX, false, T, IT>(YZl, Bl, RDX, mp.r2a, SEG[ps], SEG[ps + 1], mp.a, mp.b, (int)FT[ls], f, zs, bs);
+          FT[ls] = (IT)f; BSAVE[ls] = (IT)bs;
+          DMIN[ls] = (IT)SEG[ps];                  // final: never stale again (every F to its left lies below its segment) — its saved z is not needed again
           if (bad) { FLAG[line] = 1; *NFLAG = 1; }
         }
         if (lane < lpb) FIXn[lane] = 0x7fffffff;   // the next round's tables (last read a round ago)
@@ -423,7 +437,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   if (*NFLAG) {                                    // (block-uniform)
     if (mine && p == 0 && FLAG[line]) {
       DT_COUNT_REDO();
-      dt_seg_scan<true, T, IT>(YZl, Bl, RDX, mp.r2a, 0, len, mp.a, mp.b);
+      dt_seg_scan<true, false, T, IT>(YZl, Bl, RDX, mp.r2a, 0, len, mp.a, mp.b);
       BELOW[line] = Bl[0];
       ZLO[line] = YZl[0].y;
     }
@@ -462,15 +476,21 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       GPW(int16_t) ppq = (GPW(int16_t))pp + (size_t)(q1 - 1) * pst;
       const int os_end = mp.os + q0;           // the sub-range's first output (the loop counts the shifted position down to it)
       ++os;
-      do {                                     // (q0 < q1: at least one output)
-        --os;
-        const T fos = (T)os;                   // `z[k+1] < os`: int promoted to T (:174)
-        while (!(eyz.y < fos)) { e = nx; eyz = YZl[e]; nx = (int)Bl[e]; }
-        const double d = (double)(os - e);     // |d| < 2^15: d * d is exact in fp64 (the reference squares the int)
-        *dp = (T)(a * (d * d) + b * d + (double)eyz.x);
-        *ppq = (int16_t)e;
-        dp -= nlines; ppq -= pst;
-      } while (os > os_end);
+      auto outputs = [&](auto fused) {         // fused: a * d^2 and b * d are exact (|d| < 2^14, float-born weights): their sum is one fma
+        constexpr bool FZ = decltype(fused)::value;
+        do {                                   // (q0 < q1: at least one output)
+          --os;
+          const T fos = (T)os;                 // `z[k+1] < os`: int promoted to T (:174)
+          while (!(eyz.y < fos)) { e = nx; eyz = YZl[e]; nx = (int)Bl[e]; }
+          const double d = (double)(os - e);   // |d| < 2^15: d * d is exact in fp64 (the reference squares the int)
+          const double ad2 = a * (d * d);
+          *dp = (T)((FZ ? fma(b, d, ad2) : (ad2 + b * d)) + (double)eyz.x);
+          *ppq = (int16_t)e;
+          dp -= nlines; ppq -= pst;
+        } while (os > os_end);
+      };
+      if constexpr (!EX) { if (fz) outputs(std::true_type{}); else outputs(std::false_type{}); }
+      else outputs(std::false_type{});
     }
   }
   DT_STAMP(5);
@@ -483,6 +503,14 @@ template <typename T, int FM>
 __global__ __launch_bounds__(256, 3) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
                                                     const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Issue priority 1 for the whole block (round 6): where a distance-transform wavefront shares a SIMD with wavefronts of another batch's filter
+  // bank (priority 0: they wait for the matrix pipe most of the time) or HOG kernel, its vector instructions go first — the DP chain is the longest
+  // dependent chain of a frame.  Interleaved runs on two boxes: +1.2 % frames/s with single-frame calls in flight (1 921 -> 1 944, 1 919 -> 1 942), +0.6 ... 1.1 % in
+  // batches; priorities 1 / 2 / 3 measure the same, the filter bank's K loop at 1 / 3 instead: no change (profiles/r06/r06_session28_*, _session29_*).
+  // Alone on the chip the DT is unaffected (rounds 4's s_setprio experiments were phase-wise INSIDE the block, against its own co-resident blocks: slower).
+#if PBD_DT_PRIO > 0
+  __builtin_amdgcn_s_setprio(PBD_DT_PRIO);
+#endif
   DT_STAMP(0);
   DT_TRACE(0);
   const DtTask t = tasks[blockIdx.x];
@@ -724,10 +752,14 @@ __global__ __launch_bounds__(64) void k_backtrack(const int* __restrict__ count,
                                                   int nflat, const unsigned long long* __restrict__ scr_base,
                                                   const int16_t* __restrict__ ixs, const int16_t* __restrict__ iys,
                                                   int correct_ptr, const int16_t* __restrict__ extx,
-                                                  const int16_t* __restrict__ exty, const unsigned long long* __restrict__ ext_base) {
+                                                  const int16_t* __restrict__ exty, const unsigned long long* __restrict__ ext_base,
+                                                  int* __restrict__ count_out) {
   __shared__ int lx[BT_MAXP], ly[BT_MAXP], lm[BT_MAXP];
   const int lane = threadIdx.x;
   const int n = min(*count, capacity);
+  // count_out != null: `out` and count_out are the handle's PINNED HOST buffers (device-mapped): the records and the count go straight to
+  // the host — no copy nodes behind the kernel (two engine copies + their hand-overs cost a single frame ~40 us of its 64 us argmin stage)
+  if (count_out && blockIdx.x == 0 && lane == 0) *count_out = *count;
   // grid-stride over the candidates: the launch is sized for the chip, not for the capacity (the count is only known on the
   // device; one block per record of a 32 768-record buffer meant ~30 000 blocks that exit at once, every frame)
   for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
@@ -790,10 +822,10 @@ void launch_backtrack(const int* count, const CandRec* rec, int capacity, const 
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh, char* out,
                       size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,
                       const unsigned long long* scr_base, const int16_t* ix, const int16_t* iy, int correct_ptr,
-                      const int16_t* extx, const int16_t* exty, const unsigned long long* ext_base, hipStream_t s) {
+                      const int16_t* extx, const int16_t* exty, const unsigned long long* ext_base, int* count_out, hipStream_t s) {
   const int nblk = std::min(capacity, 2048);   // 8 blocks of one wavefront per CU; more candidates than that are taken in further sweeps
-  if (ts == 8) hipLaunchKernelGGL(k_backtrack<double>, dim3(nblk), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base);
-  else hipLaunchKernelGGL(k_backtrack<float>, dim3(nblk), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base);
+  if (ts == 8) hipLaunchKernelGGL(k_backtrack<double>, dim3(nblk), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base, count_out);
+  else hipLaunchKernelGGL(k_backtrack<float>, dim3(nblk), dim3(64), 0, s, count, rec, capacity, back, ncomp, parent, plane0, nparts, max_parts, kh, out, out_stride, flat, depth, max_depth, nflat, scr_base, ix, iy, correct_ptr, extx, exty, ext_base, count_out);
 }
 
 // ---------------------------------------------------------------------------

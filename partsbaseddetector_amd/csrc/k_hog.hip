@@ -125,6 +125,9 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
   const int sbin = SBIN_T > 0 ? SBIN_T : sbin_rt;
   const int tc = TC_T > 0 ? TC_T : tc_rt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PBD_HOG_PRIO     // experiment builds only
+  __builtin_amdgcn_s_setprio(PBD_HOG_PRIO);
+#endif
   HOG_STAMP(0);
   const HogTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];

@@ -476,6 +476,19 @@ static void dt_add_tasks(const DtGroup& g, std::vector<DtTask>& out, const std::
     }
   }
 }
+// DtGroup::fused (dt_core.hpp: dt_isect's FUSED form, the read-out's fused sum): float maps whose a and b are converted floats — the model's
+// weights always (dt_map), pbd_dt2d's caller may hand in any double — on lines short enough for the products to be exact in fp64
+static void dt_mark_fused(std::vector<DtTask>& tasks, const DtMap* maps, int ts) {
+  for (DtTask& t : tasks) {
+    DtGroup& g = t.g;
+    bool ok = ts == 4 && g.len <= DT_FUSE_MAXLEN;
+    for (int m = 0; m < g.nmaps && ok; ++m) {
+      const DtMap& mp = maps[g.map0 + m];
+      ok = (double)(float)mp.a == mp.a && (double)(float)mp.b == mp.b && (long long)g.len + std::abs((long long)mp.os) <= DT_FUSE_MAXLEN;
+    }
+    g.fused = ok ? 1 : 0;
+  }
+}
 static DtMap dt_map(const void* src, void* dst, int16_t* ptr, float wq, float wl, int os, int natural) {
   DtMap m{};
   m.src = src; m.dst = dst; m.ptr = ptr;
@@ -875,6 +888,8 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1, int 
       for (int i = 1; i < ndup; ++i) { xt.insert(xt.end(), x0.begin(), x0.end()); yt.insert(yt.end(), y0.begin(), y0.end()); }
     }
     if (PBD_PROBE_ENV("PBD_DT_REVERSE")) { std::reverse(xt.begin(), xt.end()); std::reverse(yt.begin(), yt.end()); }   // probe: coarse levels' blocks first
+    dt_mark_fused(xt, maps.data(), h->ts);
+    dt_mark_fused(yt, maps.data(), h->ts);
     xcd_order(xt);
     xcd_order(yt);
     R.lds_x = launch_lds(xt, fold_x ? h->dt_nt_x : h->dt_nt); R.lds_y = launch_lds(yt, h->dt_nt); R.fold_x = fold_x ? 1 : 0;
@@ -1126,11 +1141,17 @@ static int run_argmin_enqueue(pbd_handle* h) {
                 h->opt.max_candidates, h->ts, h->d_foldjobs, h->d_biasw, 1, h->fold_mix, nullptr, nullptr, h->stream);
     h->root_dirty = false;
   }
+  // Round 6: a handle that is not a member of an RCCL-gathering group lets the back-tracking kernel write the records and the count straight
+  // into its pinned host buffers (hipHostMalloc: device-mapped, coherent): no copy nodes behind the kernel, and never a second copy for
+  // records beyond a first block.  Group members keep the device buffer: the all-gather reads it.
+  const bool zero_copy = PBD_ARGMIN_ZERO_COPY && !h->d_gsend;
   launch_backtrack(h->d_cand_count, h->d_cand_rec, h->opt.max_candidates, h->d_back, h->md.ncomponents, h->d_parent,
-                   h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, h->d_cand_out, h->cand_stride, h->ts, h->d_flat,
+                   h->d_plane0, h->d_nparts, h->max_parts, h->md.kh, zero_copy ? h->h_cand_out : h->d_cand_out, h->cand_stride, h->ts, h->d_flat,
                    h->d_depth, h->max_depth, (int)h->parts.size(), h->d_scr_base, h->d_dt_ixT, h->d_dt_iy,
-                   h->opt.dt_correct_ptr, h->ext_ptr ? h->d_extx : nullptr, h->d_exty, h->d_ext_base, h->stream);
+                   h->opt.dt_correct_ptr, h->ext_ptr ? h->d_extx : nullptr, h->d_exty, h->d_ext_base, zero_copy ? h->h_cand_count : nullptr, h->stream);
   LAUNCHCHK(h, "argmin");
+  if (zero_copy) { h->pending = true; h->out_on_host = true; return PBD_OK; }
+  h->out_on_host = false;
   // members of an RCCL-gathering group send a fixed block (pbd_group.cpp sizes its buffers for PBD_FIRST_COPY records)
   if (h->d_gsend || h->first_copy < kFirstCopy * h->batch) h->first_copy = kFirstCopy * h->batch;
   const int first = std::min(h->first_copy, h->opt.max_candidates);
@@ -1154,7 +1175,7 @@ int pbd_i_finish_frame(pbd_handle* h, int found) {
     if (hipEventElapsedTime(&ms, h->ev_dp0, h->ev_dp1) == hipSuccess) { h->dp_ms_sum += ms; h->dp_frames++; }
   }
   const int n = std::min(found, h->opt.max_candidates);
-  const int first = std::min(h->first_copy, h->opt.max_candidates);
+  const int first = h->out_on_host ? n : std::min(h->first_copy, h->opt.max_candidates);   // (zero-copy: every record is on the host already)
   if (n > first) {
     HIPCHK(h, hipMemcpyAsync(h->h_cand_out + h->cand_stride * first, h->d_cand_out + h->cand_stride * first,
                              h->cand_stride * (n - first), hipMemcpyDeviceToHost, h->stream));
@@ -1979,6 +2000,7 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   dt_add_tasks(groups[0], tasks);
   const int nx = (int)tasks.size();
   dt_add_tasks(groups[1], tasks);
+  dt_mark_fused(tasks, maps, tsz);   // (the caller's quadratics: fused arithmetic only if they are converted floats)
   DtMap* d_maps; DtTask* d_tasks;
   HIPCHK(h, hipMalloc(&d_maps, sizeof(maps)));
   HIPCHK(h, hipMalloc(&d_tasks, sizeof(DtTask) * tasks.size()));

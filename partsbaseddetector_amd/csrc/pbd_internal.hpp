@@ -71,13 +71,20 @@ struct DtGroup {
   unsigned magic_lpb;        // lane / lpb              (lane < 2^8)
   unsigned magic_nlines;     // (l0 + lane) / nlines    (numerator < nlines + 2^8, nlines < 2^15)
   unsigned magic_P;          // (p * len) / P           (p * len < 2^21, P <= 64)
-  int pad;
+  int fused;                 // float maps only: every map of the group has weights that are converted floats, len and len + |os| <= DT_FUSE_MAXLEN: the
+                             // intersection's and the read-out's products are exact and fuse into their additions (dt_core.hpp: dt_isect)
 };
 struct DtTask { int g0, nl, m0, l0; DtGroup g;     // g0: first line (plain) / first row (fold); nl: lines of this block; plain: g0 = m0 * nlines + l0
                                                     // (first map of the block, first line inside it); the group travels with the task
   const void* src0; };                              // plain: the block's first line when its nl lines are CONTIGUOUS in memory (consecutive maps of a group
                                                     // back to back — the y pass's input always, plan_frame), else null: the loader then needs no map descriptor
 static inline unsigned dt_magic(unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; }   // d == 1: the quotient is the numerator itself (callers test)
+#ifndef PBD_ARGMIN_ZERO_COPY
+#define PBD_ARGMIN_ZERO_COPY 1   // k_backtrack writes candidates straight to the pinned host buffers (handles outside RCCL groups)
+#endif
+#ifndef PBD_DT_PRIO
+#define PBD_DT_PRIO 1            // s_setprio of k_dt_pass's wavefronts (k_dp.hip)
+#endif
 #ifndef PBD_DT_NT_DEFAULT
 #define PBD_DT_NT_DEFAULT 128   // lanes of a k_dt_pass block
 #endif
@@ -227,6 +234,7 @@ struct pbd_handle {
   // candidates
   int* d_cand_count = nullptr; CandRec* d_cand_rec = nullptr;
   char* d_cand_out = nullptr; char* h_cand_out = nullptr; int* h_cand_count = nullptr;
+  bool out_on_host = false;                          // the last back-tracking wrote its records straight into h_cand_out (run_argmin_enqueue)
   size_t cand_stride = 0;
   bool pending = false;
   int first_copy = 0;        // candidate records copied back together with the count (records): starts at PBD_FIRST_COPY per frame of the
@@ -349,7 +357,7 @@ void launch_backtrack(const int* count, const CandRec* rec, int capacity, const 
                       const int* parent, const int* plane0, const int* nparts, int max_parts, int kh,
                       char* out, size_t out_stride, int ts, const int* flat, const int* depth, int max_depth, int nflat,
                       const unsigned long long* scr_base, const int16_t* ix, const int16_t* iy, int correct_ptr,
-                      const int16_t* extx, const int16_t* exty, const unsigned long long* ext_base, hipStream_t s);
+                      const int16_t* extx, const int16_t* exty, const unsigned long long* ext_base, int* count_out, hipStream_t s);
 void dt_debug_read(unsigned long long* out);
 int dt_debug_trace(unsigned long long* t, unsigned* hw, int* nlaunch);   // probe build only
 void hog_debug_read(unsigned long long* out);

@@ -13,7 +13,7 @@ import json, sys, glob
 O = sys.argv[1]
 for L in sys.argv[2:]:
     rows = []
-    for f in sorted(glob.glob(f"{O}/{L[:-3]}_*.json")):
+    for f in sorted(glob.glob(f"{O}/{L[:-3]}_[0-9]*.json")):
         try:
             d = json.load(open(f))
         except Exception as e:

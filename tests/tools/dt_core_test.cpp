@@ -16,10 +16,10 @@ extern "C" void orc_dt1d_f64(const double* src, double* dst, int32_t* ptr, int N
 static void ref1d(const float* s, float* d, int32_t* p, int n, double a, double b, int os) { orc_dt1d(s, d, p, n, a, b, os); }
 static void ref1d(const double* s, double* d, int32_t* p, int n, double a, double b, int os) { orc_dt1d_f64(s, d, p, n, a, b, os); }
 
-struct Stats { long lines = 0, suspect = 0, inconsistent = 0, events = 0, redos = 0; };
+struct Stats { long lines = 0, suspect = 0, inconsistent = 0, events = 0, redos = 0, fused = 0; };
 
 // one line exactly as k_dt_pass processes it: `lanes` lanes per line
-template <typename T, typename IT>
+template <typename T, typename IT, bool FZ>   // FZ: the fused arithmetic of float maps with float-born weights (dt_isect's FUSED, the read-out's fused sum)
 static void run_line(const T* src, int len, int lanes, double a, double b, int os, T* dst, int32_t* ptr, Stats& st, int order_mode) {
   const int S = (len + 2) & ~1;
   std::vector<DtPair<T>> YZ(S);
@@ -35,7 +35,7 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
   for (int p = 0; p <= P; ++p) seg[p] = dt_seg_start(p, P, len);
   bool flag = false;
   for (int p = 0; p < P; ++p)
-    flag |= dt_seg_scan<EX, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[p], seg[p + 1], a, b);
+    flag |= dt_seg_scan<EX, FZ, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[p], seg[p + 1], a, b);
   if (flag) st.suspect++;
   if (!flag && P > 1) {
     // the kernel stitches all boundaries concurrently (speculation); any interleaving must give the same result:
@@ -50,7 +50,7 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
     for (int p : order) {
       int f, dmin, bs;
       T zs;
-      bad |= dt_stitch1<EX, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
+      bad |= dt_stitch1<EX, FZ, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[p], seg[p + 1], a, b, f, dmin, zs, bs);
       F[p] = (IT)f; DM[p] = (IT)dmin; ZS[p] = zs; BS[p] = (IT)bs;
     }
     // the validation rounds of k_dt_pass: every lane p >= 2 judges its own stitch against the F its left neighbour's speculative stitch
@@ -68,7 +68,7 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
       any = true;
       int f, bs = (int)BS[lowest];
       T zs = ZS[lowest];
-      bad |= dt_stitch_redo<EX, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[lowest], seg[lowest + 1], a, b, (int)F[lowest], f, zs, bs);
+      bad |= dt_stitch_redo<EX, FZ, T, IT>(YZ.data(), B.data(), R.data(), i2a, seg[lowest], seg[lowest + 1], a, b, (int)F[lowest], f, zs, bs);
       F[lowest] = (IT)f; ZS[lowest] = zs; BS[lowest] = (IT)bs; DM[lowest] = (IT)seg[lowest];
       st.redos++;
     }
@@ -79,7 +79,7 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
   if (flag) {                      // fallback: the whole line sequentially, IEEE divisions
     P = 1;
     seg[1] = len;
-    dt_seg_scan<true, T, IT>(YZ.data(), B.data(), R.data(), i2a, 0, len, a, b);
+    dt_seg_scan<true, false, T, IT>(YZ.data(), B.data(), R.data(), i2a, 0, len, a, b);
   }
   F[0] = 0;
   for (int p = 0; p < P; ++p) { BELOW[p] = B[F[p]]; ZLO[p] = YZ[F[p]].y; }   // one lane per segment in the kernel
@@ -93,7 +93,8 @@ static void run_line(const T* src, int len, int lanes, double a, double b, int o
       const T fos = (T)osq;
       while (!(YZ[e].y < fos)) e = (int)B[e];
       const int d = osq - e;
-      dst[q] = (T)(a * (double)(d * d) + b * (double)d + (double)YZ[e].x);
+      const double dd = (double)d, ad2 = a * (dd * dd);
+      dst[q] = (T)((FZ ? fma(b, dd, ad2) : (ad2 + b * dd)) + (double)YZ[e].x);
       ptr[q] = e;
     }
   }
@@ -131,21 +132,33 @@ static int sweep(long nlines, unsigned seed) {
       src[i] = (T)v;
     }
     static const double as[] = {1.0, 0.5, 0.25, 0.05, 0.03125, 0.01, 0.007, 0.003, 0.0005, 0.0001};   // the last two: weak curvature, a peak dominates several segments
-    const double a = -(double)(float)(rng() % 3 == 0 ? as[rng() % 10] : 0.005 + 0.045 * ud(rng));
-    const double b = -(double)(float)(rng() % 3 == 0 ? 0.0 : (ud(rng) * 0.02 - 0.01) * (rng() % 4 == 0 ? 5 : 1));
+    // the model's weights are floats (fused arithmetic allowed for float maps: every second such line runs it); one line in eight gets quadratics
+    // that are NOT converted floats (pbd_dt2d's caller may hand in any double): unfused only
+    const bool anyd = rng() % 8 == 0;
+    const double a_ = rng() % 3 == 0 ? as[rng() % 10] : 0.005 + 0.045 * ud(rng);
+    const double b_ = rng() % 3 == 0 ? 0.0 : (ud(rng) * 0.02 - 0.01) * (rng() % 4 == 0 ? 5 : 1);
+    const double a = anyd ? -a_ : -(double)(float)a_;
+    const double b = anyd ? -b_ : -(double)(float)b_;
     const int os = (int)(rng() % 9) - 4;
+    const bool fz = sizeof(T) == 4 && !anyd && (it & 1);
     ref1d(src.data(), d0.data(), p0.data(), len, a, b, os);
-    if (len + 2 <= 256) run_line<T, uint8_t>(src.data(), len, lanes, a, b, os, d1.data(), p1.data(), st, (int)(it % 3));
-    else run_line<T, uint16_t>(src.data(), len, lanes, a, b, os, d1.data(), p1.data(), st, (int)(it % 3));
+    if (fz) {
+      if (len + 2 <= 256) run_line<T, uint8_t, sizeof(T) == 4>(src.data(), len, lanes, a, b, os, d1.data(), p1.data(), st, (int)(it % 3));
+      else run_line<T, uint16_t, sizeof(T) == 4>(src.data(), len, lanes, a, b, os, d1.data(), p1.data(), st, (int)(it % 3));
+      st.fused++;
+    } else {
+      if (len + 2 <= 256) run_line<T, uint8_t, false>(src.data(), len, lanes, a, b, os, d1.data(), p1.data(), st, (int)(it % 3));
+      else run_line<T, uint16_t, false>(src.data(), len, lanes, a, b, os, d1.data(), p1.data(), st, (int)(it % 3));
+    }
     for (int i = 0; i < len; ++i)
       if (memcmp(&d0[i], &d1[i], sizeof(T)) || p0[i] != p1[i]) {
-        fprintf(stderr, "MISMATCH T%zu len %d lanes %d kind %d a %g b %g os %d at %d: ref (%g,%d) got (%g,%d)\n", sizeof(T), len, lanes,
+        fprintf(stderr, "MISMATCH T%zu fused %d len %d lanes %d kind %d a %g b %g os %d at %d: ref (%g,%d) got (%g,%d)\n", sizeof(T), (int)fz, len, lanes,
                 kind, a, b, os, i, (double)d0[i], p0[i], (double)d1[i], p1[i]);
         return 1;
       }
   }
   printf("T=%s: %ld lines bit-identical to the sequential reference (%ld redone for a suspect quotient, %ld for a lost stitch invariant; "
-         "%ld lines had a speculative stitch re-done, %ld redos)\n", sizeof(T) == 4 ? "float" : "double", st.lines, st.suspect, st.inconsistent, st.events, st.redos);
+         "%ld lines had a speculative stitch re-done, %ld redos; %ld lines with the fused arithmetic)\n", sizeof(T) == 4 ? "float" : "double", st.lines, st.suspect, st.inconsistent, st.events, st.redos, st.fused);
   return 0;
 }
 
