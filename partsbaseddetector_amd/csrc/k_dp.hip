@@ -194,7 +194,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   constexpr bool EX = sizeof(T) == 8;          // DistanceTransform<double>: s is not narrowed, every intersection takes the IEEE division
   // float maps whose weights are converted floats on lines of at most DT_FUSE_MAXLEN elements (every map of a detector; the planner says so per
   // group): the numerator's products are exact, so they fuse into their additions (dt_core.hpp: dt_isect, FUSED) — block-uniform
-  const bool fz = !EX && g.fused != 0;
+  const bool fz = !EX && (g.fused & DT_G_FUSED) != 0;
   const T** lptr = (const T**)smem;            // [lpb] source pointer of each line of this block (plain)
   int* FLAG = (int*)(smem + lpb * 8);          // [lpb] per line: redo sequentially (suspect quotient / lost stitch invariant)
   int* FIX = FLAG + lpb;                       // [lpb] per line: the lowest stale boundary of the line in an even validation round
@@ -454,7 +454,11 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   if (mine) {
     const double a = mp.a, b = mp.b;
     // pointers: transposed like dst (y pass -> natural layout) or natural (x pass)
+#ifdef PBD_NAT_FROM_MAP   // (A/B builds: the form before round 6's session 31)
     const bool nat = mp.ptr_natural != 0;
+#else
+    const bool nat = (g.fused & DT_G_NATURAL) != 0;   // (= mp.ptr_natural, uniform over a group: DtGroup::fused)
+#endif
     int16_t* pp = mp.ptr + (nat ? (size_t)li * len : (size_t)li);
     const int pst = nat ? 1 : g.nlines;
     const int chunk = g.chunk;                   // ceil(len / nsub)
@@ -513,11 +517,24 @@ __global__ __launch_bounds__(256, 3) void k_dt_pass(const DtTask* __restrict__ t
 #endif
   DT_STAMP(0);
   DT_TRACE(0);
+#if PBD_DT_TASK_PREFETCH > 0 && defined(__HIP_DEVICE_COMPILE__)
+  // Touch the descriptor of the block PBD_DT_TASK_PREFETCH tasks ahead (same XCD for a multiple of 8) so that ITS scalar fetch — the first of a block's
+  // dependent memory round trips (descriptor -> lines) — finds the line in this XCD's L2.  A VECTOR load (an outstanding scalar load would be waited for
+  // together with the block's own descriptor); the zero offset passes through an empty, non-volatile asm: a volatile one makes hipcc fetch every descriptor
+  // with vector loads (it counts as a clobber of memory).  Round 6, sessions 30 / 31: 64 ... 256 ahead +0.1 ... 1 % frames/s, -0.4 % for a frame alone; 1 024 ahead: nothing
+  // (the line does not survive in the L2 that long)
+  unsigned pf_off = 0;
+  asm("" : "+v"(pf_off));
+  const unsigned pf_val = *(const unsigned*)((const char*)(tasks + min(blockIdx.x + (unsigned)PBD_DT_TASK_PREFETCH, gridDim.x - 1u)) + pf_off);
+#endif
   const DtTask t = tasks[blockIdx.x];
   const DtGroup& g = t.g;
   if (g.stride <= 256) dt_block<T, unsigned char, FM>(smem, t, g, maps, folds, biasw);    // stack indices < 255 fit a byte
   else dt_block<T, unsigned short, FM>(smem, t, g, maps, folds, biasw);
   DT_TRACE(1);
+#if PBD_DT_TASK_PREFETCH > 0 && defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" :: "v"(pf_val));   // (keeps the load alive)
+#endif
 }
 
 template <typename T, int FM>

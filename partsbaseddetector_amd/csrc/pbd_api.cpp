@@ -478,7 +478,7 @@ static void dt_add_tasks(const DtGroup& g, std::vector<DtTask>& out, const std::
 }
 // DtGroup::fused (dt_core.hpp: dt_isect's FUSED form, the read-out's fused sum): float maps whose a and b are converted floats — the model's
 // weights always (dt_map), pbd_dt2d's caller may hand in any double — on lines short enough for the products to be exact in fp64
-static void dt_mark_fused(std::vector<DtTask>& tasks, const DtMap* maps, int ts) {
+static void dt_mark_fused(std::vector<DtTask>& tasks, const DtMap* maps, int ts) {   // (and the group's pointer layout: DT_G_NATURAL)
   for (DtTask& t : tasks) {
     DtGroup& g = t.g;
     bool ok = ts == 4 && g.len <= DT_FUSE_MAXLEN;
@@ -486,7 +486,8 @@ static void dt_mark_fused(std::vector<DtTask>& tasks, const DtMap* maps, int ts)
       const DtMap& mp = maps[g.map0 + m];
       ok = (double)(float)mp.a == mp.a && (double)(float)mp.b == mp.b && (long long)g.len + std::abs((long long)mp.os) <= DT_FUSE_MAXLEN;
     }
-    g.fused = ok ? 1 : 0;
+    // (the pointer layout is a property of the pass: every map of a group has the same)
+    g.fused = (ok ? DT_G_FUSED : 0) | (g.nmaps > 0 && maps[g.map0].ptr_natural ? DT_G_NATURAL : 0);
   }
 }
 static DtMap dt_map(const void* src, void* dst, int16_t* ptr, float wq, float wl, int os, int natural) {

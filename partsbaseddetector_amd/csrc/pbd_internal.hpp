@@ -71,9 +71,14 @@ struct DtGroup {
   unsigned magic_lpb;        // lane / lpb              (lane < 2^8)
   unsigned magic_nlines;     // (l0 + lane) / nlines    (numerator < nlines + 2^8, nlines < 2^15)
   unsigned magic_P;          // (p * len) / P           (p * len < 2^21, P <= 64)
-  int fused;                 // float maps only: every map of the group has weights that are converted floats, len and len + |os| <= DT_FUSE_MAXLEN: the
-                             // intersection's and the read-out's products are exact and fuse into their additions (dt_core.hpp: dt_isect)
+  int fused;                 // bit 0 — float maps only: every map of the group has weights that are converted floats, len and len + |os| <= DT_FUSE_MAXLEN: the
+                             // intersection's and the read-out's products are exact and fuse into their additions (dt_core.hpp: dt_isect);
+                             // bit 1 — the group's maps write their pointers in natural layout (DtMap::ptr_natural of every map of the group: x passes): the
+                             // block reads it HERE — from the lane's map descriptor hipcc evaluated it right behind the descriptor's load, a full memory round
+                             // trip in front of the loader of every block
 };
+#define DT_G_FUSED 1
+#define DT_G_NATURAL 2
 struct DtTask { int g0, nl, m0, l0; DtGroup g;     // g0: first line (plain) / first row (fold); nl: lines of this block; plain: g0 = m0 * nlines + l0
                                                     // (first map of the block, first line inside it); the group travels with the task
   const void* src0; };                              // plain: the block's first line when its nl lines are CONTIGUOUS in memory (consecutive maps of a group
@@ -84,6 +89,9 @@ static inline unsigned dt_magic(unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1
 #endif
 #ifndef PBD_DT_PRIO
 #define PBD_DT_PRIO 1            // s_setprio of k_dt_pass's wavefronts (k_dp.hip)
+#endif
+#ifndef PBD_DT_TASK_PREFETCH
+#define PBD_DT_TASK_PREFETCH 256 // k_dt_pass touches the task descriptor this many blocks ahead (k_dp.hip; 0: off)
 #endif
 #ifndef PBD_DT_NT_DEFAULT
 #define PBD_DT_NT_DEFAULT 128   // lanes of a k_dt_pass block
