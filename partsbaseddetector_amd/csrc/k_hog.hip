@@ -165,34 +165,50 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
     const int nword = RT * wpr;
     const int rowbytes = stride;                      // bytes of a source row
     const int b00 = rx0 * bpp;                        // source byte of the raw row's first byte (may be negative)
-    constexpr int LBW = 4;                            // words in flight per thread and batch
-    for (int i0 = tid; i0 < nword; i0 += HOG_NT * LBW) {
-      unsigned wv[LBW];
-      int ok[LBW], la[LBW];
+    // Every word comes from ONE unaligned 4-byte load at an address clamped into the source row, and a word that straddles an end of the row is shifted
+    // into place: its bytes outside the row hold whatever the shift brings in — never read (above).  No branch per word: round 6 found the first form
+    // (`inside the row ? one load : four byte loads`) compiled to a wait behind EVERY load — a block's 13 words per thread were 13 memory round trips in a
+    // row, a third of the block's time.  Positions past the tile's last word repeat it (the same value stored again).
+    constexpr int LBW = 7;                            // words in flight per thread and batch (16 x 16-cell tiles of 8-bit BGR: 13 words per thread, two batches)
+    if (rowbytes >= 4) {
+      // (word i -> (raw row, word of the row) by a multiply-high: i * wpr < 2^32; the LDS address and the shift are worked out again behind the loads instead
+      //  of waiting in registers: the kernel shares its SIMDs with the other batches' distance transforms and filter bank, whose wavefronts need the registers —
+      //  with 60 instead of 32 registers per lane the stage was 6 % faster and the three-batch pipeline 1 % slower, session 32)
+      const unsigned wmagic = 0xFFFFFFFFu / (unsigned)wpr + 1u;
+      auto place = [&](int i, int& b0, int& la) {
+        const int r = wpr > 1 ? (int)__umulhi((unsigned)i, wmagic) : i, k = i - r * wpr;
+        b0 = b00 + 4 * k;
+        la = r * RP + 4 * k;
+        return min(max(ry0 + r, 0), h - 1);
+      };
+      for (int i0 = tid; i0 < nword; i0 += HOG_NT * LBW) {
+        unsigned wv[LBW];
 #pragma unroll
-      for (int j = 0; j < LBW; ++j) {
-        const int i = min(i0 + j * HOG_NT, nword - 1);
+        for (int j = 0; j < LBW; ++j) {
+          int b0, la;
+          const int sy = place(min(i0 + j * HOG_NT, nword - 1), b0, la);
+          wv[j] = *(const __attribute__((aligned(1))) unsigned*)(im + (size_t)sy * stride + min(max(b0, 0), rowbytes - 4));
+        }
+#pragma unroll
+        for (int j = 0; j < LBW; ++j) {
+          int b0, la;
+          place(min(i0 + j * HOG_NT, nword - 1), b0, la);
+          const int sh = min(max(b0, 0), rowbytes - 4) - b0;   // > 0: the word begins in front of the row; < 0: it ends behind it; |sh| >= 4: no byte of it lies in the row
+          const int a8 = 8 * min(abs(sh), 3);
+          *(unsigned*)(raw + la) = sh > 0 ? wv[j] << a8 : wv[j] >> a8;
+        }
+      }
+    } else {                                          // a source row shorter than a word (1-3 bytes): byte by byte
+      for (int i = tid; i < nword; i += HOG_NT) {
         const int r = i / wpr, k = i - r * wpr;
         const int sy = min(max(ry0 + r, 0), h - 1);
         const int b0 = b00 + 4 * k;
-        ok[j] = (b0 >= 0 && b0 + 3 < rowbytes) ? 1 : 0;
         const uint8_t* src = im + (size_t)sy * stride;
-        la[j] = r * RP + 4 * k;
-        if (ok[j]) {
-          wv[j] = *(const __attribute__((aligned(1))) unsigned*)(src + b0);
-        } else {
-          unsigned v = 0;
+        unsigned v = 0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int b = min(max(b0 + q, 0), rowbytes - 1);
-            v |= (unsigned)src[b] << (8 * q);
-          }
-          wv[j] = v;
-        }
+        for (int q = 0; q < 4; ++q) v |= (unsigned)src[min(max(b0 + q, 0), rowbytes - 1)] << (8 * q);
+        *(unsigned*)(raw + r * RP + 4 * k) = v;
       }
-#pragma unroll
-      for (int j = 0; j < LBW; ++j)
-        if (i0 + j * HOG_NT < nword) *(unsigned*)(raw + la[j]) = wv[j];
     }
   }
   // ---- interpolation tables per window row / column (:252-260) ----
