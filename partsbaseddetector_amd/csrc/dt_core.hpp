@@ -220,8 +220,15 @@ DT_HD bool dt_stitch1(DtPair<T>* __restrict__ YZ, IT* __restrict__ B, const doub
     // no lane of the wavefront needs it.
     const bool cheap = testf && bf != q;
     T s = qz.y;
+    const double rdx = EXACT ? 0.0 : RDX[q - e];
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    // the intersection's operands are fetched with the rest of the iteration's LDS reads: hipcc sinks reads that only the branch below uses INTO the
+    // branch — a second LDS round trip in every iteration in which any lane of the wavefront needs the arithmetic (almost every one).  The empty asm
+    // pins them here (round 6, session 35: dp_min of a frame alone 0.515 -> 0.502 ms, 0.298 -> 0.295 in batches)
+    if constexpr (EXACT) asm volatile("" :: "v"(ez.x), "v"(qz.x));
+    else asm volatile("" :: "v"(ez.x), "v"(qz.x), "v"(rdx));
+#endif
     if (DT_ANY(!cheap)) {
-      const double rdx = EXACT ? 0.0 : RDX[q - e];
       const T si = dt_isect<EXACT, FUSED, T>(ez.x, e, qz.x, q, a, b, twoa, i2a, rdx, suspect);   // (a lane that does not need it may flag itself: harmless)
       s = cheap ? s : si;
     }
