@@ -94,10 +94,22 @@ size_t dt_lds_bytes(int stride, int lpb, int ts, int nt) {   // ts = sizeof(T): 
 // block of the child (wave-uniform: scalar loads) is fetched in one straight-line batch — a load inside a (uniform)
 // branch costs one full scalar-memory round trip per branch, which is what made a first version's loader 5x slower
 // than the plain one.  Everything below is branch-free except the loop over the children.
+// A child's plane pointers wait in a VECTOR register, one quad-word per lane (lane k < 8: sdt[k], lanes >= 8: ok), and come out by v_readlane where they are
+// used: fetched by scalar loads at their use (rounds 3-5) every child began with a memory round trip of its own — descriptor -> pointers -> planes —, and
+// fetched early by scalar loads they do not fit the scalar register file beside the bias block (hipcc then serialises the loads, one wait each: tried).  The
+// caller fetches child 0's with whatever else it reads from descriptors; child c + 1's are fetched behind child c's vector loads.  Every lane of the
+// wavefront must be active where fold_child_qw runs.
+static_assert(offsetof(FoldChild, ok) == 8 * PBD_FOLD_MAXMIX && PBD_FOLD_MAXMIX == 8, "fold_child_qw: sdt[8] then ok");
+__device__ __forceinline__ unsigned long long fold_child_qw(const FoldChild* C) {
+  return ((GP(unsigned long long))C)[min((int)(threadIdx.x & 63u), 8)];
+}
+__device__ __forceinline__ GP(char) fold_qw_lane(unsigned long long v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return (GP(char))(((unsigned long long)hi << 32) | lo);
+}
 template <typename T, int M, int U>
 __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, const float* __restrict__ /*biasw*/, const unsigned (&off)[U],
-                                              unsigned HW, int L, T (&acc)[U][M]) {
-  const int nch = J->nch;
+                                              unsigned HW, int L, T (&acc)[U][M], unsigned long long cv, int nch) {   // nch = J->nch (k_dt_pass has it from the task's extension record)
   unsigned ob[U];                                        // byte offsets of the cells inside a plane of T (< 2^32, plan_frame)
 #pragma unroll
   for (int u = 0; u < U; ++u) ob[u] = off[u] * (unsigned)sizeof(T);
@@ -107,7 +119,7 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
     const FoldChild& C = J->ch[c];
     // everything the child contributes is fetched up front, in straight-line code: the K planes' values of the U
     // cells (uniform base + 32-bit byte offset: no vector arithmetic per load) and the dense K x L bias block
-    GPW(uint8_t) okp = (GPW(uint8_t))C.ok;
+    GPW(uint8_t) okp = (GPW(uint8_t))fold_qw_lane(cv, 8);
     T sd[U][M];
     // (the offsets pass through an empty asm: hoisted out of the loop over the children they would be kept zero-extended to
     // 64 bits, and every load / store would pay a 64-bit vector add instead of using the scalar-base + 32-bit-offset form)
@@ -121,10 +133,11 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
     }
 #pragma unroll
     for (int k = 0; k < M; ++k) {
-      GP(char) pl = (GP(char))C.sdt[k];                  // entries beyond K repeat plane K - 1 (plan): never predicated
+      GP(char) pl = fold_qw_lane(cv, k);                 // entries beyond K repeat plane K - 1 (plan): never predicated
 #pragma unroll
       for (int u = 0; u < U; ++u) sd[u][k] = *(GP(T))(pl + obc[u]);
     }
+    cv = fold_child_qw(&J->ch[min(c + 1, nch - 1)]);      // the next child's pointers (after the last child: its own again, unused)
     float bias[M][M];
     // (wave-uniform: scalar loads.  Fetching the block with vector loads instead — it overflows the scalar register file and
     // part of it is spilled to vector-register lanes — was measured 9 % slower per fold launch: twelve more vector-memory
@@ -185,7 +198,8 @@ __device__ __forceinline__ void fold_children(const FoldJob* __restrict__ J, con
 // raw responses and its children's messages (fold_children).
 template <typename T, typename IT, int FM>   // FM: 0 = plain lines, else fold with at most FM mixtures per part
 __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGroup& g, const DtMap* __restrict__ maps,
-                                         const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
+                                         const FoldJob* __restrict__ folds, const float* __restrict__ biasw,
+                                         unsigned long long rawq, unsigned long long c0qw) {   // FOLD: the task's extension record, one quad-word per lane (k_dt_pass)
 
   constexpr bool FOLD = FM > 0;
   const int lane = threadIdx.x, NT = blockDim.x;
@@ -258,7 +272,8 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
   DtMap mp;
   P2* YZl = YZ + line * S;
   IT* Bl = B + line * S;
-  if (mine) mp = maps[g.map0 + mi];
+  mp = maps[g.map0 + mi];   // (every lane — lanes without a line read map 0 of the group —: behind an `if (mine)` the wait for the fold's extension record, at the
+                            //  join of the two paths, also waited for these loads — a memory round trip in front of the loader)
   if (!FOLD && !contig) __syncthreads();
   DT_STAMP(1);
   if constexpr (FOLD) {
@@ -269,9 +284,13 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
     const FoldJob* J = folds + g.fold;
     const int L = g.nmaps;
     const unsigned HW = (unsigned)g.nlines * (unsigned)len;     // cells of the level (< 2^31, plan_frame)
-    const void* srcp[M];
+    // the part's raw response planes (entries beyond L repeat plane L - 1) and the first child's plane pointers (c0qw: fold_children) come from the task's
+    // extension record, fetched by k_dt_pass BESIDE the task descriptor: the loader's first loads are one memory round trip behind the kernel's entry, not
+    // three (descriptor -> map table / fold job -> planes; round 6)
+    GP(char) srcp[M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) srcp[m] = maps[g.map0 + (m < L ? m : L - 1)].src;   // the part's raw response planes
+    for (int m = 0; m < M; ++m) srcp[m] = fold_qw_lane(rawq, m);
+    const int nch0 = __builtin_amdgcn_readlane((int)(unsigned)c0qw, 9);   // FoldJob::nch
     const int n = nrows * len;
     // the block's cells are rows t.g0 .. t.g0 + nrows - 1 of the level: CONTIGUOUS in every plane, cell ec of the block at
     // plane offset t.g0 * len + ec (no division for the loads); its (row, column) — the LDS slot — by multiply-high
@@ -287,7 +306,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         off[u] = cell0 + (unsigned)ec;
         const unsigned obu = off[u] * (unsigned)sizeof(T);             // byte offset inside a plane (< 2^32, plan_frame): uniform base + 32-bit offset
 #pragma unroll
-        for (int m = 0; m < M; ++m) acc[u][m] = *(GP(T))((GP(char))srcp[m] + obu);
+        for (int m = 0; m < M; ++m) acc[u][m] = *(GP(T))(srcp[m] + obu);
         const int jj = len > 1 ? (int)__umulhi((unsigned)ec, magic) : ec;
         slot[u] = __mul24(jj, S) + (ec - __mul24(jj, len));        // LDS element of mixture 0's line of that row
       }
@@ -298,7 +317,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         if (e0 == 0)
           for (int dx = lane; dx < len; dx += NT) RDX[dx] = 1.0 / (double)dx;   // entry 0 is never read
       }
-      fold_children<T, M, U>(J, biasw, off, HW, L, acc);
+      fold_children<T, M, U>(J, biasw, off, HW, L, acc, c0qw, nch0);
       const int mstride = nrows * S;                                 // LDS elements between the lines of consecutive mixtures of a row
       // (unpredicated like the plain loader: a lane past the last cell holds the last cell's values and stores them once more.  Round 6
       //  measured the alternative — wavefronts whose slot holds clamped repeats only skip the mixture reduce —: 0.7 % faster alone, 1.6 %
@@ -505,7 +524,8 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
 //  the fold loader fetching the next child's planes under this child's arithmetic: 0.333-0.344 against 0.337-0.342, 0.585-0.588 against 0.581 alone)
 template <typename T, int FM>
 __global__ __launch_bounds__(256, 3) void k_dt_pass(const DtTask* __restrict__ tasks, const DtMap* __restrict__ maps,
-                                                    const FoldJob* __restrict__ folds, const float* __restrict__ biasw) {
+                                                    const FoldJob* __restrict__ folds, const float* __restrict__ biasw,
+                                                    const unsigned long long* __restrict__ foldx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // Issue priority 1 for the whole block (round 6): where a distance-transform wavefront shares a SIMD with wavefronts of another batch's filter
   // bank (priority 0: they wait for the matrix pipe most of the time) or HOG kernel, its vector instructions go first — the DP chain is the longest
@@ -527,10 +547,19 @@ __global__ __launch_bounds__(256, 3) void k_dt_pass(const DtTask* __restrict__ t
   asm("" : "+v"(pf_off));
   const unsigned pf_val = *(const unsigned*)((const char*)(tasks + min(blockIdx.x + (unsigned)PBD_DT_TASK_PREFETCH, gridDim.x - 1u)) + pf_off);
 #endif
+  // fold launches: the task's extension record (PBD_FOLDX_QW quad-words: raw plane pointers [8], first child's plane pointers [8], its Ik base, the number of children), lane l holding
+  // quad-word l of each half — vector loads whose address depends on blockIdx only, in flight together with the scalar fetch of the task
+  unsigned long long rawq = 0, c0qw = 0;
+  if constexpr (FM > 0) {
+    GP(unsigned long long) fx = (GP(unsigned long long))foldx + (size_t)blockIdx.x * PBD_FOLDX_QW;
+    const int l = (int)(threadIdx.x & 63u);
+    rawq = fx[min(l, 7)];
+    c0qw = fx[8 + min(l, 9)];
+  }
   const DtTask t = tasks[blockIdx.x];
   const DtGroup& g = t.g;
-  if (g.stride <= 256) dt_block<T, unsigned char, FM>(smem, t, g, maps, folds, biasw);    // stack indices < 255 fit a byte
-  else dt_block<T, unsigned short, FM>(smem, t, g, maps, folds, biasw);
+  if (g.stride <= 256) dt_block<T, unsigned char, FM>(smem, t, g, maps, folds, biasw, rawq, c0qw);    // stack indices < 255 fit a byte
+  else dt_block<T, unsigned short, FM>(smem, t, g, maps, folds, biasw, rawq, c0qw);
   DT_TRACE(1);
 #if PBD_DT_TASK_PREFETCH > 0 && defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" :: "v"(pf_val));   // (keeps the load alive)
@@ -538,7 +567,7 @@ __global__ __launch_bounds__(256, 3) void k_dt_pass(const DtTask* __restrict__ t
 }
 
 template <typename T, int FM>
-static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw,
+static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const unsigned long long* foldx, const float* biasw,
                              size_t lds, int nt, hipStream_t s) {
   static LdsOptIn optin;   // one per instantiation, per-device state inside
   optin.ensure((const void*)k_dt_pass<T, FM>, lds);
@@ -546,25 +575,25 @@ static void launch_dt_pass_t(const DtTask* tasks, int ntasks, const DtMap* maps,
   static const bool tracing = getenv("PBD_DT_TRACE") != nullptr;
   if (tracing) { static int seqs[4096]; const int seq = g_dt_trace_seq++; seqs[seq & 4095] = seq; hipMemcpyToSymbolAsync(HIP_SYMBOL(pbd_dt_trace_launch), &seqs[seq & 4095], sizeof(int), 0, hipMemcpyHostToDevice, s); }
 #endif
-  hipLaunchKernelGGL((k_dt_pass<T, FM>), dim3(ntasks), dim3(nt), lds, s, tasks, maps, folds, biasw);
+  hipLaunchKernelGGL((k_dt_pass<T, FM>), dim3(ntasks), dim3(nt), lds, s, tasks, maps, folds, biasw, foldx);
 }
 template <typename T>
-static void launch_dt_pass_m(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw,
+static void launch_dt_pass_m(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const unsigned long long* foldx, const float* biasw,
                              size_t lds, int nt, int fm, hipStream_t s) {
   // fold launches are instantiated for the smallest register-array bound that holds the model's mixture counts
-  if (!folds) launch_dt_pass_t<T, 0>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
-  else if (fm <= 1) launch_dt_pass_t<T, 1>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
-  else if (fm <= 4) launch_dt_pass_t<T, 4>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
-  else if (fm <= 6) launch_dt_pass_t<T, 6>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
-  else launch_dt_pass_t<T, PBD_FOLD_MAXMIX>(tasks, ntasks, maps, folds, biasw, lds, nt, s);
+  if (!folds) launch_dt_pass_t<T, 0>(tasks, ntasks, maps, folds, foldx, biasw, lds, nt, s);
+  else if (fm <= 1) launch_dt_pass_t<T, 1>(tasks, ntasks, maps, folds, foldx, biasw, lds, nt, s);
+  else if (fm <= 4) launch_dt_pass_t<T, 4>(tasks, ntasks, maps, folds, foldx, biasw, lds, nt, s);
+  else if (fm <= 6) launch_dt_pass_t<T, 6>(tasks, ntasks, maps, folds, foldx, biasw, lds, nt, s);
+  else launch_dt_pass_t<T, PBD_FOLD_MAXMIX>(tasks, ntasks, maps, folds, foldx, biasw, lds, nt, s);
 }
 // ts = sizeof(T): DistanceTransform<float> / DistanceTransform<double>; folds != nullptr: the tasks are fold blocks of a
 // model whose parts have at most fm mixtures
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw, size_t lds,
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const unsigned long long* foldx, const float* biasw, size_t lds,
                     int ts, int nt, int fm, hipStream_t s) {
   if (ntasks <= 0) return;
-  if (ts == 8) launch_dt_pass_m<double>(tasks, ntasks, maps, folds, biasw, lds, nt, fm, s);
-  else launch_dt_pass_m<float>(tasks, ntasks, maps, folds, biasw, lds, nt, fm, s);
+  if (ts == 8) launch_dt_pass_m<double>(tasks, ntasks, maps, folds, foldx, biasw, lds, nt, fm, s);
+  else launch_dt_pass_m<float>(tasks, ntasks, maps, folds, foldx, biasw, lds, nt, fm, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -673,7 +702,11 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
   const ReduceBlock rb = blocks[blockIdx.x];
   const RootJob& J = jobs[rb.job];
   const unsigned cell = rb.cell0 + threadIdx.x;
-  if (cell >= (unsigned)J.H * J.W) return;
+  const unsigned HWr = (unsigned)J.H * (unsigned)J.W;
+  const bool live = cell < HWr;
+  // (the fold keeps every lane of the block: its children's plane pointers travel in vector-register lanes — fold_child_qw —; lanes past the job's last cell
+  //  work on that cell again and store the same Ik bytes once more)
+  if (!live && (rescan || J.fold < 0)) return;
   T v;
   int bi = 0;
   const T bias = J.bias;                             // `T bias = root.bias(0)[0]` (:165)
@@ -693,10 +726,13 @@ __global__ __launch_bounds__(256) void k_root(const RootJob* __restrict__ jobs, 
     // fold mode: the root's accumulated score is built here from its raw responses and its children's messages
     constexpr int M = FM;
     T acc[1][M];
-    const unsigned offs[1] = {cell};
+    const unsigned long long c0qw = fold_child_qw(&folds[J.fold].ch[0]);
+    const unsigned cellc = live ? cell : HWr - 1u;
+    const unsigned offs[1] = {cellc};
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[0][m] = ((GP(T))J.score[m])[cell];       // (entries beyond K repeat mixture K - 1: plan_frame)
-    fold_children<T, M, 1>(folds + J.fold, biasw, offs, (unsigned)J.H * (unsigned)J.W, K, acc);
+    for (int m = 0; m < M; ++m) acc[0][m] = ((GP(T))J.score[m])[cellc];      // (entries beyond K repeat mixture K - 1: plan_frame)
+    fold_children<T, M, 1>(folds + J.fold, biasw, offs, HWr, K, acc, c0qw, folds[J.fold].nch);
+    if (!live) return;
     if (K == 1) {
       v = acc[0][0] + bias;
     } else {

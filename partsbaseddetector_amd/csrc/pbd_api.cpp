@@ -720,6 +720,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1, int 
   std::vector<DtMap> maps;
   std::vector<DtTask> tasks;
   std::vector<FoldJob> folds;
+  std::vector<unsigned long long> foldx;               // pbd_handle::d_foldx
   std::vector<ReduceJob> red;
   std::vector<ReduceBlock> redblk;
   h->rl.clear();
@@ -895,6 +896,16 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1, int 
     xcd_order(yt);
     R.lds_x = launch_lds(xt, fold_x ? h->dt_nt_x : h->dt_nt); R.lds_y = launch_lds(yt, h->dt_nt); R.fold_x = fold_x ? 1 : 0;
     if (dbg_plan) fprintf(stderr, "plan: round %zu: %zu x blocks (%zu B LDS%s), %zu y blocks (%zu B)\n", r, xt.size(), R.lds_x, fold_x ? ", fold" : "", yt.size(), R.lds_y);
+    if (fold_x) {   // the loader's first addresses of every fold x task, in task order (pbd_handle::d_foldx)
+      R.foldx0 = foldx.size();
+      for (const DtTask& t : xt) {
+        const DtGroup& g = t.g;
+        for (int mm = 0; mm < 8; ++mm) foldx.push_back((unsigned long long)(uintptr_t)maps[(size_t)g.map0 + std::min(mm, g.nmaps - 1)].src);
+        const unsigned long long* cq = (const unsigned long long*)&folds[(size_t)g.fold].ch[0];   // sdt[8], ok (k_dp.hip: fold_child_qw)
+        for (int i = 0; i < 9; ++i) foldx.push_back(cq[i]);
+        foldx.push_back((unsigned long long)folds[(size_t)g.fold].nch);
+      }
+    }
     R.xtask0 = (int)tasks.size(); R.nxtasks = (int)xt.size();
     tasks.insert(tasks.end(), xt.begin(), xt.end());
     R.ytask0 = (int)tasks.size(); R.nytasks = (int)yt.size();
@@ -978,6 +989,7 @@ static int plan_frame(pbd_handle* h, int w, int hgt, int cn, int batch = 1, int 
   if ((rc = dev_upload(h, &h->d_dtmaps, maps))) return rc;
   if ((rc = dev_upload(h, &h->d_dttasks, tasks))) return rc;
   if ((rc = dev_upload(h, &h->d_foldjobs, folds))) return rc;
+  if ((rc = dev_upload(h, &h->d_foldx, foldx))) return rc;
   if ((rc = dev_upload(h, &h->d_redjobs, red))) return rc;
   if ((rc = dev_upload(h, &h->d_redblocks, redblk))) return rc;
   h->n_rootjobs = (int)rj.size();
@@ -1101,8 +1113,8 @@ static int run_dp_min(pbd_handle* h) {
   // messages) + y pass per round, the root's messages folded by k_root: 2 * rounds + 1 launches; legacy (models that
   // alias a filter id inside a component, or more than 8 mixtures): + the round's reduce launches.
   for (auto& R : h->rl) {
-    launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, R.fold_x ? h->d_foldjobs : nullptr, h->d_biasw, R.lds_x, h->ts, R.fold_x ? h->dt_nt_x : h->dt_nt, h->fold_mix, h->stream);
-    launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, nullptr, h->d_biasw, R.lds_y, h->ts, h->dt_nt, 0, h->stream);
+    launch_dt_pass(h->d_dttasks + R.xtask0, R.nxtasks, h->d_dtmaps, R.fold_x ? h->d_foldjobs : nullptr, R.fold_x ? h->d_foldx + R.foldx0 : nullptr, h->d_biasw, R.lds_x, h->ts, R.fold_x ? h->dt_nt_x : h->dt_nt, h->fold_mix, h->stream);
+    launch_dt_pass(h->d_dttasks + R.ytask0, R.nytasks, h->d_dtmaps, nullptr, nullptr, h->d_biasw, R.lds_y, h->ts, h->dt_nt, 0, h->stream);
     for (auto& Wv : R.waves)
       launch_reduce(h->d_redjobs, h->d_redblocks + Wv.blk0, Wv.nblks, h->d_biasw, h->opt.dt_correct_ptr, h->ts, h->stream);
   }
@@ -2008,9 +2020,9 @@ static int dt2d_(pbd_handle* h, const void* in, int rows, int cols, double ax, d
   HIPCHK(h, hipMemcpyAsync(d_maps, maps, sizeof(maps), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_tasks, tasks.data(), sizeof(DtTask) * tasks.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host staging buffers above are pageable
-  launch_dt_pass(d_tasks, nx, d_maps, nullptr, h->d_biasw, budget, tsz, nt, 0, h->stream);
+  launch_dt_pass(d_tasks, nx, d_maps, nullptr, nullptr, h->d_biasw, budget, tsz, nt, 0, h->stream);
   if (PBD_PROBE_ENV("PBD_DEBUG_SKIP_Y")) { hipMemsetAsync(d_sdt, 0, HW * ts, h->stream); hipMemsetAsync(d_iy, 0, HW * 2, h->stream); }   // probe build: leave the x pass as the last DT launch (its stamps are then readable)
-  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_maps, nullptr, h->d_biasw, budget, tsz, nt, 0, h->stream);
+  else launch_dt_pass(d_tasks + nx, (int)tasks.size() - nx, d_maps, nullptr, nullptr, h->d_biasw, budget, tsz, nt, 0, h->stream);
   std::vector<int16_t> hx(HW), hy(HW);
   HIPCHK(h, hipMemcpyAsync(out, d_sdt, HW * ts, hipMemcpyDeviceToHost, h->stream));   // the y pass's scores, untouched
   HIPCHK(h, hipMemcpyAsync(hx.data(), d_ixT, HW * 2, hipMemcpyDeviceToHost, h->stream));   // the passes' own pointers

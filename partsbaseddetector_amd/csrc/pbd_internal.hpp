@@ -108,6 +108,7 @@ struct ReduceChild {     // one child part's distance-transformed mixtures
 };
 // fold mode: the children of one (level, part), descending child index (src/DynamicProgram.cpp:95); read by the loader
 // of the part's x pass (k_dt_pass<T, true>) and, for a root, by k_root
+#define PBD_FOLDX_QW 18     // quad-words of a fold x task's extension record (pbd_handle::d_foldx)
 #define PBD_FOLD_MAXMIX 8   // fold mode keeps one value per parent mixture / child mixture in registers: K, L <= 8
 struct FoldChild {
   const void* sdt[PBD_FOLD_MAXMIX];   // T [H][W]: distance-transformed scores of child mixture k (one pointer per plane: the planes may
@@ -223,12 +224,16 @@ struct pbd_handle {
   DtMap* d_dtmaps = nullptr; DtTask* d_dttasks = nullptr;   // a task carries its group descriptor
   ReduceJob* d_redjobs = nullptr; ReduceBlock* d_redblocks = nullptr; RootJob* d_rootjobs = nullptr; BackLevel* d_back = nullptr;
   struct ReduceWave { int blk0, nblks; };
-  struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; size_t lds_x, lds_y; int fold_x; std::vector<ReduceWave> waves; };
+  struct RoundLaunch { int xtask0, nxtasks, ytask0, nytasks; size_t lds_x, lds_y; int fold_x; std::vector<ReduceWave> waves;
+                       size_t foldx0 = 0; };             // fold x launch: its first record in d_foldx (PBD_FOLDX_QW quad-words per task)
   size_t dt_lds = 0;                                 // LDS budget of a k_dt_pass block in the fullest launch of a frame (thinner launches get less)
   bool unique_filters = false;                       // every filter id belongs to exactly one (component, part, mixture)
   bool compact = false;                              // memory plan of the current frame geometry (plan_frame)
   bool fold = false;                                 // DP structure of this handle: messages folded by the parent's x pass (no k_reduce, no acc planes)
   FoldJob* d_foldjobs = nullptr;
+  unsigned long long* d_foldx = nullptr;             // per fold x task, in task order: the part's raw plane pointers [8] + the first child's plane pointers [8] + its Ik base + the number of children: what
+                                                     // the block's loader needs for its first loads, at an address that depends on blockIdx only (k_dt_pass fetches it beside the
+                                                     // task descriptor instead of behind it)
   int fold_mix = 0;                                  // largest mixture count of a part (the fold kernels' register-array bound)
   int dt_nt = PBD_DT_NT_DEFAULT;                                   // lanes of a k_dt_pass block (64 or 128)
   int dt_nt_x = PBD_DT_NT_DEFAULT;                                 // lanes of a fold x-pass block
@@ -352,7 +357,7 @@ void launch_conv_glds_f32(const ConvTile* tiles, int ntiles, const LevelDev* lev
                           float* resp, int nf, int nfpad, const float* border, int wg_per_cu, int ncu, hipStream_t s);
 void launch_conv_mfma16_f32(const ConvTile* tiles, int ntiles, const LevelDev* levels, const float* feat,
                             const float* wT, const float* w4u, float* resp, int nf, int nfpad, int nhalf, hipStream_t s, int kh, int kw);
-void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const float* biasw, size_t lds,
+void launch_dt_pass(const DtTask* tasks, int ntasks, const DtMap* maps, const FoldJob* folds, const unsigned long long* foldx, const float* biasw, size_t lds,
                     int ts, int nt, int fm, hipStream_t s);
 size_t dt_lds_bytes(int stride, int lpb, int ts, int nt);
 void launch_reduce(const ReduceJob* jobs, const ReduceBlock* blocks, int nblocks, const float* biasw, int correct_ptr,
