@@ -488,12 +488,17 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
       int e = dt_cover<T, IT>(YZl, Bl, whole ? SEG + DT_SEGS - 2 : SEG, whole ? 1 : P, BELOW + line, ZLO + line, lpb, os);
       P2 eyz = YZl[e];
       // the link below the current piece waits in a register, so a step down issues its two LDS reads (the piece and ITS
-      // link) at once: one round trip per step.  (Rounds 1-3 kept the whole piece below in registers as well — a step then
-      // starts without a wait, but rotating that state costs five register moves per step.  Measured and rejected in round 4:
+      // link) at once: one round trip per step.  (Measured and rejected in round 4:
       // the read-out as a flat state machine like the scans, one output OR one step per iteration — 0.371 ms per frame
       // instead of 0.329: most outputs need no step, and the flat form makes every one of them wait for a speculative read.)
       // The bottom of the stack (z = -inf, linked to itself) ends every walk.
       int nx = (int)Bl[e];
+      // Round 6, session 39: the piece below and ITS link wait in registers again — a step down is register moves, and the LDS reads it issues (the piece after
+      // that) are only needed one step later: in a single frame's launches the read-out is a chain of such steps (almost every output has a lane of the wavefront
+      // stepping), dp_min alone 0.494 -> 0.489 ms, 0.296 -> 0.295 in batches (round 4 had removed the prefetch for four vector instructions per step, when issue
+      // slots were all that counted).
+      P2 nyz = YZl[nx];
+      int nnx = (int)Bl[nx];
       const int nlines = g.nlines;
       GPW(T) dp = (GPW(T))mp.dst + li + (size_t)(q1 - 1) * nlines;      // running output pointers: no 64-bit multiply per element
       GPW(int16_t) ppq = (GPW(int16_t))pp + (size_t)(q1 - 1) * pst;
@@ -504,7 +509,7 @@ __device__ __forceinline__ void dt_block(char* smem, const DtTask& t, const DtGr
         do {                                   // (q0 < q1: at least one output)
           --os;
           const T fos = (T)os;                 // `z[k+1] < os`: int promoted to T (:174)
-          while (!(eyz.y < fos)) { e = nx; eyz = YZl[e]; nx = (int)Bl[e]; }
+          while (!(eyz.y < fos)) { e = nx; eyz = nyz; nx = nnx; nyz = YZl[nx]; nnx = (int)Bl[nx]; }
           const double d = (double)(os - e);   // |d| < 2^15: d * d is exact in fp64 (the reference squares the int)
           const double ad2 = a * (d * d);
           *dp = (T)((FZ ? fma(b, d, ad2) : (ad2 + b * d)) + (double)eyz.x);

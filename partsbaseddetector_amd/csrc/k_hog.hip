@@ -227,6 +227,9 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
   HOG_STAMP(1);
 
   // ---- per-pixel gradient magnitude + orientation bin (:202-249) ----
+  // (One pixel per thread and iteration.  Round 4 measured four unpredicated pixels in flight: 0.0543 against 0.0496 ms per frame; round 6 again, with the channel count at
+  //  compile time so that the pixels' LDS reads and table look-ups really go out together — 2 / 4 pixels: 0.0497 / 0.0495 against 0.0464 ms in batches, 0.0795 / 0.0790
+  //  against 0.0767 alone, profiles/r06/r06_session39_*: the phase is not waiting for one pixel's chain, and the unpredicated form works on the halo's invisible pixels.)
   for (int i = tid; i < PT * PT; i += HOG_NT) {
     const int wy = i / PT, wx = i - wy * PT;
     const int y = py0 + wy, x = px0 + wx;
