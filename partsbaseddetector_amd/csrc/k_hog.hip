@@ -77,7 +77,10 @@ struct HogLds {
   size_t mag_off, bin_off, hist_off, norm_off, ninv_off, tab_off, raw_off, out_off, total;
 };
 
-__host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int bpp, int ts) {   // ts = sizeof(T); bpp = bytes per pixel (channels x element size)
+// need_ip: the kernel reads the per-row / per-column block indices (ipy, ipx) — the generic walk of odd or run-time cell sizes; the compile-time even-cell instantiations do not,
+// and without the two tables the benched tile (4-pixel cells, 16 x 16 cells, 8-bit BGR) asks for 53 424 B instead of 54 032: THREE workgroups fit a CU's 160 KB instead of two
+// (round 6: the hardware allocates LDS in 1 280-byte granules — 43 of them x 3 = 165 120 B did not fit; SQ counters had shown ~11 resident wavefronts per CU, not 18)
+__host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int bpp, int ts, bool need_ip = true) {   // ts = sizeof(T); bpp = bytes per pixel (channels x element size)
   HogLds L;
   L.NB = tc + 2;
   // A pixel y feeds the blocks floor((y + 0.5) / sbin - 0.5) and the next one (:252-255): block b receives exactly the
@@ -105,12 +108,12 @@ __host__ __device__ inline HogLds hog_lds_layout(int sbin, int tc, int bpp, int 
   const size_t hist_bytes = (size_t)ts * L.NB * L.NB * PBD_NORIENT, raw_bytes = (size_t)L.RT * L.RP;
   L.hist_off = o; L.raw_off = o;
   o += ((hist_bytes > raw_bytes ? hist_bytes : raw_bytes) + 15) & ~(size_t)15;
-  L.tab_off = o; o += ((size_t)ts * 2 + sizeof(int)) * 2 * L.PT;  // w0,w1,ip for y and x
+  L.tab_off = o; o += ((size_t)ts * 2 + (need_ip ? sizeof(int) : 0)) * 2 * L.PT;  // w0, w1 (, ip) for y and x
   L.bin_off = (o + 3) & ~(size_t)3; o = L.bin_off + (size_t)L.PT * L.MP;
   L.total = (o + 15) & ~(size_t)15;
   return L;
 }
-size_t hog_lds_bytes(int sbin, int tc, int ts, int bpp) { return hog_lds_layout(sbin, tc, bpp, ts).total; }
+size_t hog_lds_bytes(int sbin, int tc, int ts, int bpp) { return hog_lds_layout(sbin, tc, bpp, ts).total; }   // (the planner's bound: with the index tables)
 
 #define HOG_NT 384   // threads per workgroup: (TC+2)^2 = 324 block histograms finish in one pass
 
@@ -132,7 +135,8 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
   const HogTile t = tiles[blockIdx.x];
   const LevelDev lv = levels[t.level];
   const int bpp = cn * (int)sizeof(IT);
-  const HogLds L = hog_lds_layout(sbin, tc, bpp, (int)sizeof(T));
+  constexpr bool NEED_IP = !(SBIN_T > 0 && (SBIN_T & 1) == 0);   // (the even compile-time cell sizes walk their blocks' footprints without the index tables)
+  const HogLds L = hog_lds_layout(sbin, tc, bpp, (int)sizeof(T), NEED_IP);
   T* mag = (T*)(smem + L.mag_off);
   uint8_t* bin = (uint8_t*)(smem + L.bin_off);
   uint8_t* raw = (uint8_t*)(smem + L.raw_off);
@@ -220,8 +224,8 @@ __global__ __launch_bounds__(HOG_NT, 5) void k_hog(const HogTile* __restrict__ t
     int ip = (int)t_floor(pp);
     T v0 = pp - (T)ip;
     T v1 = (T)(1.0 - (double)v0);
-    if (isx) { wx0[j] = v0; wx1[j] = v1; ipx[j] = ip; }
-    else { wy0[j] = v0; wy1[j] = v1; ipy[j] = ip; }
+    if (isx) { wx0[j] = v0; wx1[j] = v1; if constexpr (NEED_IP) ipx[j] = ip; }
+    else { wy0[j] = v0; wy1[j] = v1; if constexpr (NEED_IP) ipy[j] = ip; }
   }
   __syncthreads();
   HOG_STAMP(1);
@@ -455,19 +459,19 @@ template <typename T>
 static void launch_hog_t(const HogTile* tiles, int ntiles, const LevelDev* levels, const uint8_t* pyr, T* feat,
                          int cn, int sbin, int tc, const uint8_t* binlut, uint16_t* split, int split_parts, int depth, hipStream_t s) {
   const int esz = depth == PBD_DEPTH_16U ? 2 : depth == PBD_DEPTH_32F ? 4 : depth == PBD_DEPTH_64F ? 8 : 1;
-  const size_t lds = hog_lds_bytes(sbin, tc, (int)sizeof(T), cn * esz);
-  auto go = [&](auto kern) {
+  auto go = [&](auto kern, bool need_ip) {
+    const size_t lds = hog_lds_layout(sbin, tc, cn * esz, (int)sizeof(T), need_ip).total;   // (the kernel's own layout: NEED_IP)
     static LdsOptIn optin;  // one per instantiation (the lambda is instantiated per kernel), per-device state inside
     optin.ensure((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(HOG_NT), lds, s, tiles, levels, pyr, feat, cn, sbin, tc, binlut, split, split_parts);
   };
-  if (depth == PBD_DEPTH_16U) go(k_hog<T, 0, 0, uint16_t>);      // (the generic cell size / tile side instantiation: pbd_detect_image's depths)
-  else if (depth == PBD_DEPTH_32F) go(k_hog<T, 0, 0, float>);
-  else if (depth == PBD_DEPTH_64F) go(k_hog<T, 0, 0, double>);
-  else if (sbin == 4 && tc == 16) go(k_hog<T, 4, 16>);
-  else if (sbin == 4 && tc == 8) go(k_hog<T, 4, 8>);
-  else if (sbin == 8 && tc == 8) go(k_hog<T, 8, 8>);
-  else go(k_hog<T, 0, 0>);
+  if (depth == PBD_DEPTH_16U) go(k_hog<T, 0, 0, uint16_t>, true);      // (the generic cell size / tile side instantiation: pbd_detect_image's depths)
+  else if (depth == PBD_DEPTH_32F) go(k_hog<T, 0, 0, float>, true);
+  else if (depth == PBD_DEPTH_64F) go(k_hog<T, 0, 0, double>, true);
+  else if (sbin == 4 && tc == 16) go(k_hog<T, 4, 16>, false);
+  else if (sbin == 4 && tc == 8) go(k_hog<T, 4, 8>, false);
+  else if (sbin == 8 && tc == 8) go(k_hog<T, 8, 8>, false);
+  else go(k_hog<T, 0, 0>, true);
 }
 
 // ts = sizeof(T) of the handle's instantiation (HOGFeatures<float> / HOGFeatures<double>, src/HOGFeatures.cpp:51-52);

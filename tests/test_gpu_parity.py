@@ -451,6 +451,25 @@ def test_dt2d_ties_and_plateaus(small_handle, orc):
             np.testing.assert_array_equal(got[2], ref[2])
 
 
+def test_dt2d_fused_and_unfused_quadratics(small_handle, orc):
+    """Round 6: for float maps whose quadratics are converted floats (every map of a detector) the kernels fuse the numerator's exact
+    products into their additions (dt_core.hpp: dt_isect FUSED, DtGroup::fused); any other double keeps the unfused chain
+    (include/DistanceTransform.hpp:98-100).  Both forms, same maps, bit for bit against the oracle — weak curvature included (long pop
+    runs, redone stitches)."""
+    rng = np.random.default_rng(2026)
+    for (rows, cols) in ((118, 158), (31, 254), (64, 300)):
+        a = rng.normal(0, 1.5, (rows, cols)).astype(np.float32)
+        for w in (0.05, 0.012, 0.005):
+            fx, fy, fb = float(np.float32(w)), float(np.float32(w * 0.7)), float(np.float32(0.004))
+            for (ax, bx, ay, by) in ((-fx, -fb, -fy, fb),                                  # converted floats: fused
+                                     (-fx * (1 + 2.0 ** -40), -fb, -fy, fb * (1 - 2.0 ** -45))):   # not representable as floats: unfused
+                got = small_handle.dt2d(a, ax, bx, ay, by, 2, -3)
+                ref = orc.dt2d(a, ax, bx, ay, by, 2, -3)
+                np.testing.assert_array_equal(got[0].view(np.uint32), ref[0].view(np.uint32))
+                np.testing.assert_array_equal(got[1], ref[1])
+                np.testing.assert_array_equal(got[2], ref[2])
+
+
 def test_dt2d_is_max_plus_transform(small_handle):
     """Property (size independent): scores equal the brute-force max-plus transform."""
     rng = np.random.default_rng(3)
